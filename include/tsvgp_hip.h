@@ -1,0 +1,114 @@
+/*
+ * tsvgp_hip.h -- C ABI of the MI355X (gfx950) t-SVGP natural-gradient E-step kernels.
+ *
+ * The reference (AaltoML/t-SVGP) is pure Python on TensorFlow/GPflow and has NO FFI;
+ * this header is the seam introduced *under* its Python API.
+ * Every entry point replaces a group of TensorFlow ops on the hot path
+ * `t_SVGP.natgrad_step` (reference src/models/tsvgp.py:234-304); the citation on each
+ * declaration names the reference lines it stands in for.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no torch / C++ types.
+ *   - All pointers are DEVICE pointers (caller-allocated, caller-owned); `stream` is a
+ *     hipStream_t passed as void* (NULL = default stream).  No global state, no
+ *     allocation, no synchronisation inside: safe to capture into a hipGraph.
+ *   - Suffix _f64 / _f32 selects the arithmetic type T of the N-sized arrays.
+ *   - "Padded" dimensions: Np = N rounded up to 128, Mp = M rounded up to 128.  Work
+ *     buffers (Kfu, B) are [Np x Mp] row-major with the padding ZERO-filled by the
+ *     producing kernel, so the MFMA kernels need no bounds checks.
+ *   - Return value: 0 ok; 1 invalid argument; 2 launch failure (hipGetLastError != 0).
+ */
+#ifndef TSVGP_HIP_H
+#define TSVGP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TSVGP_OK 0
+#define TSVGP_EINVAL 1
+#define TSVGP_ELAUNCH 2
+
+#define TSVGP_TILE 128 /* padding granule of N and M */
+
+/* likelihood selectors for tsvgp_moments_* */
+#define TSVGP_LIK_NONE 0      /* moments only (predict_f) */
+#define TSVGP_LIK_GAUSSIAN 1  /* gpflow.likelihoods.Gaussian: closed form */
+#define TSVGP_LIK_BERNOULLI 2 /* gpflow.likelihoods.Bernoulli, probit + 1e-3 jitter, 20-pt Gauss-Hermite */
+
+/* k-range selectors of the panel product C[n,i] = sum_j A[n,j] * Tm[i,j] */
+#define TSVGP_TRI_LOWER 0 /* j <= i  (forward substitution with the inverted factor)   */
+#define TSVGP_TRI_UPPER 1 /* j >= i  (product with a transposed lower factor)         */
+#define TSVGP_TRI_DENSE 2 /* all j                                                    */
+
+/* Library / build identification: returns a static string "tsvgp_hip gfx950 <version>". */
+const char *tsvgp_version(void);
+
+/* Upper bound on the number of workgroup slots the site-accumulation kernel can keep resident
+ * (CUs x resident workgroups per CU for that kernel); used by the host to choose `nsplit`. */
+int tsvgp_site_accum_slots_f64(void);
+int tsvgp_site_accum_slots_f32(void);
+
+/* (1) Kernel-matrix fill: squared-exponential K(X, Z) -> K[n, m] = variance * exp(-0.5 * sum_d ((x_nd - z_md) * inv_ls_d)^2)
+ *     Replaces gpflow.covariances.Kuf / Kuu (reference src/models/tsvgp.py:209-211, 222-225, 268-269).
+ *     X [N x D] row-major, Z [M x D] row-major, inv_ls [D] (1/lengthscale per dimension),
+ *     K [rows_alloc x ldk] row-major with rows_alloc >= round_up(N,128) and ldk >= round_up(M,128); entries with n >= N or
+ *     m >= M (up to the padded extents) are written as 0. */
+int tsvgp_se_fill_f64(const double *X, const double *Z, const double *inv_ls, double variance, double *K, int64_t N,
+                      int M, int D, int64_t ldk, void *stream);
+int tsvgp_se_fill_f32(const float *X, const float *Z, const float *inv_ls, float variance, float *K, int64_t N, int M,
+                      int D, int64_t ldk, void *stream);
+
+/* (2) Blocked triangular solve with an N-sized right-hand side, in inverted-factor form:
+ *        C[n, i] = sum_{j in range(i)} A[n, j] * Tm[i, j],   range = j<=i | j>=i | all j   (mode)
+ *     With Tm = inv(chol(Kuu + jitter I)) and mode LOWER this is B = Kfu * L^-T, i.e. the forward substitution
+ *     L^-1 Kuf of tf.linalg.cholesky_solve / triangular_solve (reference src/models/tsvgp.py:270-271 and GPflow's
+ *     conditional behind :103), done as MFMA tile products.
+ *     A, C [Np x Mp] row-major (lda/ldc = Mp), Tm [Mp x Mp] row-major, zero outside its triangle/valid block. */
+int tsvgp_trmm_f64(const double *A, const double *Tm, double *C, int64_t Np, int Mp, int mode, void *stream);
+int tsvgp_trmm_f32(const float *A, const float *Tm, float *C, int64_t Np, int Mp, int mode, void *stream);
+
+/* (3)+(4) Fused predictive moments and likelihood-gradient map.
+ *     For every row n < N and latent p < P:
+ *        q    = sum_i ( sum_{j in range(i)} A[n,j] * Tm[p][i,j] )^2
+ *        mean = sum_j A[n,j] * gamma[j*P + p]
+ *        var  = kdiag - q
+ *     then (lik != NONE)  g0 = d ve/d mean,  g1 = min(d ve/d var, -1e-8),  ve_sum += ve.
+ *     Replaces base_SVGP.predict_f / GPflow conditional (reference src/models/tsvgp.py:97-114, :246), the site-form
+ *     predictive (src/util.py:175-184), likelihood.variational_expectations + GradientTape (:256-259) and the crop (:262-263).
+ *     A [Np x Mp]; Tm [P x Mp x Mp]; gamma [Mp x P]; Y [N x P]; outputs mean,var [N x P] (may be NULL),
+ *     g0,g1 [Np x P] (rows >= N written as 0; may be NULL when lik == NONE);
+ *     ve_partial [Np/128] doubles (per-workgroup sums of ve; may be NULL when lik == NONE);
+ *     nonpos_partial [Np/128] int32 (count of var <= 0, the tf.debugging.assert_positive of :113).
+ *     lik_param: Gaussian noise variance (ignored otherwise). */
+int tsvgp_moments_f64(const double *A, const double *Tm, const double *gamma, const double *Y, double kdiag, int lik,
+                      double lik_param, double *mean, double *var, double *g0, double *g1, double *ve_partial,
+                      int32_t *nonpos_partial, int64_t N, int64_t Np, int Mp, int P, int mode, void *stream);
+int tsvgp_moments_f32(const float *A, const float *Tm, const float *gamma, const float *Y, double kdiag, int lik,
+                      double lik_param, float *mean, float *var, float *g0, float *g1, double *ve_partial,
+                      int32_t *nonpos_partial, int64_t N, int64_t Np, int Mp, int P, int mode, void *stream);
+
+/* (5) Site accumulation (the two einsums of reference src/models/tsvgp.py:278-281 in whitened coordinates):
+ *        acc2[p][i][j] = sum_n g1[n,p] * B[n,i] * B[n,j]        (full symmetric [P x Mp x Mp], fp64)
+ *        acc1[p][i]    = sum_n g0[n,p] * B[n,i]                 ([P x Mp], fp64)
+ *     B [Np x Mp]; g0,g1 [Np x P] with rows >= N equal to 0.
+ *     The N range is cut into `nsplit` slices; partial tiles go to `work` and are summed in a fixed order (bitwise
+ *     reproducible; no atomics).  work must hold tsvgp_site_accum_work_bytes_*(Mp, P, nsplit) bytes. */
+int64_t tsvgp_site_accum_work_bytes_f64(int Mp, int P, int nsplit);
+int64_t tsvgp_site_accum_work_bytes_f32(int Mp, int P, int nsplit);
+int tsvgp_site_accum_f64(const double *B, const double *g0, const double *g1, double *acc2, double *acc1, void *work,
+                         int64_t Np, int Mp, int P, int nsplit, void *stream);
+int tsvgp_site_accum_f32(const float *B, const float *g0, const float *g1, double *acc2, double *acc1, void *work,
+                         int64_t Np, int Mp, int P, int nsplit, void *stream);
+
+/* Device self-test of the MFMA fragment maps used above (writes a 16x16 product C = A*B, k = 4, for host checking).
+ * a [16 x 4], b [4 x 16], c [16 x 16] row-major. */
+int tsvgp_selftest_mfma_f64(const double *a, const double *b, double *c, void *stream);
+int tsvgp_selftest_mfma_f32(const float *a, const float *b, float *c, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TSVGP_HIP_H */

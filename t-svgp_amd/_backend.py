@@ -1,0 +1,115 @@
+"""ctypes binding of the C-ABI HIP library (include/tsvgp_hip.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` (or ``build_library()`` below) as
+``t-svgp_amd/csrc/libtsvgp_hip.so``.  There is NO fallback: if the library is missing or a tensor is not
+on a ROCm device the product path raises -- it never silently computes on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from ctypes import c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libtsvgp_hip.so")
+HEADER_PATH = os.path.join(_ROOT, "include", "tsvgp_hip.h")
+SOURCES = [os.path.join(CSRC, "tsvgp_kernels.hip")]
+
+TILE = 128
+LIK_NONE, LIK_GAUSSIAN, LIK_BERNOULLI = 0, 1, 2
+TRI_LOWER, TRI_UPPER, TRI_DENSE = 0, 1, 2
+
+_lib = None
+
+
+class HipExtensionError(RuntimeError):
+    """The HIP extension is missing, failed to load, or a kernel launch was rejected."""
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    """Compile the HIP sources for gfx950 with hipcc (cross-compiles without a GPU)."""
+    if not force and os.path.exists(LIB_PATH):
+        newest = max(os.path.getmtime(p) for p in SOURCES + [HEADER_PATH])
+        if os.path.getmtime(LIB_PATH) >= newest:
+            return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC",
+           "-I", os.path.join(_ROOT, "include"), *SOURCES, "-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise HipExtensionError("hipcc failed:\n" + res.stdout + res.stderr)
+    return LIB_PATH
+
+
+_PROTOTYPES = {
+    # name: (restype, argtypes)
+    "tsvgp_version": (c_char_p, []),
+    "tsvgp_site_accum_slots_f64": (c_int, []),
+    "tsvgp_site_accum_slots_f32": (c_int, []),
+    "tsvgp_se_fill_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_double, c_void_p, c_int64, c_int, c_int, c_int64, c_void_p]),
+    "tsvgp_se_fill_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int, c_int, c_int64, c_void_p]),
+    "tsvgp_trmm_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "tsvgp_trmm_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "tsvgp_moments_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_int, c_double, c_void_p, c_void_p,
+                                  c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_void_p]),
+    "tsvgp_moments_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_int, c_double, c_void_p, c_void_p,
+                                  c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_void_p]),
+    "tsvgp_site_accum_work_bytes_f64": (c_int64, [c_int, c_int, c_int]),
+    "tsvgp_site_accum_work_bytes_f32": (c_int64, [c_int, c_int, c_int]),
+    "tsvgp_site_accum_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
+    "tsvgp_site_accum_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
+    "tsvgp_selftest_mfma_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "tsvgp_selftest_mfma_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+}
+
+
+def exported_symbols():
+    """Names every entry point of include/tsvgp_hip.h (kept in sync by tests/test_cabi.py)."""
+    return sorted(_PROTOTYPES)
+
+
+def lib():
+    """Load (once) and return the ctypes handle.  Raises HipExtensionError if the library is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipExtensionError(
+            f"HIP extension not built: {LIB_PATH} is missing. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for the E-step."
+        )
+    try:
+        handle = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover - depends on the box
+        raise HipExtensionError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (restype, argtypes) in _PROTOTYPES.items():
+        fn = getattr(handle, name)
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = handle
+    return _lib
+
+
+def check(status: int, what: str):
+    if status != 0:
+        msg = {1: "invalid argument", 2: "kernel launch failure"}.get(status, f"status {status}")
+        raise HipExtensionError(f"{what}: {msg}")
+
+
+def suffix(dtype) -> str:
+    import torch
+
+    if dtype == torch.float64:
+        return "f64"
+    if dtype == torch.float32:
+        return "f32"
+    raise TypeError(f"unsupported compute dtype {dtype}; use torch.float64 or torch.float32")
+
+
+def round_up(n: int, m: int = TILE) -> int:
+    return (int(n) + m - 1) // m * m

@@ -1,0 +1,81 @@
+"""Minimal GPflow-style parameter container on torch tensors.
+
+Stands in for ``gpflow.base.Parameter`` / ``gpflow.config`` as used by the reference hot path
+(reference src/sites.py:9-11,56,63; src/models/tsvgp.py:18,177,210).  Only what the E-step touches is
+mirrored: ``assign``, ``numpy``, float64 default, ``default_jitter() == 1e-6``.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+_DEFAULT_FLOAT = torch.float64
+_DEFAULT_JITTER = 1e-6
+
+
+def default_float():
+    """gpflow.config.default_float() [ext]: the reference path is fp64-only (tsvgp.py:265)."""
+    return _DEFAULT_FLOAT
+
+
+def default_jitter():
+    """gpflow.config.default_jitter() [ext] = 1e-6."""
+    return _DEFAULT_JITTER
+
+
+def default_device() -> torch.device:
+    return torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+
+
+def to_tensor(value, dtype=None, device=None) -> torch.Tensor:
+    dtype = dtype or _DEFAULT_FLOAT
+    device = device or default_device()
+    if isinstance(value, Parameter):
+        value = value.value
+    if isinstance(value, torch.Tensor):
+        return value.to(device=device, dtype=dtype)
+    return torch.as_tensor(np.asarray(value), dtype=dtype).to(device)
+
+
+class Parameter:
+    """Holds one tensor; ``assign`` replaces its value in place (shape-checked)."""
+
+    def __init__(self, value, dtype=None, trainable=True, name=None, device=None):
+        self._value = to_tensor(value, dtype, device).clone()
+        self.trainable = trainable
+        self.name = name
+
+    @property
+    def value(self) -> torch.Tensor:
+        return self._value
+
+    @property
+    def shape(self):
+        return tuple(self._value.shape)
+
+    @property
+    def dtype(self):
+        return self._value.dtype
+
+    @property
+    def device(self):
+        return self._value.device
+
+    def assign(self, value):
+        new = to_tensor(value, self._value.dtype, self._value.device)
+        if new.dim() == 0 and self._value.dim() > 0:
+            new = new.expand_as(self._value)
+        if tuple(new.shape) != tuple(self._value.shape):
+            raise ValueError(f"assign: shape {tuple(new.shape)} does not match {tuple(self._value.shape)}")
+        self._value = new.clone()
+        return self
+
+    def numpy(self) -> np.ndarray:
+        return self._value.detach().cpu().numpy()
+
+    def __array__(self, dtype=None):
+        a = self.numpy()
+        return a.astype(dtype) if dtype is not None else a
+
+    def __repr__(self):
+        return f"Parameter(shape={self.shape}, dtype={self.dtype}, device={self.device})"

@@ -1,0 +1,800 @@
+// tsvgp_kernels.hip -- hand-written CDNA4 (gfx950 / MI355X) kernels for the t-SVGP natural-gradient E-step.
+//
+// Hot path replaced: t_SVGP.natgrad_step, reference src/models/tsvgp.py:234-304 (see include/tsvgp_hip.h for the
+// per-entry-point citations).  Written for gfx950 only: 64-wide wavefronts, v_mfma_f64_16x16x4_f64 /
+// v_mfma_f32_16x16x4_f32 matrix instructions, 160 KiB LDS per CU, 256 CUs in 8 XCDs.
+//
+// Kernel inventory
+//   se_fill_kernel      K(X,Z) tile fill.  HBM-write bound (N*Mp*sizeof(T) bytes).  Z tile and X rows staged in LDS,
+//                       16-byte coalesced stores.
+//   panel_kernel<STORE> C = A * Tm^T restricted to a triangular k-range (inverted-factor triangular solve).  MFMA bound.
+//   panel_kernel<MOMENTS>  same product, but the tile is squared and row-summed in registers (never stored), a GEMV from
+//                       the staging registers forms the mean, and the likelihood-gradient map runs in the epilogue.
+//   syrk_kernel         weighted Gram  sum_n g1[n] b_n b_n^T  over an N-slice per workgroup (lower tiles only) + the
+//                       first-order sum on diagonal tiles.  MFMA bound.  Partial tiles -> syrk_reduce_kernel (fixed order).
+//
+// Tiling shared by the MFMA kernels: 128x128 output tile per 256-thread workgroup (4 waves as 2x2, 64x64 per wave =
+// 4x4 MFMA tiles of 16x16, 16 accumulator vectors), k-chunks of 16 staged global->registers->LDS with two LDS buffers
+// and one barrier per chunk; 2 workgroups per CU (73.7 KB LDS, <=256 VGPRs each) so one workgroup's barrier and staging
+// hide under the other's MFMAs.  LDS images are padded so that every fragment read (ds_read_b64 / _b32) and every
+// staging write is bank-conflict free:  [row][k] images use a row stride of 18 elements, [k][row] images a k stride of
+// 144 elements.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "tsvgp_hip.h"
+
+namespace {
+
+constexpr int TILE = TSVGP_TILE;  // 128
+constexpr int KC = 16;            // k-chunk
+constexpr int LDS_RS = 18;        // [row][k] image: row stride (elements)
+constexpr int LDS_KS = 144;       // [k][row] image: k stride (elements)
+constexpr int NTHREADS = 256;
+constexpr int MODE_STORE = 0;
+constexpr int MODE_MOMENTS = 1;
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// ---------------------------------------------------------------------------------------------------------------
+// MFMA wrappers.  A operand: lane l holds A[i = l&15][k = l>>4]; B operand: lane l holds B[k = l>>4][j = l&15].
+// C/D: column = l&15 for both types; row = (l>>4) + 4*r for f64, (l>>4)*4 + r for f32 (r = register index 0..3).
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+struct Mfma;
+template <>
+struct Mfma<double> {
+    typedef v4d acc_t;
+    typedef v2d pair_t;
+    static __device__ __forceinline__ acc_t run(double a, double b, acc_t c) {
+        return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ int row(int lane, int r) { return (lane >> 4) + 4 * r; }
+};
+template <>
+struct Mfma<float> {
+    typedef v4f acc_t;
+    typedef v2f pair_t;
+    static __device__ __forceinline__ acc_t run(float a, float b, acc_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ int row(int lane, int r) { return (lane >> 4) * 4 + r; }
+};
+
+// 8 consecutive elements of one row: global -> registers (16-byte loads) and registers -> LDS.
+template <typename T>
+__device__ __forceinline__ void load8(T (&r)[8], const T* __restrict__ p) {
+    if constexpr (sizeof(T) == 8) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            v2d v = *reinterpret_cast<const v2d*>(p + 2 * q);
+            r[2 * q] = v[0];
+            r[2 * q + 1] = v[1];
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            v4f v = *reinterpret_cast<const v4f*>(p + 4 * q);
+            r[4 * q] = v[0];
+            r[4 * q + 1] = v[1];
+            r[4 * q + 2] = v[2];
+            r[4 * q + 3] = v[3];
+        }
+    }
+}
+template <typename T>
+__device__ __forceinline__ void store_pairs8(T* p, const T (&r)[8]) {
+    typedef typename Mfma<T>::pair_t pair_t;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        pair_t v;
+        v[0] = r[2 * q];
+        v[1] = r[2 * q + 1];
+        *reinterpret_cast<pair_t*>(p + 2 * q) = v;
+    }
+}
+
+// One k-chunk (16) of MFMAs on [row][k] images: acc[mt][nt] += A(64 x 16) * B(64 x 16)^T for this wave.
+template <typename T>
+__device__ __forceinline__ void mma_chunk_rowk(typename Mfma<T>::acc_t (&acc)[4][4], const T* __restrict__ As,
+                                               const T* __restrict__ Bs, int wm, int wn, int lane) {
+    const int lr = lane & 15, lk = lane >> 4;
+    const T* ap = As + (wm * 64 + lr) * LDS_RS + lk;
+    const T* bp = Bs + (wn * 64 + lr) * LDS_RS + lk;
+#pragma unroll
+    for (int ks = 0; ks < KC / 4; ++ks) {
+        T a[4], b[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) a[m] = ap[m * 16 * LDS_RS + ks * 4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) b[n] = bp[n * 16 * LDS_RS + ks * 4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[m][n] = Mfma<T>::run(a[m], b[n], acc[m][n]);
+    }
+}
+
+// One k-chunk (16) of MFMAs on [k][row] images.
+template <typename T>
+__device__ __forceinline__ void mma_chunk_krow(typename Mfma<T>::acc_t (&acc)[4][4], const T* __restrict__ As,
+                                               const T* __restrict__ Bs, int wm, int wn, int lane) {
+    const int lr = lane & 15, lk = lane >> 4;
+    const T* ap = As + lk * LDS_KS + wm * 64 + lr;
+    const T* bp = Bs + lk * LDS_KS + wn * 64 + lr;
+#pragma unroll
+    for (int ks = 0; ks < KC / 4; ++ks) {
+        T a[4], b[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) a[m] = ap[ks * 4 * LDS_KS + m * 16];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) b[n] = bp[ks * 4 * LDS_KS + n * 16];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[m][n] = Mfma<T>::run(a[m], b[n], acc[m][n]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Likelihood maps (fp64 regardless of T).  Restates gpflow.likelihoods.{Gaussian,Bernoulli}.variational_expectations
+// and its tf.GradientTape derivative (reference src/models/tsvgp.py:256-263).
+// ---------------------------------------------------------------------------------------------------------------
+__device__ const double GH_X[10] = {  // positive nodes of 20-pt Gauss-Hermite, times sqrt(2)
+    3.46964157081355917e-01, 1.04294534880275114e+00, 1.74524732081412703e+00, 2.45866361117236787e+00,
+    3.18901481655339003e+00, 3.94396735065731630e+00, 4.73458133404605519e+00, 5.57873880589320148e+00,
+    6.51059015701365507e+00, 7.61904854167975909e+00};
+__device__ const double GH_W[10] = {  // matching weights / sqrt(pi)
+    2.60793063449554885e-01, 1.61739333983999978e-01, 6.15063720639768968e-02, 1.39978374471010220e-02,
+    1.83010313108049002e-03, 1.28826279961929280e-04, 4.40212109023085101e-06, 6.12749025998292797e-08,
+    2.48206236231517553e-10, 1.25780067243792340e-13};
+
+__device__ __forceinline__ void bern_point(double f, bool y1, double& lp, double& dl) {
+    const double jit = 1e-3;
+    const double p = 0.5 * (1.0 + erf(f * 0.70710678118654752440)) * (1.0 - 2.0 * jit) + jit;
+    const double dp = (1.0 - 2.0 * jit) * 0.39894228040143267794 * exp(-0.5 * f * f);
+    if (y1) {
+        lp = log(p);
+        dl = dp / p;
+    } else {
+        const double q = 1.0 - p;
+        lp = log(q);
+        dl = -dp / q;
+    }
+}
+
+__device__ __forceinline__ void lik_eval(int lik, double s2, double m, double v, double y, double& g0, double& g1,
+                                         double& ve) {
+    if (lik == TSVGP_LIK_GAUSSIAN) {
+        const double r = y - m;
+        g0 = r / s2;
+        g1 = -0.5 / s2;
+        ve = -0.5 * 1.83787706640934548356 - 0.5 * log(s2) - 0.5 * (r * r + v) / s2;
+    } else {  // Bernoulli, probit, 20-pt Gauss-Hermite; derivative OF the quadrature sum
+        const double sd = sqrt(v);
+        const bool y1 = (y == 1.0);
+        double a0 = 0.0, a1 = 0.0, av = 0.0;
+#pragma unroll 1
+        for (int i = 0; i < 10; ++i) {
+            const double z = GH_X[i], w = GH_W[i];
+            double lp, dl;
+            bern_point(m + sd * z, y1, lp, dl);
+            av += w * lp;
+            a0 += w * dl;
+            a1 += w * dl * z;
+            bern_point(m - sd * z, y1, lp, dl);
+            av += w * lp;
+            a0 += w * dl;
+            a1 -= w * dl * z;
+        }
+        g0 = a0;
+        g1 = a1 / (2.0 * sd);
+        ve = av;
+    }
+    g1 = fmin(g1, -1e-8);  // reference tsvgp.py:262-263
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// se_fill_kernel: K[n, m] = variance * exp(-0.5 * sum_d ((x_nd - z_md) * inv_ls_d)^2), zero in the padding.
+// grid = (row blocks of FILL_ROWS, column tiles of FILL_COLS); each thread owns two adjacent columns.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int FILL_ROWS = 64;
+constexpr int FILL_COLS = 512;
+
+template <typename T>
+__global__ __launch_bounds__(NTHREADS) void se_fill_kernel(const T* __restrict__ X, const T* __restrict__ Z,
+                                                           const T* __restrict__ inv_ls, T variance,
+                                                           T* __restrict__ K, int64_t N, int M, int D, int64_t ldk,
+                                                           int64_t rows_pad, int cols_pad) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* Zs = reinterpret_cast<T*>(smem_raw);  // [D][FILL_COLS], pre-scaled by inv_ls
+    T* Xs = Zs + (size_t)D * FILL_COLS;      // [FILL_ROWS][D], pre-scaled
+    typedef typename Mfma<T>::pair_t pair_t;
+
+    const int t = threadIdx.x;
+    const int64_t n0 = (int64_t)blockIdx.x * FILL_ROWS;
+    const int m0 = blockIdx.y * FILL_COLS;
+
+    for (int idx = t; idx < FILL_COLS * D; idx += NTHREADS) {
+        const int mm = idx / D, d = idx - mm * D;  // coalesced read of Z rows
+        const int m = m0 + mm;
+        Zs[d * FILL_COLS + mm] = (m < M) ? Z[(int64_t)m * D + d] * inv_ls[d] : T(0);
+    }
+    for (int idx = t; idx < FILL_ROWS * D; idx += NTHREADS) {
+        const int rr = idx / D, d = idx - rr * D;
+        const int64_t n = n0 + rr;
+        Xs[idx] = (n < N) ? X[n * D + d] * inv_ls[d] : T(0);
+    }
+    __syncthreads();
+
+    const int c = 2 * t;  // local column pair
+    const int m = m0 + c;
+    if (m >= cols_pad) return;
+    const bool v0 = (m < M), v1 = (m + 1 < M);
+#pragma unroll 2
+    for (int rr = 0; rr < FILL_ROWS; ++rr) {
+        const int64_t n = n0 + rr;
+        if (n >= rows_pad) break;
+        T s0 = T(0), s1 = T(0);
+        const T* xr = Xs + rr * D;
+        for (int d = 0; d < D; ++d) {
+            const T x = xr[d];
+            const pair_t z = *reinterpret_cast<const pair_t*>(Zs + d * FILL_COLS + c);
+            const T d0 = x - z[0], d1 = x - z[1];
+            s0 += d0 * d0;
+            s1 += d1 * d1;
+        }
+        pair_t out;
+        const bool rowok = (n < N);
+        out[0] = (rowok && v0) ? variance * exp(T(-0.5) * s0) : T(0);
+        out[1] = (rowok && v1) ? variance * exp(T(-0.5) * s1) : T(0);
+        *reinterpret_cast<pair_t*>(K + n * ldk + m) = out;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// panel_kernel: one workgroup per 128-row panel of A; loops over latents p, output column tiles `it`, k-chunks.
+//   C[n, i] = sum_{j in range(i)} A[n, j] * Tm[p][i, j]
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+struct PanelArgs {
+    const T* A;      // [Np x Mp]
+    const T* Tm;     // [P x Mp x Mp]
+    T* C;            // STORE: [Np x Mp]
+    const T* gamma;  // MOMENTS: [Mp x P]
+    const T* Y;      // [N x P]
+    T* mean;         // [N x P] or null
+    T* var;          // [N x P] or null
+    T* g0;           // [Np x P] or null
+    T* g1;           // [Np x P] or null
+    double* ve_partial;
+    int32_t* nonpos_partial;
+    double kdiag, lik_param;
+    int64_t N, Np;
+    int Mp, P, mode, lik;
+};
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(NTHREADS, 2) void panel_kernel(PanelArgs<T> a) {
+    __shared__ __attribute__((aligned(16))) T lds[2][2][TILE * LDS_RS];
+    __shared__ double rowq[2][TILE];
+    __shared__ double red[NTHREADS / 64];
+    __shared__ int redi[NTHREADS / 64];
+    typedef typename Mfma<T>::acc_t acc_t;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
+    const int srow = t >> 1, skh = t & 1;  // staging role: row of the tile, which half of the k-chunk
+    const int64_t n0 = (int64_t)blockIdx.x * TILE;
+    const int Mp = a.Mp;
+    const int ntile = Mp / TILE, nchunk = Mp / KC;
+    const int gemv_it = (a.mode == TSVGP_TRI_LOWER) ? ntile - 1 : 0;  // the pass whose k-range covers every j
+
+    const T* Arow = a.A + (n0 + srow) * (int64_t)Mp + skh * 8;
+    double ve_acc = 0.0;
+    int nonpos = 0;
+
+    for (int p = 0; p < a.P; ++p) {
+        const T* Tp = a.Tm + (size_t)p * Mp * Mp;
+        // Row sums of squares: after every column tile the 16 per-register partials are summed over the 16 lanes that
+        // share (lane>>4) and lane lr keeps the one with index lr (m = lr>>2, r = lr&3): one live double, not 16.
+        double rs_mine = 0.0;
+        T mpart = T(0);
+
+        for (int it = 0; it < ntile; ++it) {
+            int c_lo = 0, c_hi = nchunk;
+            if (a.mode == TSVGP_TRI_LOWER) c_hi = (it + 1) * (TILE / KC);
+            if (a.mode == TSVGP_TRI_UPPER) c_lo = it * (TILE / KC);
+            const bool do_gemv = (MODE == MODE_MOMENTS) && (it == gemv_it);
+            const T* Trow = Tp + (size_t)(it * TILE + srow) * Mp + skh * 8;
+
+            acc_t acc[4][4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) acc[m][n] = acc_t{0, 0, 0, 0};
+
+            T ra[8], rb[8];
+            load8(ra, Arow + c_lo * KC);
+            load8(rb, Trow + c_lo * KC);
+            if (do_gemv) {
+                const T* g = a.gamma + (size_t)(c_lo * KC + skh * 8) * a.P + p;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) mpart += ra[q] * g[q * a.P];
+            }
+            store_pairs8(&lds[0][0][srow * LDS_RS + skh * 8], ra);
+            store_pairs8(&lds[0][1][srow * LDS_RS + skh * 8], rb);
+            __syncthreads();
+
+            int buf = 0;
+            for (int c = c_lo; c < c_hi; ++c) {
+                const bool has_next = (c + 1 < c_hi);
+                if (has_next) {
+                    load8(ra, Arow + (c + 1) * KC);
+                    load8(rb, Trow + (c + 1) * KC);
+                }
+                mma_chunk_rowk<T>(acc, lds[buf][0], lds[buf][1], wm, wn, lane);
+                if (has_next) {
+                    if (do_gemv) {
+                        const T* g = a.gamma + (size_t)((c + 1) * KC + skh * 8) * a.P + p;
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) mpart += ra[q] * g[q * a.P];
+                    }
+                    store_pairs8(&lds[buf ^ 1][0][srow * LDS_RS + skh * 8], ra);
+                    store_pairs8(&lds[buf ^ 1][1][srow * LDS_RS + skh * 8], rb);
+                }
+                __syncthreads();
+                buf ^= 1;
+            }
+
+            if constexpr (MODE == MODE_STORE) {
+                T* Cb = a.C + (n0 + wm * 64) * (int64_t)Mp + it * TILE + wn * 64 + (lane & 15);
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        T* Cr = Cb + (int64_t)(m * 16 + Mfma<T>::row(lane, r)) * Mp;
+#pragma unroll
+                        for (int n = 0; n < 4; ++n) Cr[n * 16] = acc[m][n][r];
+                    }
+            } else {
+                double keep = 0.0;
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        double s = 0.0;
+#pragma unroll
+                        for (int n = 0; n < 4; ++n) {
+                            const double v = (double)acc[m][n][r];
+                            s += v * v;
+                        }
+                        s += __shfl_xor(s, 1);
+                        s += __shfl_xor(s, 2);
+                        s += __shfl_xor(s, 4);
+                        s += __shfl_xor(s, 8);
+                        keep = ((lane & 15) == m * 4 + r) ? s : keep;
+                    }
+                rs_mine += keep;
+            }
+        }  // it
+
+        if constexpr (MODE == MODE_MOMENTS) {
+            // row sums: lane (lr, lane>>4) holds the sum of row (lr>>2)*16 + rowmap(lane, lr&3); add the two column waves through LDS
+            {
+                const int lr = lane & 15;
+                rowq[wn][wm * 64 + (lr >> 2) * 16 + Mfma<T>::row(lane, lr & 3)] = rs_mine;
+            }
+            mpart += __shfl_xor(mpart, 1);
+            __syncthreads();
+            if (skh == 0) {
+                const int64_t n = n0 + srow;
+                const double q = rowq[0][srow] + rowq[1][srow];
+                const double mu = (double)mpart;
+                const double v = a.kdiag - q;
+                double g0 = 0.0, g1 = 0.0, ve = 0.0;
+                if (n < a.N) {
+                    if (!(v > 0.0)) nonpos += 1;
+                    if (a.mean) a.mean[n * a.P + p] = (T)mu;
+                    if (a.var) a.var[n * a.P + p] = (T)v;
+                    if (a.lik != TSVGP_LIK_NONE) {
+                        lik_eval(a.lik, a.lik_param, mu, v, (double)a.Y[n * a.P + p], g0, g1, ve);
+                        ve_acc += ve;
+                    }
+                }
+                if (a.lik != TSVGP_LIK_NONE) {
+                    a.g0[n * a.P + p] = (T)g0;  // rows >= N: zeros (the padding contract of site_accum)
+                    a.g1[n * a.P + p] = (T)g1;
+                }
+            }
+            __syncthreads();  // rowq reused by the next latent
+        }
+    }  // p
+
+    if constexpr (MODE == MODE_MOMENTS) {
+        double s = ve_acc;
+        int c = nonpos;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            s += __shfl_xor(s, o);
+            c += __shfl_xor(c, o);
+        }
+        if (lane == 0) {
+            red[wave] = s;
+            redi[wave] = c;
+        }
+        __syncthreads();
+        if (t == 0) {
+            if (a.ve_partial) a.ve_partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+            if (a.nonpos_partial) a.nonpos_partial[blockIdx.x] = redi[0] + redi[1] + redi[2] + redi[3];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// syrk_kernel: workgroup (p, split s, lower tile (it, jt)) accumulates over its N-slice
+//   part2[128 x 128] = sum_n g1[n,p] B[n, it*128 + :] (x) B[n, jt*128 + :],   diagonal tiles also part1 = sum_n g0 B.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+struct SyrkArgs {
+    const T* B;   // [Np x Mp]
+    const T* g0;  // [Np x P]
+    const T* g1;  // [Np x P]
+    T* part2;     // [P][nsplit][ntri][128*128]
+    T* part1;     // [P][nsplit][Mp]
+    int64_t Np;
+    int Mp, P, nsplit, ntri;
+    int64_t chunks_per_split;  // in units of KC rows
+};
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    // bijective remap: workgroups that share blockIdx % 8 (one XCD under round-robin dispatch) get a contiguous range
+    const int q = nwg / 8, r = nwg % 8, xcd = bid % 8;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+}
+
+template <typename T>
+__global__ __launch_bounds__(NTHREADS, 2) void syrk_kernel(SyrkArgs<T> a) {
+    __shared__ __attribute__((aligned(16))) T lds[2][2][KC * LDS_KS];
+    __shared__ T g0s[2][KC];
+    typedef typename Mfma<T>::acc_t acc_t;
+    typedef typename Mfma<T>::pair_t pair_t;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
+    const int lin = xcd_remap(blockIdx.x, gridDim.x);
+    const int tri = lin % a.ntri;
+    const int s = (lin / a.ntri) % a.nsplit;
+    const int p = lin / (a.ntri * a.nsplit);
+    int it = 0;
+    while ((it + 1) * (it + 2) / 2 <= tri) ++it;
+    const int jt = tri - it * (it + 1) / 2;
+    const bool diag = (it == jt);
+    const int Mp = a.Mp, P = a.P;
+
+    const int64_t total_chunks = a.Np / KC;
+    const int64_t c_lo = (int64_t)s * a.chunks_per_split;
+    int64_t c_hi = c_lo + a.chunks_per_split;
+    if (c_hi > total_chunks) c_hi = total_chunks;
+
+    // staging role: k-row of the chunk and four 16-byte pieces (2 doubles / 2 floats x2) spread over the 128 columns
+    const int krow = t >> 4, cseg = t & 15;
+    constexpr int PW = 2;  // elements per piece handled as a pair
+    // per thread: 4 pieces at columns q*32 + cseg*2 (+0,1)  -> 8 elements of the i panel and 8 of the j panel
+    const T* Bi = a.B + (int64_t)krow * Mp + it * TILE + cseg * PW;
+    const T* Bj = a.B + (int64_t)krow * Mp + jt * TILE + cseg * PW;
+
+    acc_t acc[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = acc_t{0, 0, 0, 0};
+    T acc1 = T(0);
+
+    pair_t ri[4], rj[4];
+    T w1 = T(0), w0 = T(0);
+    auto load_chunk = [&](int64_t c) {
+        const int64_t n = c * KC + krow;
+        const T* bi = Bi + c * KC * (int64_t)Mp;
+        const T* bj = Bj + c * KC * (int64_t)Mp;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ri[q] = *reinterpret_cast<const pair_t*>(bi + q * 32);
+        if (!diag) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rj[q] = *reinterpret_cast<const pair_t*>(bj + q * 32);
+        }
+        w1 = a.g1[n * P + p];
+        if (diag && cseg == 0) w0 = a.g0[n * P + p];
+    };
+    auto store_chunk = [&](int buf) {
+        T* Ai = &lds[buf][0][krow * LDS_KS + cseg * PW];
+        T* Aj = &lds[buf][1][krow * LDS_KS + cseg * PW];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            pair_t sc;
+            sc[0] = ri[q][0] * w1;
+            sc[1] = ri[q][1] * w1;
+            *reinterpret_cast<pair_t*>(Ai + q * 32) = sc;
+            *reinterpret_cast<pair_t*>(Aj + q * 32) = diag ? ri[q] : rj[q];
+        }
+        if (diag && cseg == 0) g0s[buf][krow] = w0;
+    };
+
+    if (c_lo < c_hi) {
+        load_chunk(c_lo);
+        store_chunk(0);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int64_t c = c_lo; c < c_hi; ++c) {
+        const bool has_next = (c + 1 < c_hi);
+        if (has_next) load_chunk(c + 1);
+        mma_chunk_krow<T>(acc, lds[buf][0], lds[buf][1], wm, wn, lane);
+        if (diag && t < TILE) {
+            const T* bcol = &lds[buf][1][t];
+#pragma unroll
+            for (int k = 0; k < KC; ++k) acc1 += g0s[buf][k] * bcol[k * LDS_KS];
+        }
+        if (has_next) store_chunk(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+
+    T* out = a.part2 + ((size_t)(p * a.nsplit + s) * a.ntri + tri) * (TILE * TILE);
+    T* ob = out + (wm * 64) * TILE + wn * 64 + (lane & 15);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            T* orow = ob + (m * 16 + Mfma<T>::row(lane, r)) * TILE;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) orow[n * 16] = acc[m][n][r];
+        }
+    if (diag && t < TILE) a.part1[(size_t)(p * a.nsplit + s) * Mp + it * TILE + t] = acc1;
+}
+
+// Sums the partial tiles over the splits in a fixed order and writes the full symmetric matrix (fp64).
+template <typename T>
+__global__ __launch_bounds__(NTHREADS) void syrk_reduce_kernel(const T* __restrict__ part2,
+                                                               const T* __restrict__ part1,
+                                                               double* __restrict__ acc2, double* __restrict__ acc1,
+                                                               int Mp, int P, int nsplit, int ntri) {
+    // grid.x = ntri * 64 (each block: 2 rows of 128 of one tile), grid.y = P ; extra blocks handle acc1
+    const int p = blockIdx.y;
+    const int tri = blockIdx.x / 64, sub = blockIdx.x % 64;
+    const int t = threadIdx.x;
+    if (tri < ntri) {
+        int it = 0;
+        while ((it + 1) * (it + 2) / 2 <= tri) ++it;
+        const int jt = tri - it * (it + 1) / 2;
+        const int ii = sub * 2 + (t >> 7), jj = t & 127;
+        double s = 0.0;
+        for (int sp = 0; sp < nsplit; ++sp)
+            s += (double)part2[((size_t)(p * nsplit + sp) * ntri + tri) * (TILE * TILE) + ii * TILE + jj];
+        const size_t base = (size_t)p * Mp * Mp;
+        const int gi = it * TILE + ii, gj = jt * TILE + jj;
+        if (it != jt) {
+            acc2[base + (size_t)gi * Mp + gj] = s;
+            acc2[base + (size_t)gj * Mp + gi] = s;
+        } else {
+            // diagonal tile: keep the lower triangle of the computed tile and mirror it (exactly symmetric output)
+            if (jj <= ii) {
+                acc2[base + (size_t)gi * Mp + gj] = s;
+                acc2[base + (size_t)gj * Mp + gi] = s;
+            }
+        }
+    } else {
+        // acc1
+        const int idx = (blockIdx.x - ntri * 64) * NTHREADS + t;
+        if (idx < Mp) {
+            double s = 0.0;
+            for (int sp = 0; sp < nsplit; ++sp) s += (double)part1[(size_t)(p * nsplit + sp) * Mp + idx];
+            acc1[(size_t)p * Mp + idx] = s;
+        }
+    }
+}
+
+// single-wave MFMA map self-test
+template <typename T>
+__global__ void selftest_kernel(const T* a, const T* b, T* c) {
+    typedef typename Mfma<T>::acc_t acc_t;
+    const int lane = threadIdx.x & 63;
+    acc_t acc = acc_t{0, 0, 0, 0};
+    const T av = a[(lane & 15) * 4 + (lane >> 4)];
+    const T bv = b[(lane >> 4) * 16 + (lane & 15)];
+    acc = Mfma<T>::run(av, bv, acc);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) c[Mfma<T>::row(lane, r) * 16 + (lane & 15)] = acc[r];
+}
+
+inline int launch_status() { return hipGetLastError() == hipSuccess ? TSVGP_OK : TSVGP_ELAUNCH; }
+
+template <typename T>
+int se_fill(const T* X, const T* Z, const T* inv_ls, T variance, T* K, int64_t N, int M, int D, int64_t ldk,
+            void* stream) {
+    if (!X || !Z || !inv_ls || !K || N <= 0 || M <= 0 || D <= 0) return TSVGP_EINVAL;
+    const int64_t rows_pad = (N + TILE - 1) / TILE * TILE;
+    const int cols_pad = (M + TILE - 1) / TILE * TILE;
+    if (ldk < cols_pad || (ldk % 2) != 0) return TSVGP_EINVAL;
+    const size_t smem = ((size_t)D * FILL_COLS + (size_t)FILL_ROWS * D) * sizeof(T);
+    if (smem > 160 * 1024) return TSVGP_EINVAL;
+    if (smem > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&se_fill_kernel<T>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+            return TSVGP_ELAUNCH;
+    }
+    dim3 grid((unsigned)((rows_pad + FILL_ROWS - 1) / FILL_ROWS), (unsigned)((cols_pad + FILL_COLS - 1) / FILL_COLS));
+    hipLaunchKernelGGL(se_fill_kernel<T>, grid, dim3(NTHREADS), smem, (hipStream_t)stream, X, Z, inv_ls, variance, K,
+                       N, M, D, ldk, rows_pad, cols_pad);
+    return launch_status();
+}
+
+template <typename T>
+int trmm(const T* A, const T* Tm, T* C, int64_t Np, int Mp, int mode, void* stream) {
+    if (!A || !Tm || !C || Np <= 0 || Mp <= 0 || (Np % TILE) || (Mp % TILE) || mode < 0 || mode > 2)
+        return TSVGP_EINVAL;
+    PanelArgs<T> a{};
+    a.A = A;
+    a.Tm = Tm;
+    a.C = C;
+    a.N = Np;
+    a.Np = Np;
+    a.Mp = Mp;
+    a.P = 1;
+    a.mode = mode;
+    hipLaunchKernelGGL((panel_kernel<T, MODE_STORE>), dim3((unsigned)(Np / TILE)), dim3(NTHREADS), 0,
+                       (hipStream_t)stream, a);
+    return launch_status();
+}
+
+template <typename T>
+int moments(const T* A, const T* Tm, const T* gamma, const T* Y, double kdiag, int lik, double lik_param, T* mean,
+            T* var, T* g0, T* g1, double* ve_partial, int32_t* nonpos_partial, int64_t N, int64_t Np, int Mp, int P,
+            int mode, void* stream) {
+    if (!A || !Tm || !gamma || N <= 0 || Np < N || (Np % TILE) || Mp <= 0 || (Mp % TILE) || P <= 0 || mode < 0 ||
+        mode > 2)
+        return TSVGP_EINVAL;
+    if (lik != TSVGP_LIK_NONE && lik != TSVGP_LIK_GAUSSIAN && lik != TSVGP_LIK_BERNOULLI) return TSVGP_EINVAL;
+    if (lik != TSVGP_LIK_NONE && (!Y || !g0 || !g1)) return TSVGP_EINVAL;
+    if (lik == TSVGP_LIK_GAUSSIAN && !(lik_param > 0.0)) return TSVGP_EINVAL;
+    PanelArgs<T> a{};
+    a.A = A;
+    a.Tm = Tm;
+    a.gamma = gamma;
+    a.Y = Y;
+    a.mean = mean;
+    a.var = var;
+    a.g0 = g0;
+    a.g1 = g1;
+    a.ve_partial = ve_partial;
+    a.nonpos_partial = nonpos_partial;
+    a.kdiag = kdiag;
+    a.lik_param = lik_param;
+    a.N = N;
+    a.Np = Np;
+    a.Mp = Mp;
+    a.P = P;
+    a.mode = mode;
+    a.lik = lik;
+    hipLaunchKernelGGL((panel_kernel<T, MODE_MOMENTS>), dim3((unsigned)(Np / TILE)), dim3(NTHREADS), 0,
+                       (hipStream_t)stream, a);
+    return launch_status();
+}
+
+template <typename T>
+int64_t site_accum_work_bytes(int Mp, int P, int nsplit) {
+    if (Mp <= 0 || (Mp % TILE) || P <= 0 || nsplit <= 0) return -1;
+    const int64_t nt = Mp / TILE, ntri = nt * (nt + 1) / 2;
+    return (int64_t)P * nsplit * (ntri * TILE * TILE + Mp) * (int64_t)sizeof(T);
+}
+
+template <typename T>
+int site_accum(const T* B, const T* g0, const T* g1, double* acc2, double* acc1, void* work, int64_t Np, int Mp, int P,
+               int nsplit, void* stream) {
+    if (!B || !g0 || !g1 || !acc2 || !acc1 || !work || Np <= 0 || (Np % TILE) || Mp <= 0 || (Mp % TILE) || P <= 0 ||
+        nsplit <= 0)
+        return TSVGP_EINVAL;
+    const int nt = Mp / TILE, ntri = nt * (nt + 1) / 2;
+    const int64_t total_chunks = Np / KC;
+    if (nsplit > total_chunks) nsplit = (int)total_chunks;
+    SyrkArgs<T> a{};
+    a.B = B;
+    a.g0 = g0;
+    a.g1 = g1;
+    a.part2 = reinterpret_cast<T*>(work);
+    a.part1 = a.part2 + (size_t)P * nsplit * ntri * TILE * TILE;
+    a.Np = Np;
+    a.Mp = Mp;
+    a.P = P;
+    a.nsplit = nsplit;
+    a.ntri = ntri;
+    a.chunks_per_split = (total_chunks + nsplit - 1) / nsplit;
+    const int64_t nwg = (int64_t)P * nsplit * ntri;
+    if (nwg > 0x7fffffff) return TSVGP_EINVAL;
+    hipLaunchKernelGGL(syrk_kernel<T>, dim3((unsigned)nwg), dim3(NTHREADS), 0, (hipStream_t)stream, a);
+    if (launch_status() != TSVGP_OK) return TSVGP_ELAUNCH;
+    const int extra = (Mp + NTHREADS - 1) / NTHREADS;
+    hipLaunchKernelGGL(syrk_reduce_kernel<T>, dim3((unsigned)(ntri * 64 + extra), (unsigned)P), dim3(NTHREADS), 0,
+                       (hipStream_t)stream, a.part2, a.part1, acc2, acc1, Mp, P, nsplit, ntri);
+    return launch_status();
+}
+
+template <typename T>
+int site_accum_slots() {
+    int dev = 0, cus = 0, nb = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return -1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&syrk_kernel<T>), NTHREADS,
+                                                     0) != hipSuccess)
+        return -1;
+    if (nb > 2) nb = 2;
+    return cus * nb;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* tsvgp_version(void) { return "tsvgp_hip gfx950 0.1.0"; }
+
+int tsvgp_site_accum_slots_f64(void) { return site_accum_slots<double>(); }
+int tsvgp_site_accum_slots_f32(void) { return site_accum_slots<float>(); }
+
+int tsvgp_se_fill_f64(const double* X, const double* Z, const double* inv_ls, double variance, double* K, int64_t N,
+                      int M, int D, int64_t ldk, void* stream) {
+    return se_fill<double>(X, Z, inv_ls, variance, K, N, M, D, ldk, stream);
+}
+int tsvgp_se_fill_f32(const float* X, const float* Z, const float* inv_ls, float variance, float* K, int64_t N, int M,
+                      int D, int64_t ldk, void* stream) {
+    return se_fill<float>(X, Z, inv_ls, variance, K, N, M, D, ldk, stream);
+}
+
+int tsvgp_trmm_f64(const double* A, const double* Tm, double* C, int64_t Np, int Mp, int mode, void* stream) {
+    return trmm<double>(A, Tm, C, Np, Mp, mode, stream);
+}
+int tsvgp_trmm_f32(const float* A, const float* Tm, float* C, int64_t Np, int Mp, int mode, void* stream) {
+    return trmm<float>(A, Tm, C, Np, Mp, mode, stream);
+}
+
+int tsvgp_moments_f64(const double* A, const double* Tm, const double* gamma, const double* Y, double kdiag, int lik,
+                      double lik_param, double* mean, double* var, double* g0, double* g1, double* ve_partial,
+                      int32_t* nonpos_partial, int64_t N, int64_t Np, int Mp, int P, int mode, void* stream) {
+    return moments<double>(A, Tm, gamma, Y, kdiag, lik, lik_param, mean, var, g0, g1, ve_partial, nonpos_partial, N,
+                           Np, Mp, P, mode, stream);
+}
+int tsvgp_moments_f32(const float* A, const float* Tm, const float* gamma, const float* Y, double kdiag, int lik,
+                      double lik_param, float* mean, float* var, float* g0, float* g1, double* ve_partial,
+                      int32_t* nonpos_partial, int64_t N, int64_t Np, int Mp, int P, int mode, void* stream) {
+    return moments<float>(A, Tm, gamma, Y, kdiag, lik, lik_param, mean, var, g0, g1, ve_partial, nonpos_partial, N, Np,
+                          Mp, P, mode, stream);
+}
+
+int64_t tsvgp_site_accum_work_bytes_f64(int Mp, int P, int nsplit) {
+    return site_accum_work_bytes<double>(Mp, P, nsplit);
+}
+int64_t tsvgp_site_accum_work_bytes_f32(int Mp, int P, int nsplit) {
+    return site_accum_work_bytes<float>(Mp, P, nsplit);
+}
+int tsvgp_site_accum_f64(const double* B, const double* g0, const double* g1, double* acc2, double* acc1, void* work,
+                         int64_t Np, int Mp, int P, int nsplit, void* stream) {
+    return site_accum<double>(B, g0, g1, acc2, acc1, work, Np, Mp, P, nsplit, stream);
+}
+int tsvgp_site_accum_f32(const float* B, const float* g0, const float* g1, double* acc2, double* acc1, void* work,
+                         int64_t Np, int Mp, int P, int nsplit, void* stream) {
+    return site_accum<float>(B, g0, g1, acc2, acc1, work, Np, Mp, P, nsplit, stream);
+}
+
+int tsvgp_selftest_mfma_f64(const double* a, const double* b, double* c, void* stream) {
+    if (!a || !b || !c) return TSVGP_EINVAL;
+    hipLaunchKernelGGL(selftest_kernel<double>, dim3(1), dim3(64), 0, (hipStream_t)stream, a, b, c);
+    return launch_status();
+}
+int tsvgp_selftest_mfma_f32(const float* a, const float* b, float* c, void* stream) {
+    if (!a || !b || !c) return TSVGP_EINVAL;
+    hipLaunchKernelGGL(selftest_kernel<float>, dim3(1), dim3(64), 0, (hipStream_t)stream, a, b, c);
+    return launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,208 @@
+"""Host-side driver of one N-pass of the E-step on one GPU: owns the HBM work buffers and launches the HIP kernels.
+
+Data layout in HBM (T = compute dtype, fp64 or fp32; Np/Mp = N/M rounded up to 128, padding zero-filled):
+
+    X    [N  x D ]  inputs (row-major, read once per pass by the fill kernel)
+    Y    [N  x P ]  targets
+    Kfu  [Np x Mp]  cross-covariance K(X, Z), written once by ``tsvgp_se_fill``
+    B    [Np x Mp]  whitened cross-covariance  B = Kfu L^-T  (L = chol(Kuu + jitter I)), written by ``tsvgp_trmm``
+    g0,g1[Np x P ]  likelihood gradients (rows >= N are zero)
+    work            partial 128x128 tiles of the weighted Gram, [P][nsplit][ntri][128*128] (+ first-order partials)
+
+Kernel sequence of ``run(..., sites=True)``:  fill -> trmm(LOWER) -> moments(UPPER or DENSE) -> site_accum.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import _backend as B
+
+
+@dataclass
+class EStepStats:
+    """Per-shard outputs of one N-pass (all fp64 on the model device)."""
+
+    n_rows: int
+    ve_sum: torch.Tensor  # scalar: sum of variational expectations over the shard's rows
+    nonpos: torch.Tensor  # scalar: number of rows with non-positive predictive variance
+    acc2: Optional[torch.Tensor] = None  # [P, M, M] sum_n g1 b_n b_n^T (whitened coordinates)
+    acc1: Optional[torch.Tensor] = None  # [P, M]    sum_n g0 b_n
+    mean: Optional[torch.Tensor] = None  # [N, P]
+    var: Optional[torch.Tensor] = None  # [N, P]
+    g0: Optional[torch.Tensor] = None  # [N, P]
+    g1: Optional[torch.Tensor] = None  # [N, P]
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+class EStepEngine:
+    """Launches the C-ABI kernels (include/tsvgp_hip.h) on torch-allocated device memory."""
+
+    def __init__(self, compute_dtype=torch.float64, device=None):
+        self.lib = B.lib()  # raises HipExtensionError when the extension is not built
+        if not torch.cuda.is_available():
+            raise B.HipExtensionError("no ROCm device visible: the t-SVGP E-step has no CPU fallback")
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        if self.device.type != "cuda":
+            raise B.HipExtensionError(f"EStepEngine needs a ROCm device, got {self.device}")
+        self.dtype = compute_dtype
+        self.sfx = B.suffix(compute_dtype)
+        self._buf = {}
+        self._slots = None
+        self.nsplit_override = None
+
+    # ------------------------------------------------------------------ helpers
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _fn(self, name, dtype=None):
+        return getattr(self.lib, f"{name}_{B.suffix(dtype) if dtype is not None else self.sfx}")
+
+    def _get(self, key, shape, dtype):
+        t = self._buf.get(key)
+        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
+            t = torch.empty(shape, dtype=dtype, device=self.device)
+            self._buf[key] = t
+        return t
+
+    def release(self):
+        """Drop the cached work buffers."""
+        self._buf.clear()
+
+    def slots(self) -> int:
+        if self._slots is None:
+            with torch.cuda.device(self.device):
+                s = int(self._fn("tsvgp_site_accum_slots")())
+            if s <= 0:
+                raise B.HipExtensionError("tsvgp_site_accum_slots failed")
+            self._slots = s
+        return self._slots
+
+    def _pad_square(self, A: torch.Tensor, Mp: int) -> torch.Tensor:
+        """[.., M, M] fp64 -> zero-padded contiguous [.., Mp, Mp] in the compute dtype."""
+        M = A.shape[-1]
+        out = torch.zeros(A.shape[:-2] + (Mp, Mp), dtype=self.dtype, device=self.device)
+        out[..., :M, :M] = A
+        return out
+
+    # ------------------------------------------------------------------ kernels
+    def se_fill(self, X: torch.Tensor, Z: torch.Tensor, inv_ls: torch.Tensor, variance: float, out: torch.Tensor):
+        """out[Np x Mp] <- K(X, Z) (padding zero).  X, Z, inv_ls, out share one dtype."""
+        N, D = X.shape
+        M = Z.shape[0]
+        fn = self._fn("tsvgp_se_fill", X.dtype)
+        with torch.cuda.device(self.device):
+            B.check(fn(X.data_ptr(), Z.data_ptr(), inv_ls.data_ptr(), float(variance), out.data_ptr(), N, M, D,
+                       out.shape[1], self._stream()), "tsvgp_se_fill")
+        return out
+
+    def kuu(self, Z: torch.Tensor, kernel) -> torch.Tensor:
+        """K(Z, Z) in fp64, [M, M] (no jitter)."""
+        Z = Z.to(device=self.device, dtype=torch.float64).contiguous()
+        M, D = Z.shape
+        Mp = B.round_up(M)
+        out = torch.empty((Mp, Mp), dtype=torch.float64, device=self.device)
+        inv_ls = kernel.inv_lengthscales(D, torch.float64, self.device)
+        self.se_fill(Z, Z, inv_ls, float(kernel.variance.value), out)
+        return out[:M, :M].contiguous()
+
+    def trmm(self, A: torch.Tensor, Tm: torch.Tensor, C: torch.Tensor, mode: int):
+        Np, Mp = A.shape
+        with torch.cuda.device(self.device):
+            B.check(self._fn("tsvgp_trmm")(A.data_ptr(), Tm.data_ptr(), C.data_ptr(), Np, Mp, mode, self._stream()),
+                    "tsvgp_trmm")
+        return C
+
+    def selftest_mfma(self, dtype=None):
+        """Runs one MFMA and returns (a, b, c) for a host-side check of the fragment maps."""
+        dtype = dtype or self.dtype
+        g = torch.Generator(device="cpu").manual_seed(7)
+        a = torch.randn(16, 4, generator=g, dtype=torch.float64).to(dtype).to(self.device)
+        b = torch.randn(4, 16, generator=g, dtype=torch.float64).to(dtype).to(self.device)
+        c = torch.zeros(16, 16, dtype=dtype, device=self.device)
+        with torch.cuda.device(self.device):
+            B.check(self._fn("tsvgp_selftest_mfma", dtype)(a.data_ptr(), b.data_ptr(), c.data_ptr(), self._stream()),
+                    "tsvgp_selftest_mfma")
+        return a, b, c
+
+    # ------------------------------------------------------------------ one N-pass
+    def run(self, X, Y, Z, kernel, *, moment_Tm, moment_mode, gamma, lik_id=B.LIK_NONE, lik_param=0.0,
+            whiten_Linv=None, sites=False, want_moments=False, want_grads=False) -> EStepStats:
+        """One pass over the shard's rows.
+
+        X [N, D], Y [N, P] (or None when lik_id == NONE), Z [M, D];
+        whiten_Linv [M, M] fp64 = inv(chol(Kuu + jitter I)) or None (moments then act on Kfu directly);
+        moment_Tm [P, M, M] fp64 and gamma [M, P] fp64: operands of the fused moments kernel;
+        sites=True also accumulates (acc2, acc1) from the whitened B (requires whiten_Linv).
+        """
+        T, dev = self.dtype, self.device
+        X = X.to(device=dev, dtype=T).contiguous()
+        Z = Z.to(device=dev, dtype=T).contiguous()
+        N, D = X.shape
+        M = Z.shape[0]
+        P = moment_Tm.shape[0]
+        if N == 0:
+            raise ValueError("empty shard: every rank needs at least one row")
+        if X.dim() != 2 or Z.dim() != 2 or Z.shape[1] != D:
+            raise ValueError(f"X must be [N, D] and Z [M, D] with equal D, got {tuple(X.shape)} and {tuple(Z.shape)}")
+        if lik_id != B.LIK_NONE:
+            Y = Y.to(device=dev, dtype=T).contiguous()
+            if Y.dim() != 2 or Y.shape[0] != N or Y.shape[1] != P:
+                raise ValueError(f"Y must be [N, P] = [{N}, {P}], got {tuple(Y.shape)}")
+        if sites and whiten_Linv is None:
+            raise ValueError("site accumulation needs the whitening factor")
+        Np, Mp = B.round_up(N), B.round_up(M)
+        inv_ls = kernel.inv_lengthscales(D, T, dev)
+        variance = float(kernel.variance.value)
+
+        Kfu = self._get("Kfu", (Np, Mp), T)
+        self.se_fill(X, Z, inv_ls, variance, Kfu)
+
+        A = Kfu
+        if whiten_Linv is not None:
+            Bw = self._get("B", (Np, Mp), T)
+            self.trmm(Kfu, self._pad_square(whiten_Linv, Mp), Bw, B.TRI_LOWER)
+            A = Bw
+
+        Tm = self._pad_square(moment_Tm, Mp)
+        gam = torch.zeros((Mp, P), dtype=T, device=dev)
+        gam[:M] = gamma
+        nblk = Np // B.TILE
+        ve_partial = self._get("ve_partial", (nblk,), torch.float64)
+        nonpos_partial = self._get("nonpos_partial", (nblk,), torch.int32)
+        need_g = lik_id != B.LIK_NONE
+        g0 = self._get("g0", (Np, P), T) if need_g else None
+        g1 = self._get("g1", (Np, P), T) if need_g else None
+        mean = torch.empty((N, P), dtype=T, device=dev) if want_moments else None
+        var = torch.empty((N, P), dtype=T, device=dev) if want_moments else None
+        with torch.cuda.device(dev):
+            B.check(self._fn("tsvgp_moments")(
+                A.data_ptr(), Tm.data_ptr(), gam.data_ptr(), _ptr(Y) if need_g else None, variance, lik_id,
+                float(lik_param), _ptr(mean), _ptr(var), _ptr(g0), _ptr(g1), ve_partial.data_ptr(),
+                nonpos_partial.data_ptr(), N, Np, Mp, P, moment_mode, self._stream()), "tsvgp_moments")
+        stats = EStepStats(n_rows=N, ve_sum=ve_partial.sum(), nonpos=nonpos_partial.sum().to(torch.float64))
+        if want_moments:
+            stats.mean, stats.var = mean.to(torch.float64), var.to(torch.float64)
+        if want_grads and need_g:
+            stats.g0, stats.g1 = g0[:N].to(torch.float64), g1[:N].to(torch.float64)
+
+        if sites:
+            ntri = (Mp // B.TILE) * (Mp // B.TILE + 1) // 2
+            nsplit = self.nsplit_override or max(1, self.slots() // (ntri * P))
+            nsplit = min(nsplit, Np // 16)
+            nbytes = int(self._fn("tsvgp_site_accum_work_bytes")(Mp, P, nsplit))
+            work = self._get("work", (nbytes,), torch.uint8)
+            acc2 = torch.empty((P, Mp, Mp), dtype=torch.float64, device=dev)
+            acc1 = torch.empty((P, Mp), dtype=torch.float64, device=dev)
+            with torch.cuda.device(dev):
+                B.check(self._fn("tsvgp_site_accum")(A.data_ptr(), g0.data_ptr(), g1.data_ptr(), acc2.data_ptr(),
+                                                     acc1.data_ptr(), work.data_ptr(), Np, Mp, P, nsplit,
+                                                     self._stream()), "tsvgp_site_accum")
+            stats.acc2 = acc2[:, :M, :M]
+            stats.acc1 = acc1[:, :M]
+        return stats

@@ -1,0 +1,37 @@
+"""Covariance functions on the hot path.
+
+``SquaredExponential`` mirrors ``gpflow.kernels.SquaredExponential`` (the kernel every reference test, notebook and
+experiment on this path uses: reference tests/models/test_tsvgp.py:100, experiments/uci_regression.py:186-187).
+The N-sized evaluations K(X, Z) run in the HIP fill kernel (``tsvgp_se_fill_*``); nothing here loops over data.
+"""
+from __future__ import annotations
+
+import torch
+
+from .base import Parameter, to_tensor
+
+
+class SquaredExponential:
+    """k(x, z) = variance * exp(-0.5 * sum_d ((x_d - z_d) / lengthscales_d)^2)."""
+
+    def __init__(self, variance=1.0, lengthscales=1.0, name=None):
+        self.variance = Parameter(variance)
+        self.lengthscales = Parameter(lengthscales)
+        self.name = name or "squared_exponential"
+
+    @property
+    def ard(self) -> bool:
+        return self.lengthscales.value.dim() > 0
+
+    def inv_lengthscales(self, D: int, dtype=None, device=None) -> torch.Tensor:
+        """[D] vector of 1/lengthscale (isotropic values are broadcast)."""
+        ls = self.lengthscales.value
+        if ls.dim() == 0:
+            ls = ls.expand(D)
+        if ls.shape[0] != D:
+            raise ValueError(f"lengthscales has {ls.shape[0]} entries but the inputs have {D} columns")
+        return to_tensor(1.0 / ls, dtype, device).contiguous()
+
+    def K_diag(self, X) -> torch.Tensor:
+        X = to_tensor(X)
+        return self.variance.value.expand(X.shape[0]).clone()

@@ -1,0 +1,270 @@
+"""t-SVGP model on MI355X (mirror of reference src/models/tsvgp.py).
+
+Same constructor, properties and methods as the reference's ``t_SVGP`` so a driver written against it
+(``natgrad_step(data, lr)``, ``elbo(data)``, ``predict_f``, ``new_predict_f``, ``lambda_1``, ``lambda_2_sqrt`` ...)
+runs unchanged, but every N-sized operation goes through the HIP kernels behind ``include/tsvgp_hip.h`` and the
+M x M site algebra runs on the GPU in fp64 through torch.  There is no CPU fallback.
+
+Algebra of one E-step (P latents, shared kernel; K6 = Kuu + 1e-6 I, K9 = Kuu + jitter I, L9 = chol(K9)):
+
+  reference (tsvgp.py:234-304)                       here
+  -------------------------------------------------  ----------------------------------------------------------
+  (m, chol S) = posterior_from_dense_site(K6, ...)   D = chol(W)^-1 L^T, W = I + L^T K6 L        (util.py:168-175)
+  mean = Kfu K6^-1 m                                 mean = B gamma,  gamma = L9^T beta,  beta = l1 - D^T D K6 l1
+  var  = knn - |Lm^-1 k|^2 + |chol S^T K6^-1 k|^2    var  = knn - |F^T b|^2,  F F^T = (D L9)^T (D L9)   [= knn - |D k|^2]
+  A = Kfu K9^-1;  G1 = sum g1 a a^T                  B = Kfu L9^-T (HIP trmm);  acc2 = sum g1 b b^T (HIP syrk)
+                                                     G1 = L9^-T acc2 L9^-1   (two M x M triangular solves)
+  G0 = sum g0 a                                      G0 = L9^-T acc1
+  lambda update + (-chol)                            identical (tsvgp.py:293-300)
+
+Accumulating in whitened coordinates (B, not Kfu) keeps the M x M back-solves at cond(L9) = sqrt(cond(K9)).
+"""
+from __future__ import annotations
+
+import abc
+
+import numpy as np
+import torch
+
+from .. import _backend as B
+from .. import distributed as D_
+from ..base import default_device, default_float, default_jitter, to_tensor
+from ..inducing_variables import inducingpoint_wrapper
+from ..sites import DenseSites
+from ..util import (
+    cholesky,
+    gradient_transformation_mean_var_to_expectation,
+    kl_from_dense_site,
+    posterior_from_dense_site,
+    site_projection_D,
+)
+
+
+class base_SVGP(abc.ABC):
+    """Mirror of the reference's ``base_SVGP`` (tsvgp.py:32-114): ELBO, prior KL and predict_f for a model that
+    exposes q(u) through ``get_mean_chol_cov_inducing_posterior``."""
+
+    def __init__(self, kernel, likelihood, inducing_variable, *, mean_function=None, num_latent_gps=1, num_data=None,
+                 compute_dtype=None, device=None):
+        if mean_function is not None:
+            raise NotImplementedError("only the default Zero mean function is on the hot path")
+        self.kernel = kernel
+        self.likelihood = likelihood
+        self.mean_function = None
+        self.num_latent_gps = num_latent_gps
+        self.num_data = num_data
+        self.inducing_variable = inducingpoint_wrapper(inducing_variable)
+        self.compute_dtype = compute_dtype or default_float()
+        self.device = torch.device(device) if device is not None else default_device()
+        self._engine = None
+        self.data_parallel = None  # None = automatic: shard-reduce whenever torch.distributed has > 1 rank
+
+    # -- engine ------------------------------------------------------------------------------------------------
+    def _get_engine(self):
+        """The HIP kernel launcher; creating it fails loudly when the extension or the GPU is missing."""
+        if self._engine is None:
+            from ..estep import EStepEngine
+
+            self._engine = EStepEngine(self.compute_dtype, self.device)
+        return self._engine
+
+    def _reduce(self) -> bool:
+        return D_.world_size() > 1 if self.data_parallel is None else bool(self.data_parallel)
+
+    @abc.abstractmethod
+    def get_mean_chol_cov_inducing_posterior(self):
+        """Returns the mean and cholesky factor of the covariance matrix of q(u)"""
+        raise NotImplementedError
+
+    def maximum_log_likelihood_objective(self, data):
+        return self.elbo(data)
+
+    def training_loss(self, data):
+        return -self.elbo(data)
+
+
+class t_SVGP(base_SVGP):
+    """Class for the t-SVGP model (reference tsvgp.py:117-304)."""
+
+    def __init__(self, kernel, likelihood, inducing_variable, *, mean_function=None, num_latent_gps: int = 1,
+                 lambda_1=None, lambda_2_sqrt=None, num_data=None, force=False, compute_dtype=None, device=None):
+        super().__init__(kernel, likelihood, inducing_variable, mean_function=mean_function,
+                         num_latent_gps=num_latent_gps, num_data=num_data, compute_dtype=compute_dtype, device=device)
+        self.num_inducing = self.inducing_variable.num_inducing
+        self._init_variational_parameters(self.num_inducing, lambda_1, lambda_2_sqrt)
+        self.whiten = False
+        self.force = force
+        self.name = "t_svgp"  # tf.Module derives this from the class name (experiments/uci_regression.py:150)
+
+    def _init_variational_parameters(self, num_inducing, lambda_1, lambda_2_sqrt, **kwargs):
+        """Constructs the site parameters lambda_1, Lambda_2 of t(u) = exp(u^T l1 - 1/2 u^T L2 u) (tsvgp.py:159-185)."""
+        lambda_1 = np.zeros((num_inducing, self.num_latent_gps)) if lambda_1 is None else lambda_1
+        if lambda_2_sqrt is None:
+            lambda_2_sqrt = np.array([-np.eye(num_inducing) * 1e-10 for _ in range(self.num_latent_gps)])
+        else:
+            lambda_2_sqrt = lambda_2_sqrt.value if hasattr(lambda_2_sqrt, "value") else lambda_2_sqrt
+            assert lambda_2_sqrt.ndim == 3
+            self.num_latent_gps = lambda_2_sqrt.shape[0]
+        self.sites = DenseSites(to_tensor(lambda_1, device=self.device), to_tensor(lambda_2_sqrt, device=self.device))
+
+    @property
+    def lambda_1(self):
+        """first natural parameter"""
+        return self.sites.lambda_1
+
+    @property
+    def lambda_2_sqrt(self):
+        """Cholesky factor of the second natural parameter"""
+        return self.sites.lambda_2_sqrt
+
+    @property
+    def lambda_2(self):
+        """second natural parameter"""
+        L = self.lambda_2_sqrt.value
+        return L @ L.transpose(-1, -2)
+
+    # -- M x M prelude -----------------------------------------------------------------------------------------
+    def _Z(self) -> torch.Tensor:
+        return self.inducing_variable.Z.value.to(self.device)
+
+    def _site_operands(self, whiten_jitter=None):
+        """Everything the N-pass needs that depends only on (theta, Z, lambda): O(M^3), fp64, replicated."""
+        eng = self._get_engine()
+        Z = self._Z()
+        M = Z.shape[0]
+        Kzz = eng.kuu(Z, self.kernel)  # HIP fill kernel, no jitter
+        Id = torch.eye(M, dtype=torch.float64, device=Kzz.device)
+        K6 = Kzz + default_jitter() * Id  # tsvgp.py:209-211
+        l1 = self.lambda_1.value
+        L = self.lambda_2_sqrt.value
+        Dm, chol_W = site_projection_D(K6, L, return_chol=True)  # [P, M, M]
+        DKl = torch.einsum("pmk,kp->pm", Dm @ K6, l1)
+        beta = l1 - torch.einsum("pkm,pk->mp", Dm, DKl)  # K6^-1 m = l1 - D^T D K6 l1
+        ops = dict(Z=Z, Kzz=Kzz, K6=K6, D=Dm, chol_W=chol_W, beta=beta, Id=Id)
+        if whiten_jitter is not None:
+            L9 = cholesky(Kzz + whiten_jitter * Id)  # tsvgp.py:268-270
+            ops["L9"] = L9
+            ops["Linv9"] = torch.linalg.solve_triangular(L9, Id, upper=False)
+            ops["gamma"] = L9.transpose(-1, -2) @ beta
+            T = Dm @ L9
+            G = T.transpose(-1, -2) @ T
+            G = 0.5 * (G + G.transpose(-1, -2))
+            F, info = torch.linalg.cholesky_ex(G, check_errors=False)
+            if bool((info != 0).any()) or not bool(torch.isfinite(F).all()):
+                ops["moment_Tm"], ops["moment_mode"] = T, B.TRI_DENSE  # G numerically singular: dense product
+            else:
+                ops["moment_Tm"], ops["moment_mode"] = F.transpose(-1, -2).contiguous(), B.TRI_UPPER
+        return ops
+
+    def get_mean_chol_cov_inducing_posterior(self):
+        """Mean and Cholesky factor of q(u) = N(u; m, S) (tsvgp.py:202-212)."""
+        eng = self._get_engine()
+        Kzz = eng.kuu(self._Z(), self.kernel)
+        K_uu = Kzz + default_jitter() * torch.eye(Kzz.shape[0], dtype=Kzz.dtype, device=Kzz.device)
+        return posterior_from_dense_site(K_uu, self.lambda_1.value, self.lambda_2_sqrt.value)
+
+    def prior_kl(self):
+        """KL[q(u) || p(u)] (tsvgp.py:65-70)."""
+        ops = self._site_operands()
+        return kl_from_dense_site(ops["K6"], self.lambda_1.value, ops["D"], ops["chol_W"], ops["beta"])
+
+    # -- data plumbing -----------------------------------------------------------------------------------------
+    def _as_device(self, a):
+        if isinstance(a, torch.Tensor):
+            return a.to(self.device)
+        return torch.as_tensor(np.asarray(a)).to(self.device)
+
+    def _raise_if_nonpos(self, nonpos):
+        if float(nonpos) > 0:  # tf.debugging.assert_positive(var), tsvgp.py:113
+            raise FloatingPointError(f"non-positive predictive variance at {int(float(nonpos))} point(s)")
+
+    # -- predictions -------------------------------------------------------------------------------------------
+    def predict_f(self, Xnew, full_cov=False, full_output_cov=False):
+        """Posterior prediction at new input Xnew [N, D] (tsvgp.py:97-114) through the whitened route the E-step uses."""
+        if full_cov or full_output_cov:
+            raise NotImplementedError("full covariances are not on the E-step hot path")
+        ops = self._site_operands(whiten_jitter=1e-9)
+        st = self._get_engine().run(self._as_device(Xnew), None, ops["Z"], self.kernel, moment_Tm=ops["moment_Tm"],
+                                    moment_mode=ops["moment_mode"], gamma=ops["gamma"], whiten_Linv=ops["Linv9"],
+                                    want_moments=True)
+        self._raise_if_nonpos(st.nonpos)
+        return st.mean, st.var
+
+    def new_predict_f(self, Xnew, full_cov=False, full_output_cov=False):
+        """Same moments straight from the sites: var = knn - |D k|^2 (tsvgp.py:215-232, util.py:91-185)."""
+        if full_cov or full_output_cov:
+            raise NotImplementedError("full covariances are not on the E-step hot path")
+        ops = self._site_operands()
+        st = self._get_engine().run(self._as_device(Xnew), None, ops["Z"], self.kernel, moment_Tm=ops["D"],
+                                    moment_mode=B.TRI_DENSE, gamma=ops["beta"], want_moments=True)
+        self._raise_if_nonpos(st.nonpos)
+        return st.mean, st.var
+
+    def predict_y(self, Xnew):
+        return self.likelihood.predict_mean_and_var(*self.predict_f(Xnew))
+
+    def predict_log_density(self, data):
+        X, Y = data
+        Fmu, Fvar = self.predict_f(X)
+        return self.likelihood.predict_log_density(Fmu, Fvar, self._as_device(Y).to(Fmu.dtype))
+
+    # -- ELBO --------------------------------------------------------------------------------------------------
+    def elbo(self, data):
+        """Evidence lower bound  sum_n E_q[log p(y_n | f_n)] * scale - KL[q(u) || p(u)]  (tsvgp.py:79-95).
+        With more than one rank ``data`` is this rank's row shard and the sum is all-reduced."""
+        X, Y = data
+        ops = self._site_operands()
+        kl = kl_from_dense_site(ops["K6"], self.lambda_1.value, ops["D"], ops["chol_W"], ops["beta"])
+        st = self._get_engine().run(self._as_device(X), self._as_device(Y), ops["Z"], self.kernel,
+                                    moment_Tm=ops["D"], moment_mode=B.TRI_DENSE, gamma=ops["beta"],
+                                    lik_id=self.likelihood.lik_id, lik_param=self.likelihood.lik_param)
+        packed = D_.pack_stats(st, with_sites=False)
+        if self._reduce():
+            D_.all_reduce_sum(packed)
+        _, _, ve_sum, nonpos, rows = D_.unpack_stats(packed, self.num_latent_gps, self.num_inducing, False)
+        self._raise_if_nonpos(nonpos)
+        scale = (float(self.num_data) / float(rows)) if self.num_data is not None else 1.0
+        return ve_sum * scale - kl
+
+    # -- the hot path ------------------------------------------------------------------------------------------
+    def natgrad_step(self, data, lr=0.1, jitter=1e-9):
+        """One natural-gradient step on the site parameters (tsvgp.py:234-304):
+            lambda <- (1 - lr) lambda + lr * scale * grad_mu E_q[log p(y | f)].
+        ``data = (X [N, D], Y [N, P])``; with more than one rank, this rank's contiguous row shard.
+        Updates the parameters in place and returns None."""
+        X, Y = data
+        ops = self._site_operands(whiten_jitter=jitter)
+        st = self._get_engine().run(self._as_device(X), self._as_device(Y), ops["Z"], self.kernel,
+                                    moment_Tm=ops["moment_Tm"], moment_mode=ops["moment_mode"], gamma=ops["gamma"],
+                                    lik_id=self.likelihood.lik_id, lik_param=self.likelihood.lik_param,
+                                    whiten_Linv=ops["Linv9"], sites=True)
+        self._apply_site_update(st, ops, lr, jitter)
+
+    def _apply_site_update(self, st, ops, lr, jitter):
+        """All-reduce of the packed accumulators (RCCL) + the replicated M x M epilogue (tsvgp.py:278-303)."""
+        P, M = self.num_latent_gps, self.num_inducing
+        packed = D_.pack_stats(st, with_sites=True)
+        if self._reduce():
+            D_.all_reduce_sum(packed)
+        acc2, acc1, _, nonpos, rows = D_.unpack_stats(packed, P, M, True)
+        self._raise_if_nonpos(nonpos)
+
+        L9, Kzz, beta = ops["L9"], ops["Kzz"], ops["beta"]
+        L9t = L9.transpose(-1, -2)
+        # G1 = L9^-T acc2 L9^-1,  G0 = L9^-T acc1   (tsvgp.py:279-280 in whitened coordinates)
+        X1 = torch.linalg.solve_triangular(L9t, acc2, upper=True)
+        G1 = torch.linalg.solve_triangular(L9t, X1.transpose(-1, -2), upper=True)
+        G1 = 0.5 * (G1 + G1.transpose(-1, -2))
+        G0 = torch.linalg.solve_triangular(L9t, acc1.transpose(-1, -2), upper=True)  # [M, P]
+        meanZ = Kzz @ beta  # predict_f(Z) mean, tsvgp.py:249-254
+        grad_mu = gradient_transformation_mean_var_to_expectation(meanZ, [G0, G1])  # tsvgp.py:284
+
+        scale = (float(self.num_data) / float(rows)) if self.num_data is not None else 1.0  # tsvgp.py:286-291
+        lambda_2 = -0.5 * self.lambda_2  # tsvgp.py:293
+        lambda_1 = self.lambda_1.value
+        lambda_1 = (1 - lr) * lambda_1 + lr * scale * grad_mu[0]  # tsvgp.py:296
+        lambda_2 = (1 - lr) * lambda_2 + lr * scale * grad_mu[1]  # tsvgp.py:297
+        lambda_2_sqrt = -cholesky(-2.0 * lambda_2 + ops["Id"] * jitter)  # tsvgp.py:300
+        self.lambda_1.assign(lambda_1)  # tsvgp.py:302
+        self.sites.assign_lambda_2_sqrt(lambda_2_sqrt)  # tsvgp.py:303
+        # tsvgp.py:304 recomputes the posterior and discards it: dead work, not reproduced.

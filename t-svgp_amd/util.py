@@ -1,0 +1,101 @@
+"""Site-form linear algebra of the hot path (mirror of reference src/util.py), on torch tensors.
+
+Everything here is M x M (replicated, fp64) work: O(M^3), never O(N).  The N-sized contractions that the
+reference performs with dense TensorFlow ops are in the HIP kernels (csrc/tsvgp_kernels.hip); the functions
+below prepare their small operands and consume their M-sized outputs.
+
+Shapes follow the reference: K [M, M], lambda_1 [M, P], lambda_2_sqrt [P, M, M].
+"""
+from __future__ import annotations
+
+import torch
+
+
+def cholesky(a: torch.Tensor) -> torch.Tensor:
+    """tf.linalg.cholesky equivalent; FloatingPointError stands in for TF's
+    'Cholesky decomposition was not successful' InvalidArgumentError."""
+    L, info = torch.linalg.cholesky_ex(a, upper=False, check_errors=False)
+    if bool((info != 0).any()):
+        raise FloatingPointError("Cholesky decomposition was not successful (matrix not positive definite)")
+    return L
+
+
+def _check_site_shapes(K, lambda_1, lambda_2_sqrt, who):
+    if K.dim() < 2 or K.shape[-1] != K.shape[-2]:
+        raise ValueError(f"{who}: K must be [..., M, M]")
+    M = K.shape[-1]
+    if lambda_2_sqrt.dim() != 3 or lambda_2_sqrt.shape[1] != M or lambda_2_sqrt.shape[2] != M:
+        raise ValueError(f"{who}: lambda_2_sqrt must be [P, M, M]")
+    if lambda_1.dim() != 2 or lambda_1.shape[0] != M or lambda_1.shape[1] != lambda_2_sqrt.shape[0]:
+        raise ValueError(f"{who}: lambda_1 must be [M, P]")
+
+
+def posterior_from_dense_site(K, lambda_1, lambda_2_sqrt):
+    """Mean and Cholesky factor of q(u) = p(u) t(u) = N(u; m, S)   (reference src/util.py:349-391).
+
+    S = (K^-1 + L L^T)^-1 = K - K L W^-1 L^T K,  W = I + L^T K L,  m = S lambda_1.
+    Returns m [M, P], chol(S) [P, M, M].
+    """
+    _check_site_shapes(K, lambda_1, lambda_2_sqrt, "posterior_from_dense_site()")
+    L = lambda_2_sqrt
+    Id = torch.eye(K.shape[-1], dtype=K.dtype, device=K.device)
+    C = cholesky(K)
+    CtL = C.transpose(-1, -2) @ L
+    W = Id + CtL.transpose(-1, -2) @ CtL
+    chol_W = cholesky(W)
+    LtK = L.transpose(-1, -2) @ K
+    iwLtK = torch.linalg.solve_triangular(chol_W, LtK, upper=False)
+    S_q = K - iwLtK.transpose(-1, -2) @ iwLtK
+    chol_S_q = cholesky(S_q)
+    m_q = torch.einsum("lmn,nl->ml", S_q, lambda_1)
+    return m_q, chol_S_q
+
+
+def conditional_from_precision_sites(Kuu, Kff, Kuf, l, L=None, L2=None):
+    """Predictive moments straight from the sites (reference src/util.py:91-185), dense torch form for small N.
+
+    Kuu [M, M], Kff [N, 1], Kuf [M, N], l [M, P], L [P, M, M] -> mean [N, P], cov [N, P].
+    The model's ``new_predict_f`` runs the same algebra through the HIP moments kernel instead.
+    """
+    if L is None:
+        L = cholesky(L2)
+    _check_site_shapes(Kuu, l, L, "conditional_from_precision_sites()")
+    if Kuf.dim() != 2 or Kuf.shape[0] != Kuu.shape[0] or Kff.shape != (Kuf.shape[1], 1):
+        raise ValueError("conditional_from_precision_sites(): Kuf must be [M, N] and Kff [N, 1]")
+    D = site_projection_D(Kuu, L)
+    tmp = D @ Kuf  # [P, M, N]
+    DKl = D @ (Kuu @ l.transpose(-1, -2)[..., None])  # [P, M, 1]
+    mean = Kuf.transpose(-1, -2) @ l - torch.sum(DKl * tmp, dim=-2).transpose(-1, -2)
+    cov = Kff - torch.sum(torch.square(tmp), dim=-2).transpose(-1, -2)
+    return mean, cov
+
+
+def site_projection_D(K, L, return_chol=False):
+    """D = chol(W)^-1 L^T with W = I + L^T K L  (reference src/util.py:168-175); [P, M, M].
+
+    W is formed directly from K (no Cholesky of K needed): W = I + L^T (K L).
+    """
+    Id = torch.eye(K.shape[-1], dtype=K.dtype, device=K.device)
+    W = Id + L.transpose(-1, -2) @ (K @ L)
+    W = 0.5 * (W + W.transpose(-1, -2))
+    chol_W = cholesky(W)
+    D = torch.linalg.solve_triangular(chol_W, L.transpose(-1, -2), upper=False)
+    return (D, chol_W) if return_chol else D
+
+
+def gradient_transformation_mean_var_to_expectation(inputs, grads):
+    """Chain rule (mean, var) -> (mu_1, mu_2) (reference src/util.py:429-438)."""
+    return grads[0] - 2.0 * torch.einsum("lmo,ol->ml", grads[1], inputs), grads[1]
+
+
+def kl_from_dense_site(K, lambda_1, D, chol_W, beta):
+    """KL[q(u) || p(u)] for the dense site, per the identities
+        tr(K^-1 S) = M - tr(D K D^T),  log|S| = log|K| - log|W|,  m^T K^-1 m = (K beta)^T beta,
+    which make gpflow.kullback_leiblers.gauss_kl (reference tsvgp.py:65-70) computable without chol(S):
+        KL = 1/2 sum_p [ m_p^T beta_p - tr(D_p K D_p^T) + log|W_p| ].
+    """
+    m = K @ beta  # [M, P]
+    maha = torch.sum(m * beta)
+    trace = torch.sum(D * (D @ K))
+    logdetW = 2.0 * torch.sum(torch.log(torch.diagonal(chol_W, dim1=-2, dim2=-1)))
+    return 0.5 * (maha - trace + logdetW)

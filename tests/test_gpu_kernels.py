@@ -1,0 +1,171 @@
+"""Kernel-level parity on the GPU: every C-ABI entry point against NumPy / the oracle on the same seeded inputs.
+
+Tolerances: fp64 <= 1e-11 relative (pure rounding); fp32 stated per test (inputs rounded to fp32, fp32 MFMA).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import tsvgp_oracle as O
+from tests.helpers import pkg, relerr
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [(torch.float64, 1e-11), (torch.float32, 2e-5)]
+
+
+@pytest.fixture(scope="module")
+def engines():
+    from importlib import import_module
+
+    estep = import_module("t-svgp_amd.estep")
+    return {dt: estep.EStepEngine(dt, "cuda:0") for dt, _ in DTYPES}
+
+
+@pytest.mark.parametrize("dtype,tol", DTYPES)
+def test_mfma_fragment_maps(engines, dtype, tol):
+    """A (16x4) @ B (4x16) with asymmetric random operands: catches swapped row/col maps."""
+    a, b, c = engines[dtype].selftest_mfma(dtype)
+    ref = a.double().cpu().numpy() @ b.double().cpu().numpy()
+    assert relerr(c.cpu().numpy(), ref) < tol
+
+
+@pytest.mark.parametrize("dtype,tol", DTYPES)
+@pytest.mark.parametrize("N,M,D", [(1, 1, 1), (130, 32, 1), (1000, 200, 8), (257, 513, 16), (64, 1024, 19)])
+def test_se_fill(engines, dtype, tol, N, M, D):
+    eng = engines[dtype]
+    rng = np.random.RandomState(1)
+    X, Z = rng.randn(N, D), rng.randn(M, D)
+    ls = 0.7 + rng.rand(D)
+    var = 1.3
+    B = pkg()._backend
+    Np, Mp = B.round_up(N), B.round_up(M)
+    out = torch.full((Np, Mp), float("nan"), dtype=dtype, device="cuda:0")
+    t = lambda a: torch.as_tensor(a, dtype=dtype, device="cuda:0").contiguous()
+    eng.se_fill(t(X), t(Z), t(1.0 / ls), var, out)
+    K = out.double().cpu().numpy()
+    ref = O.SquaredExponential(variance=var, lengthscales=ls).K(X, Z)
+    assert relerr(K[:N, :M], ref) < tol * 10
+    assert np.all(K[N:, :] == 0) and np.all(K[:, M:] == 0)  # zero-filled padding
+
+
+@pytest.mark.parametrize("dtype,tol", DTYPES)
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("Np,Mp", [(128, 128), (384, 256), (256, 640)])
+def test_trmm(engines, dtype, tol, mode, Np, Mp):
+    eng = engines[dtype]
+    rng = np.random.RandomState(2)
+    A = rng.randn(Np, Mp)
+    Tm = rng.randn(Mp, Mp)
+    mask = {0: np.tril(np.ones((Mp, Mp))), 1: np.triu(np.ones((Mp, Mp))), 2: np.ones((Mp, Mp))}[mode]
+    # the kernel's k-range is tile-granular: feed a matrix that is zero outside the intended triangle
+    Tm_m = Tm * mask
+    t = lambda a: torch.as_tensor(a, dtype=dtype, device="cuda:0").contiguous()
+    C = torch.empty((Np, Mp), dtype=dtype, device="cuda:0")
+    eng.trmm(t(A), t(Tm_m), C, mode)
+    ref = t(A).double().cpu().numpy() @ t(Tm_m).double().cpu().numpy().T
+    assert relerr(C.cpu().numpy(), ref) < tol * 20
+
+
+def _moments_ref(A, Tm, gamma, kdiag):
+    C = np.einsum("nj,pij->pni", A, Tm)
+    q = np.sum(C * C, axis=-1).T  # [N, P]
+    return A @ gamma, kdiag - q
+
+
+@pytest.mark.parametrize("dtype,tol", DTYPES)
+@pytest.mark.parametrize("lik", ["none", "gaussian", "bernoulli"])
+@pytest.mark.parametrize("N,M,P,mode", [(100, 128, 1, 2), (300, 256, 2, 1), (129, 384, 3, 1)])
+def test_moments_and_likelihood_map(engines, dtype, tol, lik, N, M, P, mode):
+    eng = engines[dtype]
+    B = pkg()._backend
+    rng = np.random.RandomState(3)
+    Np = B.round_up(N)
+    A = np.zeros((Np, M))
+    A[:N] = rng.randn(N, M) / np.sqrt(M)
+    Tm = rng.randn(P, M, M) * 0.5
+    if mode == 1:
+        Tm = np.triu(Tm)
+    gamma = rng.randn(M, P)
+    kdiag = 2.5
+    Y = (rng.rand(N, P) > 0.5).astype(float) if lik == "bernoulli" else rng.randn(N, P)
+    t = lambda a: torch.as_tensor(a, dtype=dtype, device="cuda:0").contiguous()
+    At, Tmt, gt, Yt = t(A), t(Tm), t(gamma), t(Y)
+    mean = torch.empty((N, P), dtype=dtype, device="cuda:0")
+    var = torch.empty((N, P), dtype=dtype, device="cuda:0")
+    g0 = torch.full((Np, P), float("nan"), dtype=dtype, device="cuda:0")
+    g1 = torch.full((Np, P), float("nan"), dtype=dtype, device="cuda:0")
+    vep = torch.zeros(Np // 128, dtype=torch.float64, device="cuda:0")
+    npp = torch.zeros(Np // 128, dtype=torch.int32, device="cuda:0")
+    lik_id = {"none": 0, "gaussian": 1, "bernoulli": 2}[lik]
+    fn = eng._fn("tsvgp_moments")
+    B.check(fn(At.data_ptr(), Tmt.data_ptr(), gt.data_ptr(), Yt.data_ptr(), kdiag, lik_id, 0.3, mean.data_ptr(),
+               var.data_ptr(), g0.data_ptr(), g1.data_ptr(), vep.data_ptr(), npp.data_ptr(), N, Np, M, P, mode,
+               eng._stream()), "moments")
+    torch.cuda.synchronize()
+    mref, vref = _moments_ref(At.double().cpu().numpy()[:N], Tmt.double().cpu().numpy(), gt.double().cpu().numpy(), kdiag)
+    assert relerr(mean.cpu().numpy(), mref) < tol * 20
+    assert np.max(np.abs(var.double().cpu().numpy() - vref)) < tol * 20 * kdiag
+    assert int(npp.sum()) == int(np.sum(vref <= 0))
+    if lik == "none":
+        return
+    ok = vref > 0  # the likelihood map is only defined for positive variance
+    mu_k, var_k = mean.double().cpu().numpy(), var.double().cpu().numpy()
+    olik = O.Gaussian(variance=0.3) if lik == "gaussian" else O.Bernoulli()
+    vs = np.where(ok, var_k, 1.0)
+    r0, r1 = olik.variational_expectations_grads(mu_k, vs, Y)
+    r1 = np.minimum(r1, -1e-8)
+    k0, k1 = g0.double().cpu().numpy(), g1.double().cpu().numpy()
+    ltol = 1e-10 if dtype == torch.float64 else 1e-5
+    np.testing.assert_allclose(k0[:N][ok], r0[ok], rtol=ltol, atol=ltol)
+    np.testing.assert_allclose(k1[:N][ok], r1[ok], rtol=ltol, atol=ltol)
+    assert np.all(k0[N:] == 0) and np.all(k1[N:] == 0)
+    if ok.all():
+        ve_ref = np.sum(olik.variational_expectations(mu_k, var_k, Y))
+        assert abs(float(vep.sum()) - ve_ref) < 1e-9 * max(1.0, abs(ve_ref))
+
+
+@pytest.mark.parametrize("dtype,tol", DTYPES)
+@pytest.mark.parametrize("Np,Mp,P,nsplit", [(128, 128, 1, 1), (1024, 256, 2, 3), (640, 384, 1, 7), (4096, 128, 3, 64)])
+def test_site_accum(engines, dtype, tol, Np, Mp, P, nsplit):
+    eng = engines[dtype]
+    B = pkg()._backend
+    rng = np.random.RandomState(4)
+    Bm = rng.randn(Np, Mp)
+    g0 = rng.randn(Np, P)
+    g1 = -rng.rand(Np, P) - 0.1
+    g0[-5:] = 0
+    g1[-5:] = 0
+    t = lambda a: torch.as_tensor(a, dtype=dtype, device="cuda:0").contiguous()
+    Bt, g0t, g1t = t(Bm), t(g0), t(g1)
+    nbytes = int(eng._fn("tsvgp_site_accum_work_bytes")(Mp, P, nsplit))
+    work = torch.empty(nbytes, dtype=torch.uint8, device="cuda:0")
+    acc2 = torch.full((P, Mp, Mp), float("nan"), dtype=torch.float64, device="cuda:0")
+    acc1 = torch.full((P, Mp), float("nan"), dtype=torch.float64, device="cuda:0")
+    B.check(eng._fn("tsvgp_site_accum")(Bt.data_ptr(), g0t.data_ptr(), g1t.data_ptr(), acc2.data_ptr(), acc1.data_ptr(),
+                                        work.data_ptr(), Np, Mp, P, nsplit, eng._stream()), "site_accum")
+    torch.cuda.synchronize()
+    Bd, g0d, g1d = Bt.double().cpu().numpy(), g0t.double().cpu().numpy(), g1t.double().cpu().numpy()
+    ref2 = np.einsum("nm,no,nl->lmo", Bd, Bd, g1d)
+    ref1 = np.einsum("nm,nl->lm", Bd, g0d)
+    a2 = acc2.cpu().numpy()
+    assert relerr(a2, ref2) < tol * 50
+    assert relerr(acc1.cpu().numpy(), ref1) < tol * 50
+    assert np.array_equal(a2, np.swapaxes(a2, -1, -2))  # exactly symmetric
+    # fixed-order reduction: bitwise reproducible
+    acc2b = torch.empty_like(acc2)
+    acc1b = torch.empty_like(acc1)
+    B.check(eng._fn("tsvgp_site_accum")(Bt.data_ptr(), g0t.data_ptr(), g1t.data_ptr(), acc2b.data_ptr(), acc1b.data_ptr(),
+                                        work.data_ptr(), Np, Mp, P, nsplit, eng._stream()), "site_accum")
+    torch.cuda.synchronize()
+    assert torch.equal(acc2, acc2b) and torch.equal(acc1, acc1b)
+
+
+def test_invalid_arguments_are_rejected(engines):
+    eng = engines[torch.float64]
+    lib = eng.lib
+    x = torch.zeros(128 * 128, dtype=torch.float64, device="cuda:0")
+    assert lib.tsvgp_trmm_f64(x.data_ptr(), x.data_ptr(), x.data_ptr(), 100, 128, 0, None) == 1  # Np not padded
+    assert lib.tsvgp_trmm_f64(None, x.data_ptr(), x.data_ptr(), 128, 128, 0, None) == 1
+    assert lib.tsvgp_se_fill_f64(x.data_ptr(), x.data_ptr(), x.data_ptr(), 1.0, x.data_ptr(), 10, 4, 2, 100, None) == 1
+    assert lib.tsvgp_site_accum_work_bytes_f64(100, 1, 1) == -1

@@ -1,0 +1,204 @@
+"""Model-level parity on the GPU: t_SVGP (HIP path, through the C-ABI) against the CPU oracle, on identical inputs.
+
+Stated tolerances:
+  fp64: max rel err <= 1e-8 on lambda_1, Lambda_2 = L L^T, mean, var;  |dELBO| / |ELBO| <= 1e-9
+  fp32 (against the fp64 oracle): mean, var atol 1e-4 + rtol 1e-3;  |dELBO| / |ELBO| <= 1e-4
+The reference-shaped tests restate reference tests/models/test_tsvgp.py on the HIP model (decimal=4 as there).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import tsvgp_oracle as O
+from tests.helpers import c1_problem, make_pair, pkg, relerr, synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def _compare_state(hip, ora, tol):
+    assert relerr(hip.lambda_1.numpy(), ora.lambda_1) < tol
+    assert relerr(hip.lambda_2.cpu().numpy(), ora.lambda_2) < tol
+
+
+@pytest.mark.parametrize("lik,P", [("gaussian", 1), ("gaussian", 2), ("bernoulli", 1), ("bernoulli", 2)])
+def test_natgrad_steps_match_oracle_fp64(lik, P):
+    """8 E-steps (lr 0.8) from the default init on a D=3 problem; state, moments, gradients and ELBO vs the oracle."""
+    X, Y, Z = synthetic(N=700, M=48, D=3, P=P, lik=lik, seed=0)
+    hip, ora = make_pair(Z, lik=lik, P=P)
+    for step in range(8):
+        hip.natgrad_step((X, Y), lr=0.8)
+        ora.natgrad_step((X, Y), lr=0.8)
+        _compare_state(hip, ora, 1e-8)
+    e_h, e_o = float(hip.elbo((X, Y))), float(ora.elbo((X, Y)))
+    assert abs(e_h - e_o) / abs(e_o) < 1e-9
+    Xs = X[:200] + 0.05
+    for fn in ("predict_f", "new_predict_f"):
+        mu_h, var_h = getattr(hip, fn)(Xs)
+        mu_o, var_o = getattr(ora, fn)(Xs)
+        assert relerr(mu_h.cpu().numpy(), mu_o) < 1e-8
+        assert relerr(var_h.cpu().numpy(), var_o) < 1e-8
+
+
+def test_c1_config_trajectory_fp64():
+    """Config C1 (N=1000, M=32, D=1, Gaussian): 8 E-steps lr=0.8; ELBO after each step matches the oracle."""
+    X, Y, Z, hp = c1_problem()
+    hip, ora = make_pair(Z, lik="gaussian", noise=hp["noise"], lengthscales=hp["lengthscales"], variance=hp["variance"])
+    for _ in range(8):
+        hip.natgrad_step((X, Y), lr=0.8)
+        ora.natgrad_step((X, Y), lr=0.8)
+        e_h, e_o = float(hip.elbo((X, Y))), float(ora.elbo((X, Y)))
+        assert abs(e_h - e_o) / abs(e_o) < 1e-9
+    _compare_state(hip, ora, 1e-8)
+
+
+def test_intermediates_match_oracle_fp64():
+    """mean, var, g0, g1 of one step and the whitened accumulators mapped back to the reference's G0, G1."""
+    X, Y, Z = synthetic(N=500, M=40, D=2, P=1, lik="bernoulli", seed=3)
+    hip, ora = make_pair(Z, lik="bernoulli")
+    for _ in range(2):
+        hip.natgrad_step((X, Y), lr=0.5)
+        ora.natgrad_step((X, Y), lr=0.5)
+    ops = hip._site_operands(whiten_jitter=1e-9)
+    B = pkg()._backend
+    st = hip._get_engine().run(hip._as_device(X), hip._as_device(Y), ops["Z"], hip.kernel, moment_Tm=ops["moment_Tm"],
+                               moment_mode=ops["moment_mode"], gamma=ops["gamma"], lik_id=B.LIK_BERNOULLI,
+                               whiten_Linv=ops["Linv9"], sites=True, want_moments=True, want_grads=True)
+    ora.natgrad_step((X, Y), lr=0.5)  # fills ora.last with the intermediates of the same state
+    last = ora.last
+    assert relerr(st.mean.cpu().numpy(), last["mean"]) < 1e-8
+    assert relerr(st.var.cpu().numpy(), last["var"]) < 1e-8
+    assert relerr(st.g0.cpu().numpy(), last["g0"]) < 1e-8
+    assert relerr(st.g1.cpu().numpy(), last["g1"]) < 1e-8
+    L9 = ops["L9"].cpu().numpy()
+    G1 = np.stack([np.linalg.solve(L9.T, np.linalg.solve(L9.T, a).T).T for a in st.acc2.cpu().numpy()])
+    G0 = np.linalg.solve(L9.T, st.acc1.cpu().numpy().T)
+    assert relerr(G1, last["G1"]) < 1e-8
+    assert relerr(G0, last["G0"]) < 1e-8
+
+
+@pytest.mark.parametrize("lik", ["gaussian", "bernoulli"])
+def test_natgrad_steps_fp32_against_fp64_oracle(lik):
+    X, Y, Z = synthetic(N=2000, M=64, D=4, P=1, lik=lik, seed=1)
+    hip, ora = make_pair(Z, lik=lik, compute_dtype=torch.float32)
+    for _ in range(4):
+        hip.natgrad_step((X, Y), lr=0.8)
+        ora.natgrad_step((X, Y), lr=0.8)
+    e_h, e_o = float(hip.elbo((X, Y))), float(ora.elbo((X, Y)))
+    assert abs(e_h - e_o) / abs(e_o) < 1e-4
+    mu_h, var_h = hip.predict_f(X[:300])
+    mu_o, var_o = ora.predict_f(X[:300])
+    np.testing.assert_allclose(mu_h.cpu().numpy(), mu_o, rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(var_h.cpu().numpy(), var_o, rtol=1e-3, atol=1e-4)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the reference's own tests, restated on the HIP model (reference tests/models/test_tsvgp.py)
+# ---------------------------------------------------------------------------------------------------------------------
+def _ref_setup():
+    rng = np.random.RandomState(123)
+    func = lambda x: np.sin(x * 3 * 3.14) + 0.3 * np.cos(x * 9 * 3.14) + 0.5 * np.sin(x * 7 * 3.14)
+    X = rng.rand(8, 1) * 2 - 1
+    Y = func(X) + 0.2 * rng.randn(8, 1)
+    return X, Y, rng
+
+
+@pytest.fixture(name="tsvgp_gpr_optim_setup")
+def _tsvgp_gpr_optim_setup():
+    p = pkg()
+    X, Y, _ = _ref_setup()
+    kernel = p.SquaredExponential(lengthscales=2.0, variance=2.25)
+    tsvgp = p.t_SVGP(kernel=kernel, likelihood=p.Gaussian(variance=0.3), inducing_variable=p.InducingPoints(X))
+    for _ in range(10):
+        tsvgp.natgrad_step((X, Y), lr=0.9)
+    return tsvgp, (X, Y, O.SquaredExponential(lengthscales=2.0, variance=2.25), 0.3)
+
+
+def test_tsvgp_elbo_optimal(tsvgp_gpr_optim_setup):
+    """reference tests/models/test_tsvgp.py:106-110."""
+    tsvgp, (X, Y, kern, noise) = tsvgp_gpr_optim_setup
+    np.testing.assert_almost_equal(float(tsvgp.elbo((X, Y))), O.gpr_log_marginal_likelihood(kern, X, Y, noise), decimal=4)
+
+
+def test_predictions_match_tsvgp_gpr_optimal(tsvgp_gpr_optim_setup):
+    """reference tests/models/test_tsvgp.py:113-120."""
+    tsvgp, (X, Y, kern, noise) = tsvgp_gpr_optim_setup
+    mu, var = tsvgp.predict_f(X + 1.0)
+    mu_gpr, var_gpr = O.gpr_predict_f(kern, X, Y, noise, X + 1.0)
+    np.testing.assert_array_almost_equal(mu.cpu().numpy(), mu_gpr, decimal=4)
+    np.testing.assert_array_almost_equal(var.cpu().numpy(), var_gpr, decimal=4)
+
+
+def test_tsvgp_unchanged_at_optimum(tsvgp_gpr_optim_setup):
+    """reference tests/models/test_tsvgp.py:134-145."""
+    tsvgp, (X, Y, _, _) = tsvgp_gpr_optim_setup
+    e0 = float(tsvgp.elbo((X, Y)))
+    tsvgp.natgrad_step((X, Y), lr=0.9)
+    np.testing.assert_almost_equal(e0, float(tsvgp.elbo((X, Y))), decimal=4)
+
+
+def test_tsvgp_minibatch_same_elbo(tsvgp_gpr_optim_setup):
+    """reference tests/models/test_tsvgp.py:148-165."""
+    tsvgp, (X, Y, _, _) = tsvgp_gpr_optim_setup
+    tsvgp.num_data = 8
+    x = X[0].repeat(8)[:, None]
+    y = Y[0].repeat(8)[:, None]
+    e2 = float(tsvgp.elbo((x, y)))
+    e1 = float(tsvgp.elbo((X[0][:, None], Y[0][:, None])))
+    np.testing.assert_almost_equal(e2, e1, decimal=4)
+
+
+@pytest.mark.parametrize("num_latent_gps", [1, 2])
+def test_bernoulli_fixture_matches_oracle(num_latent_gps):
+    """reference tests/models/test_tsvgp.py:46-88,123-131 shape: 20 steps lr=1.0, Bernoulli, Z = X (ill-conditioned
+    K_uu, cond ~ 1e16 before jitter): new_predict_f of the HIP model vs the oracle's, decimal=4 as the reference."""
+    p = pkg()
+    X, Yr, rng = _ref_setup()
+    Y = np.tile((Yr > 0).astype(float), [1, num_latent_gps]) * rng.rand(1, num_latent_gps)
+    hip = p.t_SVGP(p.SquaredExponential(lengthscales=2.0, variance=2.25), p.Bernoulli(), p.InducingPoints(X),
+                   num_latent_gps=num_latent_gps)
+    ora = O.t_SVGP(O.SquaredExponential(lengthscales=2.0, variance=2.25), O.Bernoulli(), O.InducingPoints(X),
+                   num_latent_gps=num_latent_gps)
+    for _ in range(20):
+        hip.natgrad_step((X, Y), lr=1.0)
+        ora.natgrad_step((X, Y), lr=1.0)
+    mu_h, var_h = hip.new_predict_f(X + 0.1)
+    mu_o, var_o = ora.new_predict_f(X + 0.1)
+    np.testing.assert_array_almost_equal(mu_h.cpu().numpy(), mu_o, decimal=4)
+    np.testing.assert_array_almost_equal(var_h.cpu().numpy(), var_o, decimal=4)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# API / error behaviour
+# ---------------------------------------------------------------------------------------------------------------------
+def test_api_surface_and_mutation():
+    p = pkg()
+    X, Y, Z = synthetic(N=300, M=20, D=2)
+    m = p.t_SVGP(p.SquaredExponential(), p.Gaussian(0.1), Z)  # raw array is wrapped (tsvgp.py:150)
+    assert m.lambda_1.shape == (20, 1) and m.lambda_2_sqrt.shape == (1, 20, 20)
+    np.testing.assert_allclose(np.diagonal(m.lambda_2_sqrt.numpy()[0]), -1e-10)  # negative-diagonal convention
+    assert m.natgrad_step((X, Y), 0.5) is None  # positional lr (docs/notebooks/classification_1D.py:108)
+    L = m.lambda_2_sqrt.numpy()[0]
+    assert np.all(np.diagonal(L) < 0) and np.allclose(L, np.tril(L))
+    e0 = float(m.elbo((X, Y)))
+    m.kernel.lengthscales.assign(0.7)  # parameters are read fresh on every call
+    assert float(m.elbo((X, Y))) != e0
+    q_mu, q_sqrt = m.get_mean_chol_cov_inducing_posterior()
+    assert q_mu.shape == (20, 1) and q_sqrt.shape == (1, 20, 20)
+    mu, var = m.predict_y(X[:5])
+    assert mu.shape == (5, 1) and bool((var > 0).all())
+    assert m.predict_log_density((X[:5], Y[:5])).shape == (5,)
+
+
+def test_error_behaviour():
+    p = pkg()
+    X, Y, Z = synthetic(N=100, M=10, D=2)
+    m = p.t_SVGP(p.SquaredExponential(), p.Gaussian(0.1), Z)
+    with pytest.raises(ValueError):
+        m.natgrad_step((X[:, :1], Y))  # D mismatch
+    with pytest.raises(ValueError):
+        m.natgrad_step((X, Y[:50]))  # row mismatch
+    with pytest.raises(AssertionError):
+        p.t_SVGP(p.SquaredExponential(), p.Gaussian(0.1), Z, lambda_2_sqrt=np.eye(10))  # ndim != 3 (tsvgp.py:182)
+    dup = p.t_SVGP(p.SquaredExponential(), p.Gaussian(0.1), np.zeros((4, 2)))  # duplicate inducing points
+    with pytest.raises(FloatingPointError):
+        dup.natgrad_step((X, Y), jitter=0.0)  # singular K_uu: Cholesky fails as in TF
