@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""bench.py -- natural-gradient E-steps/sec of the t-SVGP hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload ns|c2|c3|c5|c1]
+
+A "step" is one full-batch ``t_SVGP.natgrad_step((X, Y), lr=0.8)`` (reference src/models/tsvgp.py:234-304) over all
+N rows of a synthetic problem whose inputs are already resident in HBM; everything that depends on (theta, Z, lambda)
+is rebuilt inside every step ("cold" E-step: kernel matrices, Choleskys, whitening, moments, site accumulation, site
+update).  With N > 1 the driver starts one process per GPU (torch.distributed.run); the N rows are sharded
+contiguously and each step performs one RCCL all-reduce of the packed dual accumulators ("strong" scaling: total
+work is fixed).  Rank 0 prints ONE JSON line.
+
+Workloads (BASELINE.json):
+  ns  (default) north_star target / the metric's sizes: Gaussian regression N=1e6, M=1024, D=8, P=1, fp64
+  c2  configs[1]: Gaussian regression N=1e6, M=512,  D=8,  fp64
+  c3  configs[2]: Bernoulli (probit, GH-20) N=1e6, M=1024, D=16, fp32 N-arrays (M x M algebra stays fp64)
+  c5  configs[4]: P=8 latents (shared kernel) N=1e6, M=1024, D=8, fp64
+  c1  configs[0]: N=1000, M=32, D=1 plumbing case
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    "ns": dict(N=1_000_000, M=1024, D=8, P=1, lik="gaussian", dtype="f64",
+               name="gaussian_regression_N1e6_M1024_D8_P1 (north_star target; the metric's N, M)"),
+    "c2": dict(N=1_000_000, M=512, D=8, P=1, lik="gaussian", dtype="f64",
+               name="gaussian_regression_N1e6_M512_D8_P1 (BASELINE configs[1])"),
+    "c3": dict(N=1_000_000, M=1024, D=16, P=1, lik="bernoulli", dtype="f32",
+               name="bernoulli_probit_N1e6_M1024_D16_P1 (BASELINE configs[2])"),
+    "c5": dict(N=1_000_000, M=1024, D=8, P=8, lik="gaussian", dtype="f64",
+               name="gaussian_multioutput_N1e6_M1024_D8_P8_shared_kernel (BASELINE configs[4])"),
+    "c1": dict(N=1000, M=32, D=1, P=1, lik="gaussian", dtype="f64", name="gaussian_1d_N1000_M32 (BASELINE configs[0])"),
+}
+PEAK_TFLOPS = {"f64": 78.6, "f32": 157.3}  # dense MFMA peaks (AMD datasheet; f32: MI355X_MICROARCH.md; f64 = f32/2)
+HBM_PEAK_GBS = 8000.0
+
+
+def make_data(w, seed=0):
+    """X = randn(N, D); w = randn(D, P); eps = randn(N, P); f = sin(X w); Z = X[:M]."""
+    rng = np.random.RandomState(seed)
+    X = rng.randn(w["N"], w["D"])
+    W = rng.randn(w["D"], w["P"])
+    eps = rng.randn(w["N"], w["P"])
+    f = np.sin(X @ W)
+    if w["lik"] == "gaussian":
+        Y = f + np.sqrt(0.1) * eps
+    else:
+        Y = (f + np.sqrt(0.1) * eps > 0).astype(np.float64)
+    return X, Y, X[: w["M"]].copy()
+
+
+def kernel_flops(w, rows):
+    """Algorithmic flops per launch of each MFMA kernel for `rows` data rows (triangular/symmetric counts, 2 per FMA)."""
+    M, P = w["M"], w["P"]
+    return {
+        "tsvgp_trmm": rows * M * (M + 1),  # B = Kfu L^-T, lower-triangular k-range
+        "tsvgp_moments": rows * M * (M + 1) * P + 2 * rows * M * P,  # |F^T b|^2 (upper) + mean GEMV
+        "tsvgp_site_accum": rows * M * (M + 1) * P + 2 * rows * M * P,  # lower half of sum g1 b b^T + sum g0 b
+    }
+
+
+def kernel_bytes(w, rows, esize):
+    """Algorithmic HBM bytes per launch of the fill kernel (the only HBM-bound kernel): write Kfu once, read X once."""
+    return {"tsvgp_se_fill": rows * w["M"] * esize + rows * w["D"] * esize}
+
+
+def cpu_baseline(w, budget_s=20.0):
+    """The CPU oracle (op-for-op port of the reference sequence) timed on a bounded row sample of the same workload."""
+    from oracle import tsvgp_oracle as O
+
+    try:
+        from threadpoolctl import threadpool_info
+
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [os.cpu_count() or 1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    n_s = min(w["N"], max(2000, int(2.0e7 // (w["M"] * w["P"]))))  # bounds the [n, M, P] temporaries to ~160 MB each
+    X, Y, Z = make_data(dict(w, N=n_s))
+    lik = O.Gaussian(variance=0.1) if w["lik"] == "gaussian" else O.Bernoulli()
+    model = O.t_SVGP(O.SquaredExponential(variance=1.0, lengthscales=1.0), lik, Z, num_latent_gps=w["P"])
+    model.natgrad_step((X, Y), lr=0.8)  # warm-up (BLAS thread pools, page faults)
+    times = []
+    t_all = time.perf_counter()
+    while len(times) < 3 or (time.perf_counter() - t_all < budget_s and len(times) < 50):
+        t0 = time.perf_counter()
+        model.natgrad_step((X, Y), lr=0.8)
+        times.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_all > 2 * budget_s:
+            break
+    t_med = float(np.median(times))
+    # the N-dependent part of the reference sequence is linear in N; scale the sample to the full N
+    value = 1.0 / (t_med * w["N"] / n_s)
+    return {
+        "value": value, "unit": "E-steps/s", "cores": int(cores), "kind": "port",
+        "sample": f"oracle natgrad_step on the first {n_s} of {w['N']} rows (same M, D, P, likelihood), median of "
+                  f"{len(times)} steps = {t_med * 1e3:.1f} ms, scaled linearly in N (extrapolated)",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="ns", choices=sorted(WORKLOADS))
+    ap.add_argument("--rows", type=int, default=None, help="override N (debugging only; the result is then not the metric)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    pkg = importlib.import_module("t-svgp_amd")
+    w = dict(WORKLOADS[args.workload])
+    if args.rows:
+        w["N"] = args.rows
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    dtype = torch.float64 if w["dtype"] == "f64" else torch.float32
+    esize = 8 if w["dtype"] == "f64" else 4
+    X, Y, Z = make_data(w)
+    lo, hi = pkg.distributed.shard_bounds(w["N"], world, rank)
+    Xd = torch.as_tensor(X[lo:hi], dtype=dtype).to(device).contiguous()
+    Yd = torch.as_tensor(Y[lo:hi], dtype=dtype).to(device).contiguous()
+    rows = hi - lo
+    del X, Y
+
+    lik = pkg.Gaussian(variance=0.1) if w["lik"] == "gaussian" else pkg.Bernoulli()
+    model = pkg.t_SVGP(pkg.SquaredExponential(variance=1.0, lengthscales=1.0), lik, Z, num_latent_gps=w["P"],
+                       num_data=w["N"], compute_dtype=dtype, device=device)
+    eng = model._get_engine()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        model.natgrad_step((Xd, Yd), lr=0.8)
+    barrier()
+    eng.profile = {}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        model.natgrad_step((Xd, Yd), lr=0.8)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = eng.profile_summary()
+    eng.profile = None
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t)
+    elbo = float(model.elbo((Xd, Yd)))
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        flops = kernel_flops(w, rows)
+        byts = kernel_bytes(w, rows, esize)
+        kern_ms = {k: v[1] for k, v in prof.items()}
+        mfma = {k: kern_ms[k] for k in flops if k in kern_ms}
+        dom = max(mfma, key=mfma.get) if mfma else None
+        roofline = None
+        if dom:
+            achieved = flops[dom] / (mfma[dom] * 1e-3) / 1e12
+            traffic = None
+            tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+            if os.path.exists(tp):
+                try:
+                    traffic = json.load(open(tp)).get(args.workload, {}).get(dom)
+                except Exception:
+                    traffic = None
+            roofline = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_TFLOPS[w["dtype"]],
+                        "unit": "TFLOP/s", "frac": round(achieved / PEAK_TFLOPS[w["dtype"]], 4), "traffic": traffic,
+                        "algorithmic_flops_per_launch": flops[dom], "avg_launch_ms": round(mfma[dom], 4)}
+        kernels = {}
+        for k, (n, ms) in sorted(prof.items()):
+            e = {"launches_per_step": n / args.steps, "avg_ms": round(ms, 4)}
+            if k in flops:
+                e["tflops"] = round(flops[k] / (ms * 1e-3) / 1e12, 2)
+            if k in byts:
+                e["gbs"] = round(byts[k] / (ms * 1e-3) / 1e9, 1)
+                e["hbm_frac"] = round(e["gbs"] / HBM_PEAK_GBS, 4)
+            kernels[k] = e
+        out = {
+            "metric": "natgrad E-steps/sec", "value": round(args.steps / elapsed, 4), "unit": "E-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": w["dtype"],
+            "data": "synthetic",
+            "config": {"workload": w["name"], "N": w["N"], "M": w["M"], "D": w["D"], "P": w["P"],
+                       "likelihood": w["lik"], "rows_per_gpu": rows, "parallelism": f"N-sharded x{world}, 1 all-reduce/step",
+                       "e_step": "cold (K_uu, K_uf, Choleskys, whitening rebuilt every step)", "lr": 0.8},
+            "elbo_after_steps": elbo,
+            "roofline": roofline,
+            "kernels": kernels,
+            "kernel_ms_per_step": round(sum(v[0] * v[1] for v in prof.values()) / args.steps, 4),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(w, args.cpu_budget)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -55,6 +55,7 @@ class EStepEngine:
         self._buf = {}
         self._slots = None
         self.nsplit_override = None
+        self.profile = None  # set to a dict to record (start, stop) HIP events per kernel launch on the launch stream
 
     # ------------------------------------------------------------------ helpers
     def _stream(self):
@@ -69,6 +70,27 @@ class EStepEngine:
             t = torch.empty(shape, dtype=dtype, device=self.device)
             self._buf[key] = t
         return t
+
+    def _launch(self, name, status_fn):
+        """Runs one C-ABI launch; with profiling on, brackets it with events on the stream it is launched on."""
+        if self.profile is None:
+            B.check(status_fn(), name)
+            return
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(torch.cuda.current_stream(self.device))
+        B.check(status_fn(), name)
+        e1.record(torch.cuda.current_stream(self.device))
+        self.profile.setdefault(name, []).append((e0, e1))
+
+    def profile_summary(self):
+        """{kernel: (launches, mean ms)} from the recorded events (synchronises)."""
+        torch.cuda.synchronize(self.device)
+        out = {}
+        for name, evs in (self.profile or {}).items():
+            ms = [a.elapsed_time(b) for a, b in evs]
+            out[name] = (len(ms), sum(ms) / max(len(ms), 1))
+        return out
 
     def release(self):
         """Drop the cached work buffers."""
@@ -97,8 +119,9 @@ class EStepEngine:
         M = Z.shape[0]
         fn = self._fn("tsvgp_se_fill", X.dtype)
         with torch.cuda.device(self.device):
-            B.check(fn(X.data_ptr(), Z.data_ptr(), inv_ls.data_ptr(), float(variance), out.data_ptr(), N, M, D,
-                       out.shape[1], self._stream()), "tsvgp_se_fill")
+            self._launch("tsvgp_se_fill" if N != M or X.data_ptr() != Z.data_ptr() else "tsvgp_se_fill(Kuu)",
+                         lambda: fn(X.data_ptr(), Z.data_ptr(), inv_ls.data_ptr(), float(variance), out.data_ptr(), N,
+                                    M, D, out.shape[1], self._stream()))
         return out
 
     def kuu(self, Z: torch.Tensor, kernel) -> torch.Tensor:
@@ -114,8 +137,8 @@ class EStepEngine:
     def trmm(self, A: torch.Tensor, Tm: torch.Tensor, C: torch.Tensor, mode: int):
         Np, Mp = A.shape
         with torch.cuda.device(self.device):
-            B.check(self._fn("tsvgp_trmm")(A.data_ptr(), Tm.data_ptr(), C.data_ptr(), Np, Mp, mode, self._stream()),
-                    "tsvgp_trmm")
+            self._launch("tsvgp_trmm", lambda: self._fn("tsvgp_trmm")(A.data_ptr(), Tm.data_ptr(), C.data_ptr(), Np, Mp,
+                                                                      mode, self._stream()))
         return C
 
     def selftest_mfma(self, dtype=None):
@@ -181,10 +204,10 @@ class EStepEngine:
         mean = torch.empty((N, P), dtype=T, device=dev) if want_moments else None
         var = torch.empty((N, P), dtype=T, device=dev) if want_moments else None
         with torch.cuda.device(dev):
-            B.check(self._fn("tsvgp_moments")(
+            self._launch("tsvgp_moments", lambda: self._fn("tsvgp_moments")(
                 A.data_ptr(), Tm.data_ptr(), gam.data_ptr(), _ptr(Y) if need_g else None, variance, lik_id,
                 float(lik_param), _ptr(mean), _ptr(var), _ptr(g0), _ptr(g1), ve_partial.data_ptr(),
-                nonpos_partial.data_ptr(), N, Np, Mp, P, moment_mode, self._stream()), "tsvgp_moments")
+                nonpos_partial.data_ptr(), N, Np, Mp, P, moment_mode, self._stream()))
         stats = EStepStats(n_rows=N, ve_sum=ve_partial.sum(), nonpos=nonpos_partial.sum().to(torch.float64))
         if want_moments:
             stats.mean, stats.var = mean.to(torch.float64), var.to(torch.float64)
@@ -200,9 +223,9 @@ class EStepEngine:
             acc2 = torch.empty((P, Mp, Mp), dtype=torch.float64, device=dev)
             acc1 = torch.empty((P, Mp), dtype=torch.float64, device=dev)
             with torch.cuda.device(dev):
-                B.check(self._fn("tsvgp_site_accum")(A.data_ptr(), g0.data_ptr(), g1.data_ptr(), acc2.data_ptr(),
-                                                     acc1.data_ptr(), work.data_ptr(), Np, Mp, P, nsplit,
-                                                     self._stream()), "tsvgp_site_accum")
+                self._launch("tsvgp_site_accum", lambda: self._fn("tsvgp_site_accum")(
+                    A.data_ptr(), g0.data_ptr(), g1.data_ptr(), acc2.data_ptr(), acc1.data_ptr(), work.data_ptr(), Np,
+                    Mp, P, nsplit, self._stream()))
             stats.acc2 = acc2[:, :M, :M]
             stats.acc1 = acc1[:, :M]
         return stats
