@@ -29,7 +29,6 @@ namespace {
 
 constexpr int TILE = TSVGP_TILE;  // 128
 constexpr int KC = 16;            // k-chunk
-constexpr int LDS_RS = 18;        // [row][k] image: row stride (elements)
 constexpr int LDS_KS = 144;       // [k][row] image: k stride (elements)
 constexpr int NTHREADS = 256;
 constexpr int MODE_STORE = 0;
@@ -65,7 +64,15 @@ struct Mfma<float> {
     static __device__ __forceinline__ int row(int lane, int r) { return (lane >> 4) * 4 + r; }
 };
 
-// 8 consecutive elements of one row: global -> registers (16-byte loads) and registers -> LDS.
+// [row][k] LDS image: row stride in elements.  17 doubles / 18 floats make the fragment reads (the compiler pairs them
+// as ds_read2_b64 / ds_read2_b32, banked modulo 32 dwords per lane group) and the 8-byte staging writes conflict free.
+template <typename T>
+struct RowStride {
+    static constexpr int value = sizeof(T) == 8 ? 17 : 18;
+};
+
+// 8 consecutive elements of one row: global -> registers (16-byte loads) and registers -> LDS (8-byte stores: the rows
+// of the double image are only 8-byte aligned).
 template <typename T>
 __device__ __forceinline__ void load8(T (&r)[8], const T* __restrict__ p) {
     if constexpr (sizeof(T) == 8) {
@@ -87,56 +94,76 @@ __device__ __forceinline__ void load8(T (&r)[8], const T* __restrict__ p) {
     }
 }
 template <typename T>
-__device__ __forceinline__ void store_pairs8(T* p, const T (&r)[8]) {
-    typedef typename Mfma<T>::pair_t pair_t;
+__device__ __forceinline__ void store_rowk8(T* p, const T (&r)[8]) {
+    if constexpr (sizeof(T) == 8) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        pair_t v;
-        v[0] = r[2 * q];
-        v[1] = r[2 * q + 1];
-        *reinterpret_cast<pair_t*>(p + 2 * q) = v;
+        for (int q = 0; q < 8; ++q) p[q] = r[q];
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            v2f v;
+            v[0] = r[2 * q];
+            v[1] = r[2 * q + 1];
+            *reinterpret_cast<v2f*>(p + 2 * q) = v;
+        }
     }
 }
 
-// One k-chunk (16) of MFMAs on [row][k] images: acc[mt][nt] += A(64 x 16) * B(64 x 16)^T for this wave.
-template <typename T>
-__device__ __forceinline__ void mma_chunk_rowk(typename Mfma<T>::acc_t (&acc)[4][4], const T* __restrict__ As,
-                                               const T* __restrict__ Bs, int wm, int wn, int lane) {
+// Wave w (0..3) of a workgroup owns the 16-row blocks {w, 7 - w} and ALL eight 16-column blocks of the 128x128 tile
+// (32 x 128 per wave, acc[2][8]).  Every wave therefore sees the same column structure -- the k-tile on the diagonal
+// of a triangular product skips the same (chunk, column block) pairs in all waves, with compile-time masks -- and the
+// row pairing {w, 7 - w} gives every wave 9 of its 16 accumulators on a diagonal tile of the symmetric product.
+__device__ __forceinline__ int row_block(int w, int slot) { return slot == 0 ? w : 7 - w; }
+
+// One k-chunk (16) of MFMAs on [row][k] images: acc[s][n] += A(row block s) * B(column block n)^T.
+// NMASK (compile time): bit n set = column block n takes part.
+template <typename T, int NMASK>
+__device__ __forceinline__ void mma_chunk_rowk(typename Mfma<T>::acc_t (&acc)[2][8], const T* __restrict__ As,
+                                               const T* __restrict__ Bs, int w, int lane) {
+    constexpr int RS = RowStride<T>::value;
     const int lr = lane & 15, lk = lane >> 4;
-    const T* ap = As + (wm * 64 + lr) * LDS_RS + lk;
-    const T* bp = Bs + (wn * 64 + lr) * LDS_RS + lk;
+    const T* ap0 = As + (w * 16 + lr) * RS + lk;
+    const T* ap1 = As + ((7 - w) * 16 + lr) * RS + lk;
+    const T* bp = Bs + lr * RS + lk;
 #pragma unroll
     for (int ks = 0; ks < KC / 4; ++ks) {
-        T a[4], b[4];
+        T a[2], b[8];
+        a[0] = ap0[ks * 4];
+        a[1] = ap1[ks * 4];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) a[m] = ap[m * 16 * LDS_RS + ks * 4];
+        for (int n = 0; n < 8; ++n)
+            if (NMASK & (1 << n)) b[n] = bp[n * 16 * RS + ks * 4];
 #pragma unroll
-        for (int n = 0; n < 4; ++n) b[n] = bp[n * 16 * LDS_RS + ks * 4];
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int n = 0; n < 4; ++n) acc[m][n] = Mfma<T>::run(a[m], b[n], acc[m][n]);
+        for (int n = 0; n < 8; ++n)
+            if (NMASK & (1 << n)) {
+                acc[0][n] = Mfma<T>::run(a[0], b[n], acc[0][n]);
+                acc[1][n] = Mfma<T>::run(a[1], b[n], acc[1][n]);
+            }
     }
 }
 
-// One k-chunk (16) of MFMAs on [k][row] images.
-template <typename T>
-__device__ __forceinline__ void mma_chunk_krow(typename Mfma<T>::acc_t (&acc)[4][4], const T* __restrict__ As,
-                                               const T* __restrict__ Bs, int wm, int wn, int lane) {
+// One k-chunk (16) of MFMAs on [k][row] images.  DIAG: only accumulators with column block <= row block
+// (W = the wave index, compile time, selects the row blocks {W, 7 - W}).
+template <typename T, bool DIAG, int W>
+__device__ __forceinline__ void mma_chunk_krow(typename Mfma<T>::acc_t (&acc)[2][8], const T* __restrict__ As,
+                                               const T* __restrict__ Bs, int w, int lane) {
     const int lr = lane & 15, lk = lane >> 4;
-    const T* ap = As + lk * LDS_KS + wm * 64 + lr;
-    const T* bp = Bs + lk * LDS_KS + wn * 64 + lr;
+    const T* ap0 = As + lk * LDS_KS + w * 16 + lr;
+    const T* ap1 = As + lk * LDS_KS + (7 - w) * 16 + lr;
+    const T* bp = Bs + lk * LDS_KS + lr;
 #pragma unroll
     for (int ks = 0; ks < KC / 4; ++ks) {
-        T a[4], b[4];
+        T a[2], b[8];
+        a[0] = ap0[ks * 4 * LDS_KS];
+        a[1] = ap1[ks * 4 * LDS_KS];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) a[m] = ap[ks * 4 * LDS_KS + m * 16];
+        for (int n = 0; n < 8; ++n)
+            if (!DIAG || n <= 7 - W || n <= W) b[n] = bp[ks * 4 * LDS_KS + n * 16];
 #pragma unroll
-        for (int n = 0; n < 4; ++n) b[n] = bp[ks * 4 * LDS_KS + n * 16];
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int n = 0; n < 4; ++n) acc[m][n] = Mfma<T>::run(a[m], b[n], acc[m][n]);
+        for (int n = 0; n < 8; ++n) {
+            if (!DIAG || n <= W) acc[0][n] = Mfma<T>::run(a[0], b[n], acc[0][n]);
+            if (!DIAG || n <= 7 - W) acc[1][n] = Mfma<T>::run(a[1], b[n], acc[1][n]);
+        }
     }
 }
 
@@ -278,121 +305,164 @@ struct PanelArgs {
     int Mp, P, mode, lik;
 };
 
-template <typename T, int MODE>
+template <typename T, int MODE, int TRI>
 __global__ __launch_bounds__(NTHREADS, 2) void panel_kernel(PanelArgs<T> a) {
-    __shared__ __attribute__((aligned(16))) T lds[2][2][TILE * LDS_RS];
-    __shared__ double rowq[2][TILE];
+    constexpr int RS = RowStride<T>::value;
+    constexpr int CPT = TILE / KC;  // chunks per 128-wide k-tile
+    __shared__ __attribute__((aligned(16))) T lds[2][2][TILE * RS];
+    __shared__ double rowq[TILE];
     __shared__ double red[NTHREADS / 64];
     __shared__ int redi[NTHREADS / 64];
     typedef typename Mfma<T>::acc_t acc_t;
 
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int srow = t >> 1, skh = t & 1;  // staging role: row of the tile, which half of the k-chunk
     const int64_t n0 = (int64_t)blockIdx.x * TILE;
     const int Mp = a.Mp;
     const int ntile = Mp / TILE, nchunk = Mp / KC;
-    const int gemv_it = (a.mode == TSVGP_TRI_LOWER) ? ntile - 1 : 0;  // the pass whose k-range covers every j
 
     const T* Arow = a.A + (n0 + srow) * (int64_t)Mp + skh * 8;
+    T* const lds_wr = &lds[0][0][srow * RS + skh * 8];
+    constexpr int BUF_STRIDE = 2 * TILE * RS, OP_STRIDE = TILE * RS;
     double ve_acc = 0.0;
     int nonpos = 0;
 
     for (int p = 0; p < a.P; ++p) {
         const T* Tp = a.Tm + (size_t)p * Mp * Mp;
-        // Row sums of squares: after every column tile the 16 per-register partials are summed over the 16 lanes that
-        // share (lane>>4) and lane lr keeps the one with index lr (m = lr>>2, r = lr&3): one live double, not 16.
+        // Row sums of squares: after every column tile the 8 per-register partials (2 row blocks x 4 registers) are
+        // summed over the 16 lanes that share (lane>>4) and lane lr keeps the one with index lr & 7.
         double rs_mine = 0.0;
         T mpart = T(0);
+        if constexpr (MODE == MODE_MOMENTS) {
+            // Mean GEMV phase: mean[n] = sum_j A[n, j] * gamma[j, p].  A memory/VALU-only sweep of this workgroup's row
+            // panel with no accumulators live (it runs beside the partner workgroup's MFMAs on the same CU); gamma_p
+            // is staged in LDS (reusing the staging buffers) and read as a two-address broadcast.
+            T* gs = &lds[0][0][0];
+            for (int j = t; j < Mp; j += NTHREADS) gs[j] = a.gamma[(size_t)j * a.P + p];
+            __syncthreads();
+            const T* gk = gs + skh * 8;
+#pragma unroll 4
+            for (int c = 0; c < nchunk; ++c) {
+                T ra[8];
+                load8(ra, Arow + c * KC);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) mpart += ra[q] * gk[c * KC + q];
+            }
+            __syncthreads();
+        }
 
         for (int it = 0; it < ntile; ++it) {
-            int c_lo = 0, c_hi = nchunk;
-            if (a.mode == TSVGP_TRI_LOWER) c_hi = (it + 1) * (TILE / KC);
-            if (a.mode == TSVGP_TRI_UPPER) c_lo = it * (TILE / KC);
-            const bool do_gemv = (MODE == MODE_MOMENTS) && (it == gemv_it);
             const T* Trow = Tp + (size_t)(it * TILE + srow) * Mp + skh * 8;
 
-            acc_t acc[4][4];
+            acc_t acc[2][8];
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
+            for (int s = 0; s < 2; ++s)
 #pragma unroll
-                for (int n = 0; n < 4; ++n) acc[m][n] = acc_t{0, 0, 0, 0};
+                for (int n = 0; n < 8; ++n) acc[s][n] = acc_t{0, 0, 0, 0};
 
             T ra[8], rb[8];
-            load8(ra, Arow + c_lo * KC);
-            load8(rb, Trow + c_lo * KC);
-            if (do_gemv) {
-                const T* g = a.gamma + (size_t)(c_lo * KC + skh * 8) * a.P + p;
-#pragma unroll
-                for (int q = 0; q < 8; ++q) mpart += ra[q] * g[q * a.P];
-            }
-            store_pairs8(&lds[0][0][srow * LDS_RS + skh * 8], ra);
-            store_pairs8(&lds[0][1][srow * LDS_RS + skh * 8], rb);
+            int buf = 0;
+            // one pipeline step: prefetch chunk `cnext` to registers, MFMAs on the chunk in LDS buffer `buf`, then stage
+            // the prefetched chunk into the other buffer; one barrier per chunk.
+#define TSVGP_FETCH(cnext)                    \
+    {                                         \
+        load8(ra, Arow + (cnext) * KC);       \
+        load8(rb, Trow + (cnext) * KC);       \
+    }
+#define TSVGP_STAGE(cnext, b_)                                   \
+    {                                                            \
+        store_rowk8(lds_wr + (b_) * BUF_STRIDE, ra);             \
+        store_rowk8(lds_wr + (b_) * BUF_STRIDE + OP_STRIDE, rb); \
+    }
+#define TSVGP_STEP(NMASK, cnext, has_next)                                                      \
+    {                                                                                           \
+        if (has_next) TSVGP_FETCH(cnext)                                                        \
+        mma_chunk_rowk<T, NMASK>(acc, &lds[buf][0][0], &lds[buf][1][0], w, lane);               \
+        if (has_next) TSVGP_STAGE(cnext, buf ^ 1)                                               \
+        __syncthreads();                                                                        \
+        buf ^= 1;                                                                               \
+    }
+            const int c_first = (TRI == TSVGP_TRI_UPPER) ? it * CPT : 0;
+            TSVGP_FETCH(c_first)
+            TSVGP_STAGE(c_first, 0)
             __syncthreads();
 
-            int buf = 0;
-            for (int c = c_lo; c < c_hi; ++c) {
-                const bool has_next = (c + 1 < c_hi);
-                if (has_next) {
-                    load8(ra, Arow + (c + 1) * KC);
-                    load8(rb, Trow + (c + 1) * KC);
-                }
-                mma_chunk_rowk<T>(acc, lds[buf][0], lds[buf][1], wm, wn, lane);
-                if (has_next) {
-                    if (do_gemv) {
-                        const T* g = a.gamma + (size_t)((c + 1) * KC + skh * 8) * a.P + p;
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) mpart += ra[q] * g[q * a.P];
-                    }
-                    store_pairs8(&lds[buf ^ 1][0][srow * LDS_RS + skh * 8], ra);
-                    store_pairs8(&lds[buf ^ 1][1][srow * LDS_RS + skh * 8], rb);
-                }
-                __syncthreads();
-                buf ^= 1;
+            if constexpr (TRI == TSVGP_TRI_DENSE) {
+                for (int c = 0; c < nchunk; ++c) TSVGP_STEP(0xFF, c + 1, (c + 1 < nchunk))
+            } else if constexpr (TRI == TSVGP_TRI_LOWER) {
+                // full k-tiles 0..it-1, then the diagonal k-tile: chunk cl only meets column blocks cb >= cl
+                const int cd = it * CPT;
+                for (int c = 0; c < cd; ++c) TSVGP_STEP(0xFF, c + 1, true)
+                TSVGP_STEP(0xFF, cd + 1, true)
+                TSVGP_STEP(0xFE, cd + 2, true)
+                TSVGP_STEP(0xFC, cd + 3, true)
+                TSVGP_STEP(0xF8, cd + 4, true)
+                TSVGP_STEP(0xF0, cd + 5, true)
+                TSVGP_STEP(0xE0, cd + 6, true)
+                TSVGP_STEP(0xC0, cd + 7, true)
+                TSVGP_STEP(0x80, cd + 8, false)
+            } else {
+                // the diagonal k-tile first: chunk cl only meets column blocks cb <= cl; then full k-tiles it+1..
+                const int cd = it * CPT;
+                const bool more = (it + 1 < ntile);
+                TSVGP_STEP(0x01, cd + 1, true)
+                TSVGP_STEP(0x03, cd + 2, true)
+                TSVGP_STEP(0x07, cd + 3, true)
+                TSVGP_STEP(0x0F, cd + 4, true)
+                TSVGP_STEP(0x1F, cd + 5, true)
+                TSVGP_STEP(0x3F, cd + 6, true)
+                TSVGP_STEP(0x7F, cd + 7, true)
+                TSVGP_STEP(0xFF, cd + 8, more)
+                for (int c = cd + CPT; c < nchunk; ++c) TSVGP_STEP(0xFF, c + 1, (c + 1 < nchunk))
             }
+#undef TSVGP_STEP
+#undef TSVGP_STAGE
+#undef TSVGP_FETCH
 
             if constexpr (MODE == MODE_STORE) {
-                T* Cb = a.C + (n0 + wm * 64) * (int64_t)Mp + it * TILE + wn * 64 + (lane & 15);
+                T* Cb = a.C + n0 * (int64_t)Mp + it * TILE + (lane & 15);
 #pragma unroll
-                for (int m = 0; m < 4; ++m)
+                for (int s = 0; s < 2; ++s)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        T* Cr = Cb + (int64_t)(m * 16 + Mfma<T>::row(lane, r)) * Mp;
+                        T* Cr = Cb + (int64_t)(row_block(w, s) * 16 + Mfma<T>::row(lane, r)) * Mp;
 #pragma unroll
-                        for (int n = 0; n < 4; ++n) Cr[n * 16] = acc[m][n][r];
+                        for (int n = 0; n < 8; ++n) Cr[n * 16] = acc[s][n][r];
                     }
             } else {
                 double keep = 0.0;
 #pragma unroll
-                for (int m = 0; m < 4; ++m)
+                for (int s = 0; s < 2; ++s)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        double s = 0.0;
+                        double q = 0.0;
 #pragma unroll
-                        for (int n = 0; n < 4; ++n) {
-                            const double v = (double)acc[m][n][r];
-                            s += v * v;
+                        for (int n = 0; n < 8; ++n) {
+                            const double v = (double)acc[s][n][r];
+                            q += v * v;
                         }
-                        s += __shfl_xor(s, 1);
-                        s += __shfl_xor(s, 2);
-                        s += __shfl_xor(s, 4);
-                        s += __shfl_xor(s, 8);
-                        keep = ((lane & 15) == m * 4 + r) ? s : keep;
+                        q += __shfl_xor(q, 1);
+                        q += __shfl_xor(q, 2);
+                        q += __shfl_xor(q, 4);
+                        q += __shfl_xor(q, 8);
+                        keep = ((lane & 7) == s * 4 + r) ? q : keep;
                     }
                 rs_mine += keep;
             }
         }  // it
 
         if constexpr (MODE == MODE_MOMENTS) {
-            // row sums: lane (lr, lane>>4) holds the sum of row (lr>>2)*16 + rowmap(lane, lr&3); add the two column waves through LDS
-            {
+            // lane (lr < 8, lane>>4) holds the complete sum of row  row_block(w, lr>>2)*16 + rowmap(lane, lr&3)
+            if ((lane & 15) < 8) {
                 const int lr = lane & 15;
-                rowq[wn][wm * 64 + (lr >> 2) * 16 + Mfma<T>::row(lane, lr & 3)] = rs_mine;
+                rowq[row_block(w, lr >> 2) * 16 + Mfma<T>::row(lane, lr & 3)] = rs_mine;
             }
             mpart += __shfl_xor(mpart, 1);
             __syncthreads();
             if (skh == 0) {
                 const int64_t n = n0 + srow;
-                const double q = rowq[0][srow] + rowq[1][srow];
+                const double q = rowq[srow];
                 const double mu = (double)mpart;
                 const double v = a.kdiag - q;
                 double g0 = 0.0, g1 = 0.0, ve = 0.0;
@@ -423,8 +493,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void panel_kernel(PanelArgs<T> a) {
             c += __shfl_xor(c, o);
         }
         if (lane == 0) {
-            red[wave] = s;
-            redi[wave] = c;
+            red[w] = s;
+            redi[w] = c;
         }
         __syncthreads();
         if (t == 0) {
@@ -435,19 +505,23 @@ __global__ __launch_bounds__(NTHREADS, 2) void panel_kernel(PanelArgs<T> a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// syrk_kernel: workgroup (p, split s, lower tile (it, jt)) accumulates over its N-slice
+// syrk_kernel: workgroup (p, lower tile (it, jt), split s) accumulates over its N-slice
 //   part2[128 x 128] = sum_n g1[n,p] B[n, it*128 + :] (x) B[n, jt*128 + :],   diagonal tiles also part1 = sum_n g0 B.
+// Diagonal tiles (it == jt) only compute accumulators with column block <= row block: 9 of 16 per wave and k-step
+// (row blocks {w, 7 - w}), so they get N-slices 16/9 as long: ns_diag = ceil(9/16 ns_off) splits instead of ns_off.
+// Workgroup order: all off-diagonal tiles of split 0, of split 1, ...; then the diagonal tiles the same way; remapped
+// so that workgroups sharing an XCD (blockIdx % 8) get a contiguous range, i.e. mostly one N-slice -> shared L2 lines.
 // ---------------------------------------------------------------------------------------------------------------
 template <typename T>
 struct SyrkArgs {
     const T* B;   // [Np x Mp]
     const T* g0;  // [Np x P]
     const T* g1;  // [Np x P]
-    T* part2;     // [P][nsplit][ntri][128*128]
-    T* part1;     // [P][nsplit][Mp]
+    T* part2;     // [P][slabs_per_p][128*128], slab(tri, s) = (tri - it) * ns_off + it * ns_diag + s
+    T* part1;     // [P][ns_diag][Mp]
     int64_t Np;
-    int Mp, P, nsplit, ntri;
-    int64_t chunks_per_split;  // in units of KC rows
+    int Mp, P, nt, ns_off, ns_diag;
+    int64_t chunks_off, chunks_diag;  // N-slice lengths in units of KC rows
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -456,41 +530,36 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
 }
 
-template <typename T>
-__global__ __launch_bounds__(NTHREADS, 2) void syrk_kernel(SyrkArgs<T> a) {
-    __shared__ __attribute__((aligned(16))) T lds[2][2][KC * LDS_KS];
-    __shared__ T g0s[2][KC];
+__host__ __device__ inline int syrk_ns_diag(int ns_off) {
+    const int d = (9 * ns_off + 15) / 16;
+    return d < 1 ? 1 : d;
+}
+
+// The chunk loop of one workgroup.  DIAG / W are compile time so that the MFMA sequence is straight-line code.
+template <typename T, bool DIAG, int W>
+__device__ __forceinline__ void syrk_body(const SyrkArgs<T>& a, T (*lds)[2][KC * LDS_KS], T (*g0s)[KC], int p, int it,
+                                          int jt, int sidx, int slab, int per_p, int w) {
     typedef typename Mfma<T>::acc_t acc_t;
     typedef typename Mfma<T>::pair_t pair_t;
-
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
-    const int lin = xcd_remap(blockIdx.x, gridDim.x);
-    const int tri = lin % a.ntri;
-    const int s = (lin / a.ntri) % a.nsplit;
-    const int p = lin / (a.ntri * a.nsplit);
-    int it = 0;
-    while ((it + 1) * (it + 2) / 2 <= tri) ++it;
-    const int jt = tri - it * (it + 1) / 2;
-    const bool diag = (it == jt);
+    const int t = threadIdx.x, lane = t & 63;
     const int Mp = a.Mp, P = a.P;
-
     const int64_t total_chunks = a.Np / KC;
-    const int64_t c_lo = (int64_t)s * a.chunks_per_split;
-    int64_t c_hi = c_lo + a.chunks_per_split;
+    const int64_t per = DIAG ? a.chunks_diag : a.chunks_off;
+    int64_t c_lo = (int64_t)sidx * per;
+    int64_t c_hi = c_lo + per;
+    if (c_lo > total_chunks) c_lo = total_chunks;
     if (c_hi > total_chunks) c_hi = total_chunks;
 
-    // staging role: k-row of the chunk and four 16-byte pieces (2 doubles / 2 floats x2) spread over the 128 columns
+    // staging role: k-row of the chunk and four 16-byte (fp64) / 8-byte (fp32) pieces spread over the 128 columns
     const int krow = t >> 4, cseg = t & 15;
-    constexpr int PW = 2;  // elements per piece handled as a pair
-    // per thread: 4 pieces at columns q*32 + cseg*2 (+0,1)  -> 8 elements of the i panel and 8 of the j panel
-    const T* Bi = a.B + (int64_t)krow * Mp + it * TILE + cseg * PW;
-    const T* Bj = a.B + (int64_t)krow * Mp + jt * TILE + cseg * PW;
+    const T* Bi = a.B + (int64_t)krow * Mp + it * TILE + cseg * 2;
+    const T* Bj = a.B + (int64_t)krow * Mp + jt * TILE + cseg * 2;
 
-    acc_t acc[4][4];
+    acc_t acc[2][8];
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int n = 0; n < 4; ++n) acc[m][n] = acc_t{0, 0, 0, 0};
+        for (int n = 0; n < 8; ++n) acc[s][n] = acc_t{0, 0, 0, 0};
     T acc1 = T(0);
 
     pair_t ri[4], rj[4];
@@ -498,61 +567,146 @@ __global__ __launch_bounds__(NTHREADS, 2) void syrk_kernel(SyrkArgs<T> a) {
     auto load_chunk = [&](int64_t c) {
         const int64_t n = c * KC + krow;
         const T* bi = Bi + c * KC * (int64_t)Mp;
-        const T* bj = Bj + c * KC * (int64_t)Mp;
 #pragma unroll
         for (int q = 0; q < 4; ++q) ri[q] = *reinterpret_cast<const pair_t*>(bi + q * 32);
-        if (!diag) {
+        if constexpr (!DIAG) {
+            const T* bj = Bj + c * KC * (int64_t)Mp;
 #pragma unroll
             for (int q = 0; q < 4; ++q) rj[q] = *reinterpret_cast<const pair_t*>(bj + q * 32);
         }
         w1 = a.g1[n * P + p];
-        if (diag && cseg == 0) w0 = a.g0[n * P + p];
+        if (DIAG && cseg == 0) w0 = a.g0[n * P + p];
     };
     auto store_chunk = [&](int buf) {
-        T* Ai = &lds[buf][0][krow * LDS_KS + cseg * PW];
-        T* Aj = &lds[buf][1][krow * LDS_KS + cseg * PW];
+        T* Ai = &lds[buf][0][krow * LDS_KS + cseg * 2];
+        T* Aj = &lds[buf][1][krow * LDS_KS + cseg * 2];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             pair_t sc;
             sc[0] = ri[q][0] * w1;
             sc[1] = ri[q][1] * w1;
             *reinterpret_cast<pair_t*>(Ai + q * 32) = sc;
-            *reinterpret_cast<pair_t*>(Aj + q * 32) = diag ? ri[q] : rj[q];
+            *reinterpret_cast<pair_t*>(Aj + q * 32) = DIAG ? ri[q] : rj[q];
         }
-        if (diag && cseg == 0) g0s[buf][krow] = w0;
+        if (DIAG && cseg == 0) g0s[buf][krow] = w0;
     };
 
+#if defined(TSVGP_DIAG_CLOCK)
+    unsigned long long seg[4] = {0, 0, 0, 0};
+#define STAMP(i)
+    const unsigned long long tstart = __builtin_amdgcn_s_memtime();
+    const unsigned long long rstart = __builtin_amdgcn_s_memrealtime();
+#elif defined(TSVGP_DIAG_STAMPS)
+    unsigned long long seg[4] = {0, 0, 0, 0}, tprev;
+#define STAMP(i)                                                                             \
+    {                                                                                        \
+        unsigned long long tn;                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tn)::"memory");           \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        seg[i] += tn - tprev;                                                                \
+        tprev = tn;                                                                          \
+    }
+    const unsigned long long tstart = __builtin_amdgcn_s_memtime();
+    const unsigned long long rstart = __builtin_amdgcn_s_memrealtime();
+#else
+#define STAMP(i)
+#endif
     if (c_lo < c_hi) {
         load_chunk(c_lo);
         store_chunk(0);
     }
     __syncthreads();
     int buf = 0;
+#ifdef TSVGP_DIAG_STAMPS
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory");
+#endif
     for (int64_t c = c_lo; c < c_hi; ++c) {
         const bool has_next = (c + 1 < c_hi);
         if (has_next) load_chunk(c + 1);
-        mma_chunk_krow<T>(acc, lds[buf][0], lds[buf][1], wm, wn, lane);
-        if (diag && t < TILE) {
+        STAMP(0)
+        mma_chunk_krow<T, DIAG, W>(acc, lds[buf][0], lds[buf][1], w, lane);
+        STAMP(1)
+        if (DIAG && t < TILE) {
             const T* bcol = &lds[buf][1][t];
 #pragma unroll
             for (int k = 0; k < KC; ++k) acc1 += g0s[buf][k] * bcol[k * LDS_KS];
         }
         if (has_next) store_chunk(buf ^ 1);
+        STAMP(2)
         __syncthreads();
+        STAMP(3)
         buf ^= 1;
     }
+#if defined(TSVGP_DIAG_STAMPS) || defined(TSVGP_DIAG_CLOCK)
+    if (lane == 0) {
+        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(a.part1 + (size_t)a.P * a.ns_diag * a.Mp) + ((size_t)blockIdx.x * 4 + w) * 8;
+        dbg[0] = seg[0]; dbg[1] = seg[1]; dbg[2] = seg[2]; dbg[3] = seg[3];
+        dbg[4] = __builtin_amdgcn_s_memtime() - tstart;
+        dbg[5] = __builtin_amdgcn_s_memrealtime() - rstart;
+        dbg[6] = (unsigned long long)(c_hi - c_lo);
+        dbg[7] = DIAG;
+#if defined(TSVGP_DIAG_CLOCK)
+        dbg[0] = rstart;                             // absolute start (100 MHz ticks)
+        dbg[1] = __builtin_amdgcn_s_memrealtime();   // absolute end
+        dbg[2] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));   // HW_REG_HW_ID
+        dbg[3] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11));  // HW_REG_XCC_ID
+#endif
+    }
+#endif
+#undef STAMP
 
-    T* out = a.part2 + ((size_t)(p * a.nsplit + s) * a.ntri + tri) * (TILE * TILE);
-    T* ob = out + (wm * 64) * TILE + wn * 64 + (lane & 15);
+    T* out = a.part2 + ((size_t)p * per_p + slab) * (TILE * TILE) + (lane & 15);
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            T* orow = ob + (m * 16 + Mfma<T>::row(lane, r)) * TILE;
+            T* orow = out + (row_block(w, s) * 16 + Mfma<T>::row(lane, r)) * TILE;
 #pragma unroll
-            for (int n = 0; n < 4; ++n) orow[n * 16] = acc[m][n][r];
+            for (int n = 0; n < 8; ++n)
+                if (!DIAG || n <= (s == 0 ? W : 7 - W)) orow[n * 16] = acc[s][n][r];
         }
-    if (diag && t < TILE) a.part1[(size_t)(p * a.nsplit + s) * Mp + it * TILE + t] = acc1;
+    if (DIAG && t < TILE) a.part1[((size_t)p * a.ns_diag + sidx) * Mp + it * TILE + t] = acc1;
+}
+
+template <typename T>
+__global__ __launch_bounds__(NTHREADS, 2) void syrk_kernel(SyrkArgs<T> a) {
+    __shared__ __attribute__((aligned(16))) T lds[2][2][KC * LDS_KS];
+    __shared__ T g0s[2][KC];
+
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nt = a.nt, n_off = nt * (nt - 1) / 2;
+    const int per_p = n_off * a.ns_off + nt * a.ns_diag;
+    int lin = xcd_remap(blockIdx.x, gridDim.x);
+    const int p = lin / per_p;
+    lin -= p * per_p;
+    int it, jt, sidx;
+    if (lin < n_off * a.ns_off) {
+        sidx = lin / n_off;
+        const int idx = lin - sidx * n_off;  // idx-th pair (it, jt) with jt < it
+        it = 1;
+        while (it * (it + 1) / 2 <= idx) ++it;
+        jt = idx - it * (it - 1) / 2;
+    } else {
+        lin -= n_off * a.ns_off;
+        sidx = lin / nt;
+        it = jt = lin - sidx * nt;
+    }
+    const int tri = it * (it + 1) / 2 + jt;
+    const int slab = (tri - it) * a.ns_off + it * a.ns_diag + sidx;
+
+    // top-level uniform dispatch: no live state crosses the branches, each body is straight-line MFMA code
+    if (it != jt) {
+        syrk_body<T, false, 0>(a, lds, g0s, p, it, jt, sidx, slab, per_p, w);
+    } else if (w == 0) {
+        syrk_body<T, true, 0>(a, lds, g0s, p, it, jt, sidx, slab, per_p, w);
+    } else if (w == 1) {
+        syrk_body<T, true, 1>(a, lds, g0s, p, it, jt, sidx, slab, per_p, w);
+    } else if (w == 2) {
+        syrk_body<T, true, 2>(a, lds, g0s, p, it, jt, sidx, slab, per_p, w);
+    } else {
+        syrk_body<T, true, 3>(a, lds, g0s, p, it, jt, sidx, slab, per_p, w);
+    }
 }
 
 // Sums the partial tiles over the splits in a fixed order and writes the full symmetric matrix (fp64).
@@ -560,37 +714,35 @@ template <typename T>
 __global__ __launch_bounds__(NTHREADS) void syrk_reduce_kernel(const T* __restrict__ part2,
                                                                const T* __restrict__ part1,
                                                                double* __restrict__ acc2, double* __restrict__ acc1,
-                                                               int Mp, int P, int nsplit, int ntri) {
-    // grid.x = ntri * 64 (each block: 2 rows of 128 of one tile), grid.y = P ; extra blocks handle acc1
+                                                               int Mp, int P, int nt, int ns_off, int ns_diag) {
+    // grid.x = ntri * 64 (each block: 2 rows of 128 of one tile) + blocks for acc1, grid.y = P
     const int p = blockIdx.y;
+    const int ntri = nt * (nt + 1) / 2;
+    const int per_p = (ntri - nt) * ns_off + nt * ns_diag;
     const int tri = blockIdx.x / 64, sub = blockIdx.x % 64;
     const int t = threadIdx.x;
     if (tri < ntri) {
         int it = 0;
         while ((it + 1) * (it + 2) / 2 <= tri) ++it;
         const int jt = tri - it * (it + 1) / 2;
+        const int ns = (it == jt) ? ns_diag : ns_off;
+        const int slab0 = (tri - it) * ns_off + it * ns_diag;
         const int ii = sub * 2 + (t >> 7), jj = t & 127;
+        // diagonal tile: only 16x16 blocks with column block <= row block were accumulated; inside the diagonal
+        // blocks keep the lower triangle; everything is mirrored below (exactly symmetric output)
+        if (it == jt && jj > ii) return;
         double s = 0.0;
-        for (int sp = 0; sp < nsplit; ++sp)
-            s += (double)part2[((size_t)(p * nsplit + sp) * ntri + tri) * (TILE * TILE) + ii * TILE + jj];
+        for (int sp = 0; sp < ns; ++sp)
+            s += (double)part2[((size_t)p * per_p + slab0 + sp) * (TILE * TILE) + ii * TILE + jj];
         const size_t base = (size_t)p * Mp * Mp;
         const int gi = it * TILE + ii, gj = jt * TILE + jj;
-        if (it != jt) {
-            acc2[base + (size_t)gi * Mp + gj] = s;
-            acc2[base + (size_t)gj * Mp + gi] = s;
-        } else {
-            // diagonal tile: keep the lower triangle of the computed tile and mirror it (exactly symmetric output)
-            if (jj <= ii) {
-                acc2[base + (size_t)gi * Mp + gj] = s;
-                acc2[base + (size_t)gj * Mp + gi] = s;
-            }
-        }
+        acc2[base + (size_t)gi * Mp + gj] = s;
+        acc2[base + (size_t)gj * Mp + gi] = s;
     } else {
-        // acc1
         const int idx = (blockIdx.x - ntri * 64) * NTHREADS + t;
         if (idx < Mp) {
             double s = 0.0;
-            for (int sp = 0; sp < nsplit; ++sp) s += (double)part1[(size_t)(p * nsplit + sp) * Mp + idx];
+            for (int sp = 0; sp < ns_diag; ++sp) s += (double)part1[((size_t)p * ns_diag + sp) * Mp + idx];
             acc1[(size_t)p * Mp + idx] = s;
         }
     }
@@ -644,8 +796,13 @@ int trmm(const T* A, const T* Tm, T* C, int64_t Np, int Mp, int mode, void* stre
     a.Mp = Mp;
     a.P = 1;
     a.mode = mode;
-    hipLaunchKernelGGL((panel_kernel<T, MODE_STORE>), dim3((unsigned)(Np / TILE)), dim3(NTHREADS), 0,
-                       (hipStream_t)stream, a);
+    const dim3 grid((unsigned)(Np / TILE)), block(NTHREADS);
+    if (mode == TSVGP_TRI_LOWER)
+        hipLaunchKernelGGL((panel_kernel<T, MODE_STORE, TSVGP_TRI_LOWER>), grid, block, 0, (hipStream_t)stream, a);
+    else if (mode == TSVGP_TRI_UPPER)
+        hipLaunchKernelGGL((panel_kernel<T, MODE_STORE, TSVGP_TRI_UPPER>), grid, block, 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL((panel_kernel<T, MODE_STORE, TSVGP_TRI_DENSE>), grid, block, 0, (hipStream_t)stream, a);
     return launch_status();
 }
 
@@ -678,16 +835,23 @@ int moments(const T* A, const T* Tm, const T* gamma, const T* Y, double kdiag, i
     a.P = P;
     a.mode = mode;
     a.lik = lik;
-    hipLaunchKernelGGL((panel_kernel<T, MODE_MOMENTS>), dim3((unsigned)(Np / TILE)), dim3(NTHREADS), 0,
-                       (hipStream_t)stream, a);
+    const dim3 grid((unsigned)(Np / TILE)), block(NTHREADS);
+    if (mode == TSVGP_TRI_LOWER)
+        hipLaunchKernelGGL((panel_kernel<T, MODE_MOMENTS, TSVGP_TRI_LOWER>), grid, block, 0, (hipStream_t)stream, a);
+    else if (mode == TSVGP_TRI_UPPER)
+        hipLaunchKernelGGL((panel_kernel<T, MODE_MOMENTS, TSVGP_TRI_UPPER>), grid, block, 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL((panel_kernel<T, MODE_MOMENTS, TSVGP_TRI_DENSE>), grid, block, 0, (hipStream_t)stream, a);
     return launch_status();
 }
 
 template <typename T>
 int64_t site_accum_work_bytes(int Mp, int P, int nsplit) {
     if (Mp <= 0 || (Mp % TILE) || P <= 0 || nsplit <= 0) return -1;
-    const int64_t nt = Mp / TILE, ntri = nt * (nt + 1) / 2;
-    return (int64_t)P * nsplit * (ntri * TILE * TILE + Mp) * (int64_t)sizeof(T);
+    const int64_t nt = Mp / TILE, n_off = nt * (nt - 1) / 2;
+    const int64_t ns_diag = syrk_ns_diag(nsplit);
+    const int64_t per_p = n_off * nsplit + nt * ns_diag;
+    return (int64_t)P * (per_p * TILE * TILE + ns_diag * Mp) * (int64_t)sizeof(T);
 }
 
 template <typename T>
@@ -696,28 +860,30 @@ int site_accum(const T* B, const T* g0, const T* g1, double* acc2, double* acc1,
     if (!B || !g0 || !g1 || !acc2 || !acc1 || !work || Np <= 0 || (Np % TILE) || Mp <= 0 || (Mp % TILE) || P <= 0 ||
         nsplit <= 0)
         return TSVGP_EINVAL;
-    const int nt = Mp / TILE, ntri = nt * (nt + 1) / 2;
+    const int nt = Mp / TILE, ntri = nt * (nt + 1) / 2, n_off = ntri - nt;
     const int64_t total_chunks = Np / KC;
-    if (nsplit > total_chunks) nsplit = (int)total_chunks;
     SyrkArgs<T> a{};
     a.B = B;
     a.g0 = g0;
     a.g1 = g1;
-    a.part2 = reinterpret_cast<T*>(work);
-    a.part1 = a.part2 + (size_t)P * nsplit * ntri * TILE * TILE;
     a.Np = Np;
     a.Mp = Mp;
     a.P = P;
-    a.nsplit = nsplit;
-    a.ntri = ntri;
-    a.chunks_per_split = (total_chunks + nsplit - 1) / nsplit;
-    const int64_t nwg = (int64_t)P * nsplit * ntri;
+    a.nt = nt;
+    a.ns_off = nsplit;
+    a.ns_diag = syrk_ns_diag(nsplit);
+    a.chunks_off = (total_chunks + a.ns_off - 1) / a.ns_off;
+    a.chunks_diag = (total_chunks + a.ns_diag - 1) / a.ns_diag;
+    const int64_t per_p = (int64_t)n_off * a.ns_off + (int64_t)nt * a.ns_diag;
+    a.part2 = reinterpret_cast<T*>(work);
+    a.part1 = a.part2 + (size_t)P * per_p * TILE * TILE;
+    const int64_t nwg = (int64_t)P * per_p;
     if (nwg > 0x7fffffff) return TSVGP_EINVAL;
     hipLaunchKernelGGL(syrk_kernel<T>, dim3((unsigned)nwg), dim3(NTHREADS), 0, (hipStream_t)stream, a);
     if (launch_status() != TSVGP_OK) return TSVGP_ELAUNCH;
     const int extra = (Mp + NTHREADS - 1) / NTHREADS;
     hipLaunchKernelGGL(syrk_reduce_kernel<T>, dim3((unsigned)(ntri * 64 + extra), (unsigned)P), dim3(NTHREADS), 0,
-                       (hipStream_t)stream, a.part2, a.part1, acc2, acc1, Mp, P, nsplit, ntri);
+                       (hipStream_t)stream, a.part2, a.part1, acc2, acc1, Mp, P, nt, a.ns_off, a.ns_diag);
     return launch_status();
 }
 

@@ -105,6 +105,17 @@ class EStepEngine:
             self._slots = s
         return self._slots
 
+    def choose_nsplit(self, Mp: int, P: int) -> int:
+        """Largest number of N-slices (for off-diagonal tiles) whose workgroups all fit in one resident round:
+        n_off * ns + nt * ceil(9 ns / 16) <= slots / P  (diagonal tiles cost 9/16 and get 16/9-longer slices)."""
+        nt = Mp // B.TILE
+        n_off = nt * (nt - 1) // 2
+        budget = max(1, self.slots() // P)
+        ns = 1
+        while n_off * (ns + 1) + nt * ((9 * (ns + 1) + 15) // 16) <= budget:
+            ns += 1
+        return ns
+
     def _pad_square(self, A: torch.Tensor, Mp: int) -> torch.Tensor:
         """[.., M, M] fp64 -> zero-padded contiguous [.., Mp, Mp] in the compute dtype."""
         M = A.shape[-1]
@@ -215,9 +226,8 @@ class EStepEngine:
             stats.g0, stats.g1 = g0[:N].to(torch.float64), g1[:N].to(torch.float64)
 
         if sites:
-            ntri = (Mp // B.TILE) * (Mp // B.TILE + 1) // 2
-            nsplit = self.nsplit_override or max(1, self.slots() // (ntri * P))
-            nsplit = min(nsplit, Np // 16)
+            nsplit = self.nsplit_override or self.choose_nsplit(Mp, P)
+            nsplit = max(1, min(nsplit, Np // 16))
             nbytes = int(self._fn("tsvgp_site_accum_work_bytes")(Mp, P, nsplit))
             work = self._get("work", (nbytes,), torch.uint8)
             acc2 = torch.empty((P, Mp, Mp), dtype=torch.float64, device=dev)
