@@ -103,6 +103,14 @@ int tsvgp_site_accum_f64(const double *B, const double *g0, const double *g1, do
 int tsvgp_site_accum_f32(const float *B, const float *g0, const float *g1, double *acc2, double *acc1, void *work,
                          int64_t Np, int Mp, int P, int nsplit, void *stream);
 
+/* (6) Batched lower Cholesky of the M x M site matrices, in place:  A[b] = L[b] L[b]^T, L written to the lower triangle
+ *     of the 128x128 diagonal blocks and below (the strictly upper part of the diagonal blocks is zeroed; blocks above
+ *     the diagonal are left untouched).  Replaces tf.linalg.cholesky of reference src/models/tsvgp.py:270,300 and
+ *     src/util.py:377-388.  M must be a multiple of 128 (pad with an identity block), lda >= M, matrix b starts at
+ *     A + b*stride.  info[b] = 0, or the 1-based index of the first non-positive pivot (LAPACK potrf convention).
+ *     work: batch * 128 * 128 doubles. */
+int tsvgp_potrf_f64(double *A, int M, int lda, int batch, int64_t stride, int32_t *info, double *work, void *stream);
+
 /* Device self-test of the MFMA fragment maps used above (writes a 16x16 product C = A*B, k = 4, for host checking).
  * a [16 x 4], b [4 x 16], c [16 x 16] row-major. */
 int tsvgp_selftest_mfma_f64(const double *a, const double *b, double *c, void *stream);

@@ -748,6 +748,166 @@ __global__ __launch_bounds__(NTHREADS) void syrk_reduce_kernel(const T* __restri
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Blocked Cholesky of the M x M site matrices (K_uu + jitter I, W, the moments Gram, -2 lambda_2 + jitter I):
+// replaces tf.linalg.cholesky of reference src/models/tsvgp.py:270,300 and src/util.py:377-388 on the GPU.
+// Right-looking, 128-wide block columns, three kernels per block column k:
+//   potrf_diag_kernel   one workgroup: factor the 128x128 diagonal block in LDS (left-looking, one barrier per
+//                       column), write L_kk, then invert it in place (trti2) and write inv(L_kk) to `work`
+//   chol_tile_kernel<PANEL>   A[i,k] <- A[i,k] * inv(L_kk)^T            (one workgroup per tile below the diagonal)
+//   chol_tile_kernel<UPDATE>  A[i,j] <- A[i,j] - A[i,k] * A[j,k]^T      (one workgroup per trailing lower tile)
+// The tile products reuse the MFMA chunk code of the E-step kernels.  Latency bound by design (M^3/3 flops is
+// microseconds of MFMA time): the critical path is 8 diagonal blocks, each ~M/8 dependent column steps.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int CH_NB = 128;
+constexpr int CH_LD = CH_NB + 1;  // LDS row stride of the diagonal block (conflict-free row and column walks)
+
+constexpr int CH_THREADS = 1024;  // 8 threads per row of the diagonal block
+constexpr int CH_TPR = 8;
+
+// dot product of two LDS vectors with stride: elements c = c0 + part, step CH_TPR; four independent partial sums
+__device__ __forceinline__ double strided_dot(const double* __restrict__ x, int xs, const double* __restrict__ y, int ys,
+                                              int c0, int c1, int part) {
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int c = c0 + part;
+    for (; c + 3 * CH_TPR < c1; c += 4 * CH_TPR) {
+        a0 += x[c * xs] * y[c * ys];
+        a1 += x[(c + CH_TPR) * xs] * y[(c + CH_TPR) * ys];
+        a2 += x[(c + 2 * CH_TPR) * xs] * y[(c + 2 * CH_TPR) * ys];
+        a3 += x[(c + 3 * CH_TPR) * xs] * y[(c + 3 * CH_TPR) * ys];
+    }
+    for (; c < c1; c += CH_TPR) a0 += x[c * xs] * y[c * ys];
+    double acc = (a0 + a1) + (a2 + a3);
+    acc += __shfl_xor(acc, 1);
+    acc += __shfl_xor(acc, 2);
+    acc += __shfl_xor(acc, 4);
+    return acc;
+}
+
+__global__ __launch_bounds__(CH_THREADS) void potrf_diag_kernel(double* __restrict__ A, int lda, int64_t stride, int k,
+                                                                double* __restrict__ work, int* __restrict__ info) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double* S = reinterpret_cast<double*>(smem_raw);  // [CH_NB][CH_LD]
+    __shared__ int fail;
+    const int t = threadIdx.x, b = blockIdx.x;
+    double* Ab = A + (size_t)b * stride + (size_t)k * CH_NB * lda + (size_t)k * CH_NB;
+    if (t == 0) fail = 0;
+    for (int idx = t; idx < CH_NB * CH_NB; idx += CH_THREADS) {
+        const int r = idx >> 7, c = idx & 127;
+        S[r * CH_LD + c] = (c <= r) ? Ab[(size_t)r * lda + c] : 0.0;
+    }
+    __syncthreads();
+    // left-looking Cholesky: column j = (a_j - L[:, :j] L[j, :j]^T) / l_jj ; eight threads per row share the dot product
+    const int row = t >> 3, part = t & 7;
+    for (int j = 0; j < CH_NB; ++j) {
+        // the dot products read columns < j only; column j is written below
+        const double acc = (row >= j) ? strided_dot(S + row * CH_LD, 1, S + j * CH_LD, 1, 0, j, part) : 0.0;
+        double v = 0.0;
+        if (row >= j && part == 0) v = S[row * CH_LD + j] - acc;
+        if (row == j && part == 0) {
+            if (!(v > 0.0)) {
+                if (fail == 0) fail = k * CH_NB + j + 1;
+            }
+            S[j * CH_LD + j] = sqrt(v);
+        }
+        __syncthreads();
+        if (row > j && part == 0) S[row * CH_LD + j] = v / S[j * CH_LD + j];
+        __syncthreads();  // the next column's dot products read column j
+    }
+    for (int idx = t; idx < CH_NB * CH_NB; idx += CH_THREADS) {
+        const int r = idx >> 7, c = idx & 127;
+        Ab[(size_t)r * lda + c] = S[r * CH_LD + c];  // L_kk, zeros above the diagonal
+    }
+    if (t == 0 && fail != 0 && info[b] == 0) info[b] = fail;
+    __syncthreads();
+    // in-place inverse of the lower-triangular block (LAPACK trti2, lower): columns from the last to the first
+    for (int j = CH_NB - 1; j >= 0; --j) {
+        const double xjj = 1.0 / S[j * CH_LD + j];
+        // x_row = sum_{c = j+1..row} X[row][c] * L[c][j]   (X: the already inverted trailing block, same storage)
+        const double acc = (row > j) ? strided_dot(S + row * CH_LD, 1, S + j, CH_LD, j + 1, row + 1, part) : 0.0;
+        __syncthreads();
+        if (part == 0) {
+            if (row > j) S[row * CH_LD + j] = -acc * xjj;
+            if (row == j) S[j * CH_LD + j] = xjj;
+        }
+        __syncthreads();
+    }
+    double* Wb = work + (size_t)b * CH_NB * CH_NB;
+    for (int idx = t; idx < CH_NB * CH_NB; idx += CH_THREADS) {
+        const int r = idx >> 7, c = idx & 127;
+        Wb[idx] = S[r * CH_LD + c];
+    }
+}
+
+// 128x128x128 tile products for the panel solve and the trailing update; operands with arbitrary leading dimension.
+template <int OP>  // 0: C = A * B^T (panel: B = inv(L_kk) from `work`);  1: C -= A * B^T (trailing update)
+__global__ __launch_bounds__(NTHREADS, 2) void chol_tile_kernel(double* __restrict__ Amat, int lda, int64_t stride,
+                                                                int k, int nt, const double* __restrict__ work) {
+    constexpr int RS = RowStride<double>::value;
+    __shared__ __attribute__((aligned(16))) double lds[2][2][TILE * RS];
+    typedef Mfma<double>::acc_t acc_t;
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int srow = t >> 1, skh = t & 1;
+    const int b = blockIdx.y;
+    double* Ab = Amat + (size_t)b * stride;
+    int ti, tj;
+    if (OP == 0) {
+        ti = k + 1 + blockIdx.x;
+        tj = k;
+    } else {
+        // blockIdx.x enumerates pairs (ti >= tj > k)
+        const int idx = blockIdx.x;
+        int r = 0;
+        while ((r + 1) * (r + 2) / 2 <= idx) ++r;
+        ti = k + 1 + r;
+        tj = k + 1 + (idx - r * (r + 1) / 2);
+    }
+    const double* Asrc = Ab + (size_t)(ti * CH_NB + srow) * lda + (size_t)k * CH_NB + skh * 8;
+    const double* Bsrc = (OP == 0) ? work + (size_t)b * CH_NB * CH_NB + (size_t)srow * CH_NB + skh * 8
+                                   : Ab + (size_t)(tj * CH_NB + srow) * lda + (size_t)k * CH_NB + skh * 8;
+    acc_t acc[2][8];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int n = 0; n < 8; ++n) acc[s][n] = acc_t{0, 0, 0, 0};
+    double ra[8], rb[8];
+    load8(ra, Asrc);
+    load8(rb, Bsrc);
+    store_rowk8(&lds[0][0][srow * RS + skh * 8], ra);
+    store_rowk8(&lds[0][1][srow * RS + skh * 8], rb);
+    __syncthreads();
+    int buf = 0;
+    for (int c = 0; c < CH_NB / KC; ++c) {
+        const bool has_next = (c + 1 < CH_NB / KC);
+        if (has_next) {
+            load8(ra, Asrc + (c + 1) * KC);
+            load8(rb, Bsrc + (c + 1) * KC);
+        }
+        mma_chunk_rowk<double, 0xFF>(acc, &lds[buf][0][0], &lds[buf][1][0], w, lane);
+        if (has_next) {
+            store_rowk8(&lds[buf ^ 1][0][srow * RS + skh * 8], ra);
+            store_rowk8(&lds[buf ^ 1][1][srow * RS + skh * 8], rb);
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+    double* Cb = Ab + (size_t)(ti * CH_NB) * lda + (size_t)tj * CH_NB + (lane & 15);
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double* Cr = Cb + (size_t)(row_block(w, s) * 16 + Mfma<double>::row(lane, r)) * lda;
+#pragma unroll
+            for (int n = 0; n < 8; ++n) {
+                if (OP == 0)
+                    Cr[n * 16] = acc[s][n][r];
+                else
+                    Cr[n * 16] -= acc[s][n][r];
+            }
+        }
+}
+
 // single-wave MFMA map self-test
 template <typename T>
 __global__ void selftest_kernel(const T* a, const T* b, T* c) {
@@ -899,6 +1059,32 @@ int site_accum_slots() {
     return cus * nb;
 }
 
+int potrf(double* A, int M, int lda, int batch, int64_t stride, int* info, double* work, void* stream) {
+    if (!A || !info || !work || M <= 0 || (M % CH_NB) || lda < M || batch <= 0) return TSVGP_EINVAL;
+    const int nt = M / CH_NB;
+    const size_t smem = (size_t)CH_NB * CH_LD * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&potrf_diag_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+            return TSVGP_ELAUNCH;
+        attr_set = true;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(info, 0, sizeof(int) * batch, st) != hipSuccess) return TSVGP_ELAUNCH;
+    for (int k = 0; k < nt; ++k) {
+        hipLaunchKernelGGL(potrf_diag_kernel, dim3(batch), dim3(CH_THREADS), smem, st, A, lda, stride, k, work, info);
+        const int below = nt - k - 1;
+        if (below > 0) {
+            hipLaunchKernelGGL(chol_tile_kernel<0>, dim3(below, batch), dim3(NTHREADS), 0, st, A, lda, stride, k, nt,
+                               work);
+            hipLaunchKernelGGL(chol_tile_kernel<1>, dim3(below * (below + 1) / 2, batch), dim3(NTHREADS), 0, st, A,
+                               lda, stride, k, nt, work);
+        }
+    }
+    return launch_status();
+}
+
 }  // namespace
 
 extern "C" {
@@ -950,6 +1136,10 @@ int tsvgp_site_accum_f64(const double* B, const double* g0, const double* g1, do
 int tsvgp_site_accum_f32(const float* B, const float* g0, const float* g1, double* acc2, double* acc1, void* work,
                          int64_t Np, int Mp, int P, int nsplit, void* stream) {
     return site_accum<float>(B, g0, g1, acc2, acc1, work, Np, Mp, P, nsplit, stream);
+}
+
+int tsvgp_potrf_f64(double* A, int M, int lda, int batch, int64_t stride, int* info, double* work, void* stream) {
+    return potrf(A, M, lda, batch, stride, info, work, stream);
 }
 
 int tsvgp_selftest_mfma_f64(const double* a, const double* b, double* c, void* stream) {

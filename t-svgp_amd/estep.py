@@ -116,10 +116,17 @@ class EStepEngine:
             ns += 1
         return ns
 
-    def _pad_square(self, A: torch.Tensor, Mp: int) -> torch.Tensor:
-        """[.., M, M] fp64 -> zero-padded contiguous [.., Mp, Mp] in the compute dtype."""
+    def _pad_square(self, A: torch.Tensor, Mp: int, key: str = None) -> torch.Tensor:
+        """[.., M, M] fp64 -> zero-padded contiguous [.., Mp, Mp] in the compute dtype (a cached buffer per key)."""
         M = A.shape[-1]
-        out = torch.zeros(A.shape[:-2] + (Mp, Mp), dtype=self.dtype, device=self.device)
+        if M == Mp and A.dtype == self.dtype and A.is_contiguous():
+            return A
+        shape = tuple(A.shape[:-2]) + (Mp, Mp)
+        out = self._buf.get(key) if key else None
+        if out is None or tuple(out.shape) != shape:
+            out = torch.zeros(shape, dtype=self.dtype, device=self.device)
+            if key:
+                self._buf[key] = out
         out[..., :M, :M] = A
         return out
 
@@ -144,6 +151,29 @@ class EStepEngine:
         inv_ls = kernel.inv_lengthscales(D, torch.float64, self.device)
         self.se_fill(Z, Z, inv_ls, float(kernel.variance.value), out)
         return out[:M, :M].contiguous()
+
+    def cholesky(self, A: torch.Tensor):
+        """Batched lower Cholesky on the GPU through ``tsvgp_potrf_f64`` (no host synchronisation).
+        A [.., M, M] fp64 (lower triangle referenced) -> (L [.., M, M] with zeros above the diagonal, info [batch] int32)."""
+        A = A.to(device=self.device, dtype=torch.float64)
+        M = A.shape[-1]
+        batch_shape = A.shape[:-2]
+        Mp = B.round_up(M)
+        nb = 1
+        for d in batch_shape:
+            nb *= int(d)
+        W = torch.zeros((nb, Mp, Mp), dtype=torch.float64, device=self.device)
+        W[:, :M, :M] = A.reshape(nb, M, M)
+        if Mp > M:
+            idx = torch.arange(M, Mp, device=self.device)
+            W[:, idx, idx] = 1.0  # chol([[A, 0], [0, I]]) = [[L, 0], [0, I]]
+        info = torch.empty(nb, dtype=torch.int32, device=self.device)
+        work = self._get("potrf_work", (nb, 128 * 128), torch.float64)
+        with torch.cuda.device(self.device):
+            self._launch("tsvgp_potrf", lambda: self.lib.tsvgp_potrf_f64(W.data_ptr(), Mp, Mp, nb, Mp * Mp, info.data_ptr(),
+                                                                        work.data_ptr(), self._stream()))
+        L = torch.tril(W[:, :M, :M]).reshape(tuple(batch_shape) + (M, M))
+        return L, info
 
     def trmm(self, A: torch.Tensor, Tm: torch.Tensor, C: torch.Tensor, mode: int):
         Np, Mp = A.shape
@@ -200,10 +230,10 @@ class EStepEngine:
         A = Kfu
         if whiten_Linv is not None:
             Bw = self._get("B", (Np, Mp), T)
-            self.trmm(Kfu, self._pad_square(whiten_Linv, Mp), Bw, B.TRI_LOWER)
+            self.trmm(Kfu, self._pad_square(whiten_Linv, Mp, "pad_Linv"), Bw, B.TRI_LOWER)
             A = Bw
 
-        Tm = self._pad_square(moment_Tm, Mp)
+        Tm = self._pad_square(moment_Tm, Mp, "pad_Tm")
         gam = torch.zeros((Mp, P), dtype=T, device=dev)
         gam[:M] = gamma
         nblk = Np // B.TILE

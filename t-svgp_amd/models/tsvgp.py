@@ -32,7 +32,7 @@ from ..base import default_device, default_float, default_jitter, to_tensor
 from ..inducing_variables import inducingpoint_wrapper
 from ..sites import DenseSites
 from ..util import (
-    cholesky,
+    cholesky_deferred,
     gradient_transformation_mean_var_to_expectation,
     kl_from_dense_site,
     posterior_from_dense_site,
@@ -127,34 +127,59 @@ class t_SVGP(base_SVGP):
     def _Z(self) -> torch.Tensor:
         return self.inducing_variable.Z.value.to(self.device)
 
-    def _site_operands(self, whiten_jitter=None):
-        """Everything the N-pass needs that depends only on (theta, Z, lambda): O(M^3), fp64, replicated."""
+    def _site_operands(self, whiten_jitter=None, dense_moments=False):
+        """Everything the N-pass needs that depends only on (theta, Z, lambda): O(M^3), fp64, replicated.
+        No host synchronisation happens here: Cholesky statuses are collected in ops["infos"] and checked once per
+        call by ``_check_step`` (TF raises immediately; here the raise comes at the end of the same call)."""
         eng = self._get_engine()
         Z = self._Z()
         M = Z.shape[0]
+        infos = []
         Kzz = eng.kuu(Z, self.kernel)  # HIP fill kernel, no jitter
         Id = torch.eye(M, dtype=torch.float64, device=Kzz.device)
         K6 = Kzz + default_jitter() * Id  # tsvgp.py:209-211
         l1 = self.lambda_1.value
         L = self.lambda_2_sqrt.value
-        Dm, chol_W = site_projection_D(K6, L, return_chol=True)  # [P, M, M]
+        potrf = getattr(eng, "cholesky", None)  # HIP blocked Cholesky (tsvgp_potrf_f64)
+        Dm, chol_W = site_projection_D(K6, L, return_chol=True, infos=infos, potrf=potrf)  # [P, M, M]
         DKl = torch.einsum("pmk,kp->pm", Dm @ K6, l1)
         beta = l1 - torch.einsum("pkm,pk->mp", Dm, DKl)  # K6^-1 m = l1 - D^T D K6 l1
-        ops = dict(Z=Z, Kzz=Kzz, K6=K6, D=Dm, chol_W=chol_W, beta=beta, Id=Id)
+        ops = dict(Z=Z, Kzz=Kzz, K6=K6, D=Dm, chol_W=chol_W, beta=beta, Id=Id, infos=infos, G_info=None, potrf=potrf)
         if whiten_jitter is not None:
-            L9 = cholesky(Kzz + whiten_jitter * Id)  # tsvgp.py:268-270
+            L9 = cholesky_deferred(Kzz + whiten_jitter * Id, infos, potrf)  # tsvgp.py:268-270
             ops["L9"] = L9
             ops["Linv9"] = torch.linalg.solve_triangular(L9, Id, upper=False)
             ops["gamma"] = L9.transpose(-1, -2) @ beta
             T = Dm @ L9
-            G = T.transpose(-1, -2) @ T
-            G = 0.5 * (G + G.transpose(-1, -2))
-            F, info = torch.linalg.cholesky_ex(G, check_errors=False)
-            if bool((info != 0).any()) or not bool(torch.isfinite(F).all()):
-                ops["moment_Tm"], ops["moment_mode"] = T, B.TRI_DENSE  # G numerically singular: dense product
+            if dense_moments:
+                ops["moment_Tm"], ops["moment_mode"] = T, B.TRI_DENSE
             else:
+                # var = knn - |T b|^2 = knn - |F^T b|^2 with F F^T = T^T T + eps I.  |b|^2 <= knn (1 + o(1)), so the
+                # jitter eps = 1e-14 moves var by <= 1e-14 knn (rounding level) and keeps the factorisation safe when
+                # the site precision is numerically rank deficient (e.g. the initial lambda_2_sqrt = -1e-10 I).
+                G = T.transpose(-1, -2) @ T
+                G = 0.5 * (G + G.transpose(-1, -2)) + 1e-14 * Id
+                ginfo = []
+                F = cholesky_deferred(G, ginfo, potrf)
+                ops["G_info"] = ginfo[0]
                 ops["moment_Tm"], ops["moment_mode"] = F.transpose(-1, -2).contiguous(), B.TRI_UPPER
         return ops
+
+    def _check_step(self, ops, nonpos, extra_infos=()):
+        """ONE device->host read per call: Cholesky statuses, the moments-factor status and the count of non-positive
+        variances.  Returns False when only the moments factor F failed (the caller retries with the dense product);
+        raises FloatingPointError for what TensorFlow raises on (tsvgp.py:113 assert_positive; failed Cholesky)."""
+        parts = list(ops["infos"]) + list(extra_infos)
+        g = ops["G_info"] if ops["G_info"] is not None else torch.zeros(1, dtype=torch.float64, device=self.device)
+        flags = torch.cat([torch.cat(parts).sum().reshape(1), g.reshape(1),
+                           nonpos.reshape(1).to(torch.float64)]).cpu()
+        if float(flags[0]) != 0:
+            raise FloatingPointError("Cholesky decomposition was not successful (matrix not positive definite)")
+        if float(flags[1]) != 0:
+            return False
+        if not (float(flags[2]) == 0):  # a NaN count also lands here
+            raise FloatingPointError(f"non-positive predictive variance at {float(flags[2]):.0f} point(s)")
+        return True
 
     def get_mean_chol_cov_inducing_posterior(self):
         """Mean and Cholesky factor of q(u) = N(u; m, S) (tsvgp.py:202-212)."""
@@ -166,7 +191,9 @@ class t_SVGP(base_SVGP):
     def prior_kl(self):
         """KL[q(u) || p(u)] (tsvgp.py:65-70)."""
         ops = self._site_operands()
-        return kl_from_dense_site(ops["K6"], self.lambda_1.value, ops["D"], ops["chol_W"], ops["beta"])
+        kl = kl_from_dense_site(ops["K6"], self.lambda_1.value, ops["D"], ops["chol_W"], ops["beta"])
+        self._check_step(ops, torch.zeros(1, dtype=torch.float64, device=self.device))
+        return kl
 
     # -- data plumbing -----------------------------------------------------------------------------------------
     def _as_device(self, a):
@@ -174,20 +201,19 @@ class t_SVGP(base_SVGP):
             return a.to(self.device)
         return torch.as_tensor(np.asarray(a)).to(self.device)
 
-    def _raise_if_nonpos(self, nonpos):
-        if float(nonpos) > 0:  # tf.debugging.assert_positive(var), tsvgp.py:113
-            raise FloatingPointError(f"non-positive predictive variance at {int(float(nonpos))} point(s)")
-
     # -- predictions -------------------------------------------------------------------------------------------
     def predict_f(self, Xnew, full_cov=False, full_output_cov=False):
         """Posterior prediction at new input Xnew [N, D] (tsvgp.py:97-114) through the whitened route the E-step uses."""
         if full_cov or full_output_cov:
             raise NotImplementedError("full covariances are not on the E-step hot path")
-        ops = self._site_operands(whiten_jitter=1e-9)
-        st = self._get_engine().run(self._as_device(Xnew), None, ops["Z"], self.kernel, moment_Tm=ops["moment_Tm"],
-                                    moment_mode=ops["moment_mode"], gamma=ops["gamma"], whiten_Linv=ops["Linv9"],
-                                    want_moments=True)
-        self._raise_if_nonpos(st.nonpos)
+        Xnew = self._as_device(Xnew)
+        for dense in (False, True):
+            ops = self._site_operands(whiten_jitter=1e-9, dense_moments=dense)
+            st = self._get_engine().run(Xnew, None, ops["Z"], self.kernel, moment_Tm=ops["moment_Tm"],
+                                        moment_mode=ops["moment_mode"], gamma=ops["gamma"], whiten_Linv=ops["Linv9"],
+                                        want_moments=True)
+            if self._check_step(ops, st.nonpos):
+                break
         return st.mean, st.var
 
     def new_predict_f(self, Xnew, full_cov=False, full_output_cov=False):
@@ -197,7 +223,7 @@ class t_SVGP(base_SVGP):
         ops = self._site_operands()
         st = self._get_engine().run(self._as_device(Xnew), None, ops["Z"], self.kernel, moment_Tm=ops["D"],
                                     moment_mode=B.TRI_DENSE, gamma=ops["beta"], want_moments=True)
-        self._raise_if_nonpos(st.nonpos)
+        self._check_step(ops, st.nonpos)
         return st.mean, st.var
 
     def predict_y(self, Xnew):
@@ -222,8 +248,8 @@ class t_SVGP(base_SVGP):
         if self._reduce():
             D_.all_reduce_sum(packed)
         _, _, ve_sum, nonpos, rows = D_.unpack_stats(packed, self.num_latent_gps, self.num_inducing, False)
-        self._raise_if_nonpos(nonpos)
-        scale = (float(self.num_data) / float(rows)) if self.num_data is not None else 1.0
+        self._check_step(ops, nonpos)
+        scale = (float(self.num_data) / rows) if self.num_data is not None else 1.0
         return ve_sum * scale - kl
 
     # -- the hot path ------------------------------------------------------------------------------------------
@@ -231,40 +257,54 @@ class t_SVGP(base_SVGP):
         """One natural-gradient step on the site parameters (tsvgp.py:234-304):
             lambda <- (1 - lr) lambda + lr * scale * grad_mu E_q[log p(y | f)].
         ``data = (X [N, D], Y [N, P])``; with more than one rank, this rank's contiguous row shard.
-        Updates the parameters in place and returns None."""
-        X, Y = data
-        ops = self._site_operands(whiten_jitter=jitter)
-        st = self._get_engine().run(self._as_device(X), self._as_device(Y), ops["Z"], self.kernel,
-                                    moment_Tm=ops["moment_Tm"], moment_mode=ops["moment_mode"], gamma=ops["gamma"],
-                                    lik_id=self.likelihood.lik_id, lik_param=self.likelihood.lik_param,
-                                    whiten_Linv=ops["Linv9"], sites=True)
-        self._apply_site_update(st, ops, lr, jitter)
+        Updates the parameters in place and returns None.  The whole step is enqueued without host
+        synchronisation; one device->host read of the status flags ends it."""
+        X, Y = self._as_device(data[0]), self._as_device(data[1])
+        old_l1, old_L = self.lambda_1.value, self.lambda_2_sqrt.value
+        for dense in (False, True):
+            ops = self._site_operands(whiten_jitter=jitter, dense_moments=dense)
+            st = self._get_engine().run(X, Y, ops["Z"], self.kernel, moment_Tm=ops["moment_Tm"],
+                                        moment_mode=ops["moment_mode"], gamma=ops["gamma"],
+                                        lik_id=self.likelihood.lik_id, lik_param=self.likelihood.lik_param,
+                                        whiten_Linv=ops["Linv9"], sites=True)
+            try:
+                done = self._apply_site_update(st, ops, lr, jitter)
+            except FloatingPointError:
+                self.lambda_1.assign(old_l1)  # the reference raises before its assigns: leave the state untouched
+                self.sites.assign_lambda_2_sqrt(old_L)
+                raise
+            if done:
+                return
+            self.lambda_1.assign(old_l1)
+            self.sites.assign_lambda_2_sqrt(old_L)
 
     def _apply_site_update(self, st, ops, lr, jitter):
-        """All-reduce of the packed accumulators (RCCL) + the replicated M x M epilogue (tsvgp.py:278-303)."""
+        """All-reduce of the packed accumulators (RCCL) + the replicated M x M epilogue (tsvgp.py:278-303).
+        Returns False if the step has to be redone with the dense moments product."""
         P, M = self.num_latent_gps, self.num_inducing
         packed = D_.pack_stats(st, with_sites=True)
         if self._reduce():
             D_.all_reduce_sum(packed)
         acc2, acc1, _, nonpos, rows = D_.unpack_stats(packed, P, M, True)
-        self._raise_if_nonpos(nonpos)
 
-        L9, Kzz, beta = ops["L9"], ops["Kzz"], ops["beta"]
-        L9t = L9.transpose(-1, -2)
+        Linv9, Kzz, beta = ops["Linv9"], ops["Kzz"], ops["beta"]
         # G1 = L9^-T acc2 L9^-1,  G0 = L9^-T acc1   (tsvgp.py:279-280 in whitened coordinates)
-        X1 = torch.linalg.solve_triangular(L9t, acc2, upper=True)
-        G1 = torch.linalg.solve_triangular(L9t, X1.transpose(-1, -2), upper=True)
+        Linv9t = Linv9.transpose(-1, -2)
+        G1 = Linv9t @ acc2 @ Linv9
         G1 = 0.5 * (G1 + G1.transpose(-1, -2))
-        G0 = torch.linalg.solve_triangular(L9t, acc1.transpose(-1, -2), upper=True)  # [M, P]
+        G0 = Linv9t @ acc1.transpose(-1, -2)  # [M, P]
         meanZ = Kzz @ beta  # predict_f(Z) mean, tsvgp.py:249-254
         grad_mu = gradient_transformation_mean_var_to_expectation(meanZ, [G0, G1])  # tsvgp.py:284
 
-        scale = (float(self.num_data) / float(rows)) if self.num_data is not None else 1.0  # tsvgp.py:286-291
+        # tsvgp.py:286-291; `rows` = global number of rows, a device scalar (no synchronisation)
+        scale = (float(self.num_data) / rows) if self.num_data is not None else 1.0
         lambda_2 = -0.5 * self.lambda_2  # tsvgp.py:293
         lambda_1 = self.lambda_1.value
         lambda_1 = (1 - lr) * lambda_1 + lr * scale * grad_mu[0]  # tsvgp.py:296
         lambda_2 = (1 - lr) * lambda_2 + lr * scale * grad_mu[1]  # tsvgp.py:297
-        lambda_2_sqrt = -cholesky(-2.0 * lambda_2 + ops["Id"] * jitter)  # tsvgp.py:300
+        final_info = []
+        lambda_2_sqrt = -cholesky_deferred(-2.0 * lambda_2 + ops["Id"] * jitter, final_info, ops["potrf"])  # tsvgp.py:300
         self.lambda_1.assign(lambda_1)  # tsvgp.py:302
         self.sites.assign_lambda_2_sqrt(lambda_2_sqrt)  # tsvgp.py:303
         # tsvgp.py:304 recomputes the posterior and discards it: dead work, not reproduced.
+        return self._check_step(ops, nonpos, final_info)

@@ -20,6 +20,18 @@ def cholesky(a: torch.Tensor) -> torch.Tensor:
     return L
 
 
+def cholesky_deferred(a: torch.Tensor, infos: list, potrf=None) -> torch.Tensor:
+    """Cholesky without a host synchronisation: the LAPACK-style ``info`` tensor is appended to ``infos`` and
+    checked later in one device->host read (see ``t_SVGP._check_step``).  ``potrf`` is the engine's HIP
+    factorisation (``EStepEngine.cholesky``); without it torch's is used."""
+    if potrf is not None:
+        L, info = potrf(a)
+    else:
+        L, info = torch.linalg.cholesky_ex(a, upper=False, check_errors=False)
+    infos.append(info.reshape(-1).to(torch.float64).abs().sum().reshape(1))
+    return L
+
+
 def _check_site_shapes(K, lambda_1, lambda_2_sqrt, who):
     if K.dim() < 2 or K.shape[-1] != K.shape[-2]:
         raise ValueError(f"{who}: K must be [..., M, M]")
@@ -70,15 +82,16 @@ def conditional_from_precision_sites(Kuu, Kff, Kuf, l, L=None, L2=None):
     return mean, cov
 
 
-def site_projection_D(K, L, return_chol=False):
+def site_projection_D(K, L, return_chol=False, infos=None, potrf=None):
     """D = chol(W)^-1 L^T with W = I + L^T K L  (reference src/util.py:168-175); [P, M, M].
 
     W is formed directly from K (no Cholesky of K needed): W = I + L^T (K L).
+    With ``infos`` (a list) the factorisation does not synchronise; its status is appended for a deferred check.
     """
     Id = torch.eye(K.shape[-1], dtype=K.dtype, device=K.device)
     W = Id + L.transpose(-1, -2) @ (K @ L)
     W = 0.5 * (W + W.transpose(-1, -2))
-    chol_W = cholesky(W)
+    chol_W = cholesky(W) if infos is None else cholesky_deferred(W, infos, potrf)
     D = torch.linalg.solve_triangular(chol_W, L.transpose(-1, -2), upper=False)
     return (D, chol_W) if return_chol else D
 

@@ -169,3 +169,22 @@ def test_invalid_arguments_are_rejected(engines):
     assert lib.tsvgp_trmm_f64(None, x.data_ptr(), x.data_ptr(), 128, 128, 0, None) == 1
     assert lib.tsvgp_se_fill_f64(x.data_ptr(), x.data_ptr(), x.data_ptr(), 1.0, x.data_ptr(), 10, 4, 2, 100, None) == 1
     assert lib.tsvgp_site_accum_work_bytes_f64(100, 1, 1) == -1
+
+
+@pytest.mark.parametrize("M,batch", [(128, 1), (256, 3), (1024, 1), (200, 2), (33, 1)])
+def test_potrf(engines, M, batch):
+    """Blocked Cholesky (tsvgp_potrf_f64) vs LAPACK; non-positive-definite input reports info like potrf."""
+    eng = engines[torch.float64]
+    rng = np.random.RandomState(5)
+    A = rng.randn(batch, M, M)
+    A = A @ np.swapaxes(A, -1, -2) / M + 0.5 * np.eye(M)
+    L, info = eng.cholesky(torch.as_tensor(A, device="cuda:0"))
+    torch.cuda.synchronize()
+    assert int(info.abs().sum()) == 0
+    ref = np.linalg.cholesky(A)
+    assert relerr(L.cpu().numpy(), ref) < 1e-12
+    assert np.array_equal(np.triu(L.cpu().numpy(), 1), np.zeros_like(A))
+    bad = A.copy()
+    bad[0, M // 2, M // 2] = -1.0
+    _, info = eng.cholesky(torch.as_tensor(bad, device="cuda:0"))
+    assert int(info[0]) == M // 2 + 1  # 1-based index of the first non-positive pivot
