@@ -1,0 +1,69 @@
+"""Full-size checks on the GPU (BASELINE.json configs C2 / C3 sizes, where the oracle is too slow): size-independent
+properties of the path.
+
+* shard additivity   -- the per-shard accumulators (acc2, acc1, sum ve) of two half ranges add up to those of the whole
+                        range: the exact property the N-sharded multi-GPU path relies on (fp64: 1e-11 relative).
+* conjugate fixed point -- Gaussian likelihood, lr = 1: one step reaches the optimum, a second step leaves the site
+                        parameters and the ELBO unchanged (reference tests/models/test_tsvgp.py:134-145 at N = 1e6).
+* two predictive routes agree -- predict_f (whitened / triangular) == new_predict_f (dense site form), tsvgp.py:215-232.
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import pkg, relerr, synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def _stats(model, X, Y, ops):
+    B = pkg()._backend
+    return model._get_engine().run(X, Y, ops["Z"], model.kernel, moment_Tm=ops["moment_Tm"], moment_mode=ops["moment_mode"],
+                                   gamma=ops["gamma"], lik_id=model.likelihood.lik_id, lik_param=model.likelihood.lik_param,
+                                   whiten_Linv=ops["Linv9"], sites=True)
+
+
+@pytest.mark.parametrize("cfg", ["c2_fp64", "c3_fp32"])
+def test_shard_additivity_full_size(cfg):
+    p = pkg()
+    if cfg == "c2_fp64":
+        N, M, D, lik, dt, tol = 1_000_000, 512, 8, "gaussian", torch.float64, 1e-11
+    else:
+        N, M, D, lik, dt, tol = 1_000_000, 1024, 16, "bernoulli", torch.float32, 2e-4
+    X, Y, Z = synthetic(N=N, M=M, D=D, lik=lik, seed=0)
+    model = p.t_SVGP(p.SquaredExponential(1.0, 1.0), p.Gaussian(0.1) if lik == "gaussian" else p.Bernoulli(), Z,
+                     compute_dtype=dt)
+    Xd = torch.as_tensor(X, dtype=dt, device="cuda:0")
+    Yd = torch.as_tensor(Y, dtype=dt, device="cuda:0")
+    model.natgrad_step((Xd, Yd), lr=0.8)  # a non-trivial state
+    ops = model._site_operands(whiten_jitter=1e-9)
+    whole = _stats(model, Xd, Yd, ops)
+    w2, w1, wv = whole.acc2.clone(), whole.acc1.clone(), whole.ve_sum.clone()
+    h = N // 2 + 37  # uneven cut, not a multiple of the 128-row tile
+    a = _stats(model, Xd[:h], Yd[:h], ops)
+    a2, a1, av = a.acc2.clone(), a.acc1.clone(), a.ve_sum.clone()
+    b = _stats(model, Xd[h:], Yd[h:], ops)
+    assert relerr((a2 + b.acc2).cpu().numpy(), w2.cpu().numpy()) < tol
+    assert relerr((a1 + b.acc1).cpu().numpy(), w1.cpu().numpy()) < tol
+    assert abs(float(av + b.ve_sum) - float(wv)) < max(tol, 1e-12) * abs(float(wv))
+    assert float(whole.nonpos) == 0
+
+
+def test_conjugate_fixed_point_full_size():
+    p = pkg()
+    N, M, D = 1_000_000, 512, 8
+    X, Y, Z = synthetic(N=N, M=M, D=D, lik="gaussian", seed=1)
+    model = p.t_SVGP(p.SquaredExponential(1.0, 1.0), p.Gaussian(0.1), Z)
+    Xd, Yd = torch.as_tensor(X, device="cuda:0"), torch.as_tensor(Y, device="cuda:0")
+    model.natgrad_step((Xd, Yd), lr=1.0)
+    l1, L2, e1 = model.lambda_1.numpy(), model.lambda_2.cpu().numpy(), float(model.elbo((Xd, Yd)))
+    model.natgrad_step((Xd, Yd), lr=1.0)
+    assert relerr(model.lambda_1.numpy(), l1) < 1e-8
+    assert relerr(model.lambda_2.cpu().numpy(), L2) < 1e-8
+    assert abs(float(model.elbo((Xd, Yd))) - e1) < 1e-9 * abs(e1)
+    # two predictive routes agree on a row sample
+    Xs = Xd[::997][:1500] + 0.01
+    mu_a, var_a = model.predict_f(Xs)
+    mu_b, var_b = model.new_predict_f(Xs)
+    assert relerr(mu_a.cpu().numpy(), mu_b.cpu().numpy()) < 1e-9
+    assert relerr(var_a.cpu().numpy(), var_b.cpu().numpy()) < 1e-8

@@ -1,0 +1,127 @@
+"""Host logic on CPU (no GPU, no HIP compute): the M x M site algebra in torch against the oracle, the GPflow-style
+containers, and the sharded E-step over ``gloo`` with world_size 2 (rank-sharded rows, one all-reduce of the packed
+accumulators, replicated epilogue) against the oracle's single-process full-data step."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import tsvgp_oracle as O
+from tests.cpu_engine import NumpyShardEngine
+from tests.helpers import pkg, relerr, synthetic
+
+
+def _pair(Z, lik, P=1, num_data=None):
+    p = pkg()
+    hip = p.t_SVGP(p.SquaredExponential(1.0, 1.0), p.Gaussian(0.1) if lik == "gaussian" else p.Bernoulli(), Z,
+                   num_latent_gps=P, num_data=num_data, device="cpu")
+    hip._engine = NumpyShardEngine()  # test double: the HIP engine cannot exist without a GPU
+    ora = O.t_SVGP(O.SquaredExponential(1.0, 1.0), O.Gaussian(0.1) if lik == "gaussian" else O.Bernoulli(), Z,
+                   num_latent_gps=P, num_data=num_data)
+    return hip, ora
+
+
+@pytest.mark.parametrize("lik,P", [("gaussian", 1), ("bernoulli", 2)])
+def test_host_prelude_and_epilogue_match_oracle(lik, P):
+    """The torch M x M algebra (site operands, whitened back-solves, natural-parameter update, -chol) is exact
+    reference algebra: with a NumPy N-pass plugged in, the model reproduces the oracle step for step."""
+    X, Y, Z = synthetic(N=300, M=24, D=2, P=P, lik=lik, seed=2)
+    hip, ora = _pair(Z, lik, P, num_data=450)
+    for _ in range(4):
+        hip.natgrad_step((X, Y), lr=0.7)
+        ora.natgrad_step((X, Y), lr=0.7)
+        assert relerr(hip.lambda_1.numpy(), ora.lambda_1) < 1e-9
+        assert relerr(hip.lambda_2.numpy(), ora.lambda_2) < 1e-9
+    assert abs(float(hip.elbo((X, Y))) - ora.elbo((X, Y))) < 1e-9 * abs(ora.elbo((X, Y)))
+    assert abs(float(hip.prior_kl()) - ora.prior_kl()) < 1e-8 * max(1.0, abs(ora.prior_kl()))
+
+
+def test_util_functions_match_oracle():
+    p = pkg()
+    rng = np.random.RandomState(0)
+    M, P, N = 7, 2, 5
+    A = rng.randn(M, M)
+    K = A @ A.T + M * np.eye(M)
+    l1 = rng.randn(M, P)
+    L = -np.tril(rng.randn(P, M, M)) * 0.3 - np.eye(M)
+    t = torch.as_tensor
+    m, cS = p.util.posterior_from_dense_site(t(K), t(l1), t(L))
+    mo, cSo = O.posterior_from_dense_site(K, l1, L)
+    assert relerr(m.numpy(), mo) < 1e-11 and relerr(cS.numpy(), cSo) < 1e-11
+    Kuf = rng.randn(M, N)
+    Kff = np.full((N, 1), 50.0)
+    mu, cov = p.util.conditional_from_precision_sites(t(K), t(Kff), t(Kuf), t(l1), L=t(L))
+    muo, covo = O.conditional_from_precision_sites(K, Kff, Kuf, l1, L=L)
+    assert relerr(mu.numpy(), muo) < 1e-11 and relerr(cov.numpy(), covo) < 1e-11
+    g = [rng.randn(M, P), rng.randn(P, M, M)]
+    a0, a1 = p.util.gradient_transformation_mean_var_to_expectation(t(l1), [t(g[0]), t(g[1])])
+    b0, b1 = O.gradient_transformation_mean_var_to_expectation(l1, g)
+    assert relerr(a0.numpy(), b0) < 1e-13 and relerr(a1.numpy(), b1) < 1e-13
+    # site-form KL == gauss_kl of the explicit posterior
+    D, cW = p.util.site_projection_D(t(K), t(L), return_chol=True)
+    DKl = torch.einsum("pmk,kp->pm", D @ t(K), t(l1))
+    beta = t(l1) - torch.einsum("pkm,pk->mp", D, DKl)
+    kl = p.util.kl_from_dense_site(t(K), t(l1), D, cW, beta)
+    assert abs(float(kl) - O.gauss_kl(mo, cSo, K)) < 1e-10 * abs(O.gauss_kl(mo, cSo, K))
+    with pytest.raises(FloatingPointError):
+        p.util.cholesky(t(-np.eye(3)))
+    with pytest.raises(ValueError):
+        p.util.posterior_from_dense_site(t(K), t(l1[:, :1]), t(L))  # shape mismatch (util.py:368-372)
+
+
+def test_containers_follow_the_reference():
+    p = pkg()
+    s = p.DenseSites(np.zeros((4, 2)), lambda_2_sqrt=np.ones((2, 4, 4)))
+    assert np.array_equal(s.lambda_2_sqrt.numpy(), np.tril(np.ones((2, 4, 4))))  # triangular() transform
+    assert s.num_latent_gps == 4  # reference src/sites.py:57 (sic)
+    assert s.lambda_2.shape == (2, 4, 4)
+    s2 = p.DenseSites(np.zeros((3, 1)), lambda_2=2.0 * np.eye(3)[None])
+    np.testing.assert_allclose(s2.lambda_2_sqrt.numpy()[0], np.sqrt(2.0) * np.eye(3))
+    k = p.SquaredExponential(variance=2.0, lengthscales=[1.0, 2.0])
+    assert k.ard and np.allclose(k.inv_lengthscales(2).numpy(), [1.0, 0.5])
+    with pytest.raises(ValueError):
+        k.inv_lengthscales(3)
+    par = p.Parameter(np.arange(3.0))
+    par.assign([1.0, 2.0, 3.0])
+    with pytest.raises(ValueError):
+        par.assign(np.zeros(4))
+    assert p.inducingpoint_wrapper(np.zeros((5, 2))).num_inducing == 5
+    assert p.default_jitter() == 1e-6 and p.default_float() == torch.float64
+    lo_hi = [p.distributed.shard_bounds(10, 3, r) for r in range(3)]
+    assert lo_hi == [(0, 4), (4, 7), (7, 10)]
+
+
+def _worker(rank, world, port, lik, P, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        p = pkg()
+        X, Y, Z = synthetic(N=401, M=20, D=2, P=P, lik=lik, seed=4)  # 401 rows: uneven shards (201 + 200)
+        Xs, Ys = p.distributed.shard_rows(X, Y)
+        hip, _ = _pair(Z, lik, P, num_data=401)
+        assert hip._reduce()
+        for _ in range(3):
+            hip.natgrad_step((Xs, Ys), lr=0.8)
+        elbo = float(hip.elbo((Xs, Ys)))
+        if rank == 0:
+            np.savez(out, l1=hip.lambda_1.numpy(), L2=hip.lambda_2.numpy(), elbo=elbo)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("lik,P", [("gaussian", 1), ("bernoulli", 2)])
+def test_sharded_estep_gloo_world2_matches_single_process_oracle(tmp_path, lik, P):
+    out = str(tmp_path / "r0.npz")
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, lik, P, out), nprocs=2, join=True)
+    got = np.load(out)
+    X, Y, Z = synthetic(N=401, M=20, D=2, P=P, lik=lik, seed=4)
+    _, ora = _pair(Z, lik, P, num_data=401)
+    for _ in range(3):
+        ora.natgrad_step((X, Y), lr=0.8)
+    assert relerr(got["l1"], ora.lambda_1) < 1e-9
+    assert relerr(got["L2"], ora.lambda_2) < 1e-9
+    assert abs(float(got["elbo"]) - ora.elbo((X, Y))) < 1e-9 * abs(ora.elbo((X, Y)))
