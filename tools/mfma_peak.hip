@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void k_f64_rand(double* out, int iters, double
 
 // MFMA + LDS operand reads (+ optional global streaming): NREAD ds_read_b64 per 16 MFMAs, random data in LDS.
 // Models the E-step kernels' inner loop to see which clock the chip holds under that mix.
-template <int NREAD, int GLOADS>
+template <int NREAD, int GLOADS, int BAR = 0>
 __global__ __launch_bounds__(256, 2) void k_f64_lds(double* out, const double* __restrict__ src, int iters, unsigned long long* clk) {
     __shared__ double sm[4608];
     v4d acc[16];
@@ -81,6 +81,7 @@ __global__ __launch_bounds__(256, 2) void k_f64_lds(double* out, const double* _
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(f[(i & 3) % (NREAD / 2)]), "v"(f[NREAD / 2 + (i >> 2) % (NREAD / 2)]));
+        if (BAR > 0 && (it % BAR) == BAR - 1) __builtin_amdgcn_s_barrier();
     }
     unsigned long long t1 = __builtin_amdgcn_s_memtime();
     unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
@@ -154,6 +155,10 @@ int main() {
     hipMemset(src, 0, (size_t)4096 * 131072 * 8 + (1 << 22));
     run("f64 + 8 ds_read_b64 /16 MFMA, 2 WG/CU", [&](unsigned long long* c) { hipLaunchKernelGGL((k_f64_lds<8, 0>), dim3(512), dim3(256), 0, 0, od, src, iters, c); }, 512, iters, 16, 2048.0);
     run("f64 + 16 ds_read_b64 /16 MFMA, 2 WG/CU", [&](unsigned long long* c) { hipLaunchKernelGGL((k_f64_lds<16, 0>), dim3(512), dim3(256), 0, 0, od, src, iters, c); }, 512, iters, 16, 2048.0);
+    run("f64 + 8 ds_read, barrier / 64 MFMA, 2WG", [&](unsigned long long* c) { hipLaunchKernelGGL((k_f64_lds<8, 0, 4>), dim3(512), dim3(256), 0, 0, od, src, iters, c); }, 512, iters, 16, 2048.0);
+    run("f64 + 8 ds_read, barrier / 64 MFMA, 1WG", [&](unsigned long long* c) { hipLaunchKernelGGL((k_f64_lds<8, 0, 4>), dim3(256), dim3(256), 0, 0, od, src, iters, c); }, 256, iters, 16, 2048.0);
+    run("f64 + 8 ds_read, no barrier, 1WG/CU", [&](unsigned long long* c) { hipLaunchKernelGGL((k_f64_lds<8, 0, 0>), dim3(256), dim3(256), 0, 0, od, src, iters, c); }, 256, iters, 16, 2048.0);
+    run("f64 + 8 ds_read, barrier / 16 MFMA, 2WG", [&](unsigned long long* c) { hipLaunchKernelGGL((k_f64_lds<8, 0, 1>), dim3(512), dim3(256), 0, 0, od, src, iters, c); }, 512, iters, 16, 2048.0);
     run("f64 + 8 ds_read + 1 gload16B /16 MFMA", [&](unsigned long long* c) { hipLaunchKernelGGL((k_f64_lds<8, 1>), dim3(512), dim3(256), 0, 0, od, src, iters, c); }, 512, iters, 16, 2048.0);
     for (int blocks : {256, 512}) {
         run("f64 16x16x4, 4 accumulators", [&](unsigned long long* c) { hipLaunchKernelGGL(k_f64<4>, dim3(blocks), dim3(256), 0, 0, od, iters * 4, 0.37, c); }, blocks, iters * 4, 4, 2048.0);
