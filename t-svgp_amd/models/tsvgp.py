@@ -36,7 +36,6 @@ from ..util import (
     gradient_transformation_mean_var_to_expectation,
     kl_from_dense_site,
     posterior_from_dense_site,
-    site_projection_D,
 )
 
 
@@ -141,13 +140,21 @@ class t_SVGP(base_SVGP):
         l1 = self.lambda_1.value
         L = self.lambda_2_sqrt.value
         potrf = getattr(eng, "cholesky", None)  # HIP blocked Cholesky (tsvgp_potrf_f64)
-        Dm, chol_W = site_projection_D(K6, L, return_chol=True, infos=infos, potrf=potrf)  # [P, M, M]
+        # W = I + L^T K6 L (util.py:171-172, formed without chol(K6)).  chol(W) and chol(K_uu + jitter I) are
+        # independent and both latency bound (one workgroup per diagonal block): factor them in ONE batched call.
+        W = Id + L.transpose(-1, -2) @ (K6 @ L)
+        W = 0.5 * (W + W.transpose(-1, -2))
+        if whiten_jitter is not None:
+            both = cholesky_deferred(torch.cat([W, (Kzz + whiten_jitter * Id)[None]], dim=0), infos, potrf)
+            chol_W, L9 = both[:-1], both[-1]
+        else:
+            chol_W, L9 = cholesky_deferred(W, infos, potrf), None
+        Dm = torch.linalg.solve_triangular(chol_W, L.transpose(-1, -2), upper=False)  # D = chol(W)^-1 L^T, [P, M, M]
         DKl = torch.einsum("pmk,kp->pm", Dm @ K6, l1)
         beta = l1 - torch.einsum("pkm,pk->mp", Dm, DKl)  # K6^-1 m = l1 - D^T D K6 l1
         ops = dict(Z=Z, Kzz=Kzz, K6=K6, D=Dm, chol_W=chol_W, beta=beta, Id=Id, infos=infos, G_info=None, potrf=potrf)
         if whiten_jitter is not None:
-            L9 = cholesky_deferred(Kzz + whiten_jitter * Id, infos, potrf)  # tsvgp.py:268-270
-            ops["L9"] = L9
+            ops["L9"] = L9  # chol(K_uu + jitter I), tsvgp.py:268-270
             ops["Linv9"] = torch.linalg.solve_triangular(L9, Id, upper=False)
             ops["gamma"] = L9.transpose(-1, -2) @ beta
             T = Dm @ L9
@@ -262,6 +269,8 @@ class t_SVGP(base_SVGP):
         X, Y = self._as_device(data[0]), self._as_device(data[1])
         old_l1, old_L = self.lambda_1.value, self.lambda_2_sqrt.value
         for dense in (False, True):
+            # (Overlapping the K(X, Z) fill with this latency-bound prelude on a second stream was measured and is not
+            # used: the fill's workgroups occupy every CU, so the prelude's single-workgroup kernels just queue.)
             ops = self._site_operands(whiten_jitter=jitter, dense_moments=dense)
             st = self._get_engine().run(X, Y, ops["Z"], self.kernel, moment_Tm=ops["moment_Tm"],
                                         moment_mode=ops["moment_mode"], gamma=ops["gamma"],
