@@ -822,7 +822,7 @@ __global__ __launch_bounds__(FAT_THREADS, 2) void fat_panel_kernel(PanelArgs<dou
 // syrk_kernel: workgroup (p, lower tile (it, jt), split s) accumulates over its N-slice
 //   part2[128 x 128] = sum_n g1[n,p] B[n, it*128 + :] (x) B[n, jt*128 + :],   diagonal tiles also part1 = sum_n g0 B.
 // Diagonal tiles (it == jt) only compute accumulators with column block <= row block: 9 of 16 per wave and k-step
-// (row blocks {w, 7 - w}), so they get N-slices 16/9 as long: ns_diag = ceil(9/16 ns_off) splits instead of ns_off.
+// (row blocks {w, 7 - w}), so they get longer N-slices: ns_diag = ceil(23/32 ns_off) splits instead of ns_off.
 // Workgroup order: all off-diagonal tiles of split 0, of split 1, ...; then the diagonal tiles the same way; remapped
 // so that workgroups sharing an XCD (blockIdx % 8) get a contiguous range, i.e. mostly one N-slice -> shared L2 lines.
 // ---------------------------------------------------------------------------------------------------------------
@@ -844,8 +844,14 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
 }
 
+// Diagonal tiles run 9 of 16 MFMAs per k-step but the same loads, LDS traffic and barrier per chunk: measured with
+// in-kernel stamps (tools/diag_syrk.py) a diagonal-tile chunk costs 0.71 of an off-diagonal one, not 9/16.
+#ifndef TSVGP_SYRK_DIAG_NUM
+#define TSVGP_SYRK_DIAG_NUM 23
+#define TSVGP_SYRK_DIAG_DEN 32
+#endif
 __host__ __device__ inline int syrk_ns_diag(int ns_off) {
-    const int d = (9 * ns_off + 15) / 16;
+    const int d = (TSVGP_SYRK_DIAG_NUM * ns_off + TSVGP_SYRK_DIAG_DEN - 1) / TSVGP_SYRK_DIAG_DEN;
     return d < 1 ? 1 : d;
 }
 

@@ -16,7 +16,7 @@ g0 = torch.randn(rows, P, dtype=torch.float64, device=dev); g1 = -torch.rand(row
 nsplit = 15
 lib.tsvgp_site_accum_work_bytes_f64.restype = ctypes.c_int64
 nb = lib.tsvgp_site_accum_work_bytes_f64(Mp, P, nsplit)
-nwg = 28 * nsplit + 8 * ((9 * nsplit + 15) // 16)
+nwg = 28 * nsplit + 8 * ((23 * nsplit + 31) // 32)
 work = torch.zeros(nb + nwg * 4 * 8 * 8 + 4096, dtype=torch.uint8, device=dev)
 acc2 = torch.empty(P, Mp, Mp, dtype=torch.float64, device=dev); acc1 = torch.empty(P, Mp, dtype=torch.float64, device=dev)
 vp = ctypes.c_void_p
@@ -28,8 +28,8 @@ for rep in range(4):
     assert st == 0
 e1.record(); torch.cuda.synchronize()
 print("mode", mode, "launch ms (syrk + reduce):", e0.elapsed_time(e1) / 3)
-per_p = 28 * nsplit + 8 * ((9 * nsplit + 15) // 16)
-off = per_p * 128 * 128 * 8 + P * ((9 * nsplit + 15) // 16) * Mp * 8
+per_p = 28 * nsplit + 8 * ((23 * nsplit + 31) // 32)
+off = per_p * 128 * 128 * 8 + P * ((23 * nsplit + 31) // 32) * Mp * 8
 dbg = work[off: off + nwg * 4 * 8 * 8].view(torch.int64).cpu().numpy().reshape(nwg, 4, 8)
 for kind in (0, 1):
     sel = dbg[dbg[:, 0, 7] == kind]
@@ -58,3 +58,21 @@ if mode == "CLOCK":
     print("WGs per XCC:", sorted(collections.Counter(xcc.tolist()).items()))
     dur = en_us - st_us
     print("WG duration (us): min %.0f median %.0f max %.0f" % (dur.min(), np.median(dur), dur.max()))
+if mode == "CLOCK":
+    kind = dbg[:, 0, 7]
+    for kd in (0, 1):
+        d = dur[kind == kd]
+        print(("diag" if kd else "off-diag"), "durations us: min %.0f p10 %.0f median %.0f p90 %.0f max %.0f  (n=%d)" % (d.min(), np.percentile(d, 10), np.median(d), np.percentile(d, 90), d.max(), len(d)))
+    # pairing: which kinds share a CU
+    import collections
+    bycu = collections.defaultdict(list)
+    for i, kk in enumerate(key.tolist()): bycu[kk].append(i)
+    pair_d = collections.defaultdict(list)
+    for kk, idxs in bycu.items():
+        kinds = tuple(sorted(int(kind[i]) for i in idxs))
+        for i in idxs: pair_d[(kinds, int(kind[i]))].append(dur[i])
+    for (kinds, kd), v in sorted(pair_d.items()):
+        print("CU holds kinds", kinds, "-> WG kind", kd, "median %.0f max %.0f n=%d" % (np.median(v), max(v), len(v)))
+    xs = collections.defaultdict(list)
+    for i in range(len(dur)): xs[int(xcc[i])].append(dur[i])
+    print("per XCC max duration:", {k: int(max(v)) for k, v in sorted(xs.items())})
