@@ -173,6 +173,22 @@ def main():
     elapsed = float(t)
     elbo = float(model.elbo((Xd, Yd)))
 
+    # "warm" E-steps, reported beside the headline and never as `value`: consecutive E-steps with unchanged
+    # hyperparameters (the reference's E/M loop runs 8 per M-step) reuse chol(K_uu), its inverse and the whitened B.
+    model.cache_whitened = True
+    for _ in range(2):
+        model.natgrad_step((Xd, Yd), lr=0.8)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        model.natgrad_step((Xd, Yd), lr=0.8)
+    barrier()
+    tw = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+    warm_elapsed = float(tw)
+    model.cache_whitened = False
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         flops = kernel_flops(w, rows)
@@ -211,6 +227,10 @@ def main():
                        "likelihood": w["lik"], "rows_per_gpu": rows, "parallelism": f"N-sharded x{world}, 1 all-reduce/step",
                        "e_step": "cold (K_uu, K_uf, Choleskys, whitening rebuilt every step)", "lr": 0.8},
             "elbo_after_steps": elbo,
+            "warm": {"value": round(args.steps / warm_elapsed, 4), "unit": "E-steps/s",
+                     "ms_per_step": round(warm_elapsed / args.steps * 1e3, 4),
+                     "note": "cache_whitened=True: chol(K_uu+jitter I), its inverse and B = K_fu L^-T reused across "
+                             "E-steps with unchanged hyperparameters; not the headline"},
             "roofline": roofline,
             "kernels": kernels,
             "kernel_ms_per_step": round(sum(v[0] * v[1] for v in prof.values()) / args.steps, 4),

@@ -44,6 +44,7 @@ class Parameter:
         self._value = to_tensor(value, dtype, device).clone()
         self.trainable = trainable
         self.name = name
+        self.version = 0  # bumped by assign(): lets cached kernel factorisations notice external parameter changes
 
     @property
     def value(self) -> torch.Tensor:
@@ -68,6 +69,7 @@ class Parameter:
         if tuple(new.shape) != tuple(self._value.shape):
             raise ValueError(f"assign: shape {tuple(new.shape)} does not match {tuple(self._value.shape)}")
         self._value = new.clone()
+        self.version += 1
         return self
 
     def numpy(self) -> np.ndarray:

@@ -56,6 +56,7 @@ class EStepEngine:
         self._slots = None
         self.nsplit_override = None
         self.syrk_oversubscribe = 8
+        self._b_tag = None  # identifies the contents of the cached whitened buffer B
         self.profile = None  # set to a dict to record (start, stop) HIP events per kernel launch on the launch stream
 
     # ------------------------------------------------------------------ helpers
@@ -96,6 +97,7 @@ class EStepEngine:
     def release(self):
         """Drop the cached work buffers."""
         self._buf.clear()
+        self._b_tag = None
 
     def slots(self) -> int:
         if self._slots is None:
@@ -200,13 +202,16 @@ class EStepEngine:
 
     # ------------------------------------------------------------------ one N-pass
     def run(self, X, Y, Z, kernel, *, moment_Tm, moment_mode, gamma, lik_id=B.LIK_NONE, lik_param=0.0,
-            whiten_Linv=None, sites=False, want_moments=False, want_grads=False) -> EStepStats:
+            whiten_Linv=None, sites=False, want_moments=False, want_grads=False, b_tag=None) -> EStepStats:
         """One pass over the shard's rows.
 
         X [N, D], Y [N, P] (or None when lik_id == NONE), Z [M, D];
         whiten_Linv [M, M] fp64 = inv(chol(Kuu + jitter I)) or None (moments then act on Kfu directly);
         moment_Tm [P, M, M] fp64 and gamma [M, P] fp64: operands of the fused moments kernel;
         sites=True also accumulates (acc2, acc1) from the whitened B (requires whiten_Linv).
+        b_tag: a hashable description of (X, Z, kernel parameters, jitter).  When it equals the tag of the B buffer left
+        by the previous call, the fill and the whitening are skipped and B is reused ("warm" E-step: consecutive
+        E-steps with unchanged hyperparameters, as in the reference's E/M loop, experiments/uci_regression.py:152-153).
         """
         T, dev = self.dtype, self.device
         X = X.to(device=dev, dtype=T).contiguous()
@@ -228,14 +233,20 @@ class EStepEngine:
         inv_ls = kernel.inv_lengthscales(D, T, dev)
         variance = float(kernel.variance.value)
 
-        Kfu = self._get("Kfu", (Np, Mp), T)
-        self.se_fill(X, Z, inv_ls, variance, Kfu)
-
-        A = Kfu
-        if whiten_Linv is not None:
-            Bw = self._get("B", (Np, Mp), T)
-            self.trmm(Kfu, self._pad_square(whiten_Linv, Mp, "pad_Linv"), Bw, B.TRI_LOWER)
-            A = Bw
+        reuse = (b_tag is not None and whiten_Linv is not None and self._b_tag == b_tag
+                 and self._buf.get("B") is not None and tuple(self._buf["B"].shape) == (Np, Mp))
+        if reuse:
+            A = self._buf["B"]
+        else:
+            Kfu = self._get("Kfu", (Np, Mp), T)
+            self.se_fill(X, Z, inv_ls, variance, Kfu)
+            A = Kfu
+            if whiten_Linv is not None:
+                self._b_tag = None
+                Bw = self._get("B", (Np, Mp), T)
+                self.trmm(Kfu, self._pad_square(whiten_Linv, Mp, "pad_Linv"), Bw, B.TRI_LOWER)
+                A = Bw
+                self._b_tag = b_tag
 
         Tm = self._pad_square(moment_Tm, Mp, "pad_Tm")
         gam = torch.zeros((Mp, P), dtype=T, device=dev)

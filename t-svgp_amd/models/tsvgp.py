@@ -86,13 +86,19 @@ class t_SVGP(base_SVGP):
     """Class for the t-SVGP model (reference tsvgp.py:117-304)."""
 
     def __init__(self, kernel, likelihood, inducing_variable, *, mean_function=None, num_latent_gps: int = 1,
-                 lambda_1=None, lambda_2_sqrt=None, num_data=None, force=False, compute_dtype=None, device=None):
+                 lambda_1=None, lambda_2_sqrt=None, num_data=None, force=False, compute_dtype=None, device=None,
+                 cache_whitened=False):
         super().__init__(kernel, likelihood, inducing_variable, mean_function=mean_function,
                          num_latent_gps=num_latent_gps, num_data=num_data, compute_dtype=compute_dtype, device=device)
         self.num_inducing = self.inducing_variable.num_inducing
         self._init_variational_parameters(self.num_inducing, lambda_1, lambda_2_sqrt)
         self.whiten = False
         self.force = force
+        # Opt-in "warm" E-steps: keep chol(K_uu + jitter I), its inverse and the whitened B = K_fu L^-T between calls while
+        # the kernel parameters, Z, the jitter and the data tensor are unchanged (the reference rebuilds them on every
+        # call; with the cache off -- the default -- so does this class).
+        self.cache_whitened = cache_whitened
+        self._warm = None
         self.name = "t_svgp"  # tf.Module derives this from the class name (experiments/uci_regression.py:150)
 
     def _init_variational_parameters(self, num_inducing, lambda_1, lambda_2_sqrt, **kwargs):
@@ -126,7 +132,15 @@ class t_SVGP(base_SVGP):
     def _Z(self) -> torch.Tensor:
         return self.inducing_variable.Z.value.to(self.device)
 
-    def _site_operands(self, whiten_jitter=None, dense_moments=False):
+    def _warm_key(self, X, jitter):
+        """Cache key of everything B = K(X, Z) L9^-T depends on; None when caching is off or X is not a device tensor."""
+        if not self.cache_whitened or not isinstance(X, torch.Tensor) or X.device != self.device:
+            return None
+        k = self.kernel
+        return (X.data_ptr(), tuple(X.shape), X._version, X.dtype, k.variance.version, k.lengthscales.version,
+                id(self.inducing_variable.Z), self.inducing_variable.Z.version, float(jitter), self.compute_dtype)
+
+    def _site_operands(self, whiten_jitter=None, dense_moments=False, warm_key=None):
         """Everything the N-pass needs that depends only on (theta, Z, lambda): O(M^3), fp64, replicated.
         No host synchronisation happens here: Cholesky statuses are collected in ops["infos"] and checked once per
         call by ``_check_step`` (TF raises immediately; here the raise comes at the end of the same call)."""
@@ -134,7 +148,8 @@ class t_SVGP(base_SVGP):
         Z = self._Z()
         M = Z.shape[0]
         infos = []
-        Kzz = eng.kuu(Z, self.kernel)  # HIP fill kernel, no jitter
+        warm = self._warm if (warm_key is not None and self._warm is not None and self._warm[0] == warm_key) else None
+        Kzz = warm[1]["Kzz"] if warm else eng.kuu(Z, self.kernel)  # HIP fill kernel, no jitter
         Id = torch.eye(M, dtype=torch.float64, device=Kzz.device)
         K6 = Kzz + default_jitter() * Id  # tsvgp.py:209-211
         l1 = self.lambda_1.value
@@ -144,7 +159,9 @@ class t_SVGP(base_SVGP):
         # independent and both latency bound (one workgroup per diagonal block): factor them in ONE batched call.
         W = Id + L.transpose(-1, -2) @ (K6 @ L)
         W = 0.5 * (W + W.transpose(-1, -2))
-        if whiten_jitter is not None:
+        if whiten_jitter is not None and warm:
+            chol_W, L9 = cholesky_deferred(W, infos, potrf), warm[1]["L9"]
+        elif whiten_jitter is not None:
             both = cholesky_deferred(torch.cat([W, (Kzz + whiten_jitter * Id)[None]], dim=0), infos, potrf)
             chol_W, L9 = both[:-1], both[-1]
         else:
@@ -155,7 +172,9 @@ class t_SVGP(base_SVGP):
         ops = dict(Z=Z, Kzz=Kzz, K6=K6, D=Dm, chol_W=chol_W, beta=beta, Id=Id, infos=infos, G_info=None, potrf=potrf)
         if whiten_jitter is not None:
             ops["L9"] = L9  # chol(K_uu + jitter I), tsvgp.py:268-270
-            ops["Linv9"] = torch.linalg.solve_triangular(L9, Id, upper=False)
+            ops["Linv9"] = warm[1]["Linv9"] if warm else torch.linalg.solve_triangular(L9, Id, upper=False)
+            if warm_key is not None and not warm:
+                self._warm = (warm_key, dict(Kzz=Kzz, L9=L9, Linv9=ops["Linv9"]))
             ops["gamma"] = L9.transpose(-1, -2) @ beta
             T = Dm @ L9
             if dense_moments:
@@ -271,11 +290,12 @@ class t_SVGP(base_SVGP):
         for dense in (False, True):
             # (Overlapping the K(X, Z) fill with this latency-bound prelude on a second stream was measured and is not
             # used: the fill's workgroups occupy every CU, so the prelude's single-workgroup kernels just queue.)
-            ops = self._site_operands(whiten_jitter=jitter, dense_moments=dense)
+            warm_key = self._warm_key(X, jitter)
+            ops = self._site_operands(whiten_jitter=jitter, dense_moments=dense, warm_key=warm_key)
             st = self._get_engine().run(X, Y, ops["Z"], self.kernel, moment_Tm=ops["moment_Tm"],
                                         moment_mode=ops["moment_mode"], gamma=ops["gamma"],
                                         lik_id=self.likelihood.lik_id, lik_param=self.likelihood.lik_param,
-                                        whiten_Linv=ops["Linv9"], sites=True)
+                                        whiten_Linv=ops["Linv9"], sites=True, b_tag=warm_key)
             try:
                 done = self._apply_site_update(st, ops, lr, jitter)
             except FloatingPointError:

@@ -18,7 +18,7 @@ class NumpyShardEngine:
         return torch.as_tensor(k.K(Z.cpu().numpy()))
 
     def run(self, X, Y, Z, kernel, *, moment_Tm, moment_mode, gamma, lik_id=0, lik_param=0.0, whiten_Linv=None,
-            sites=False, want_moments=False, want_grads=False):
+            sites=False, want_moments=False, want_grads=False, b_tag=None):
         k = O.SquaredExponential(variance=float(kernel.variance.value), lengthscales=kernel.lengthscales.numpy())
         Xn, Zn = X.cpu().numpy(), Z.cpu().numpy()
         A = k.K(Xn, Zn)

@@ -202,3 +202,25 @@ def test_error_behaviour():
     dup = p.t_SVGP(p.SquaredExponential(), p.Gaussian(0.1), np.zeros((4, 2)))  # duplicate inducing points
     with pytest.raises(FloatingPointError):
         dup.natgrad_step((X, Y), jitter=0.0)  # singular K_uu: Cholesky fails as in TF
+
+
+def test_warm_cache_matches_cold_and_invalidates():
+    """cache_whitened=True (reuse chol(K_uu), its inverse and B between E-steps) gives the same trajectory as the default
+    rebuild-everything path, and notices kernel-parameter assigns, a changed jitter and other data."""
+    p = pkg()
+    X, Y, Z = synthetic(N=900, M=40, D=3, lik="bernoulli", seed=5)
+    Xd, Yd = torch.as_tensor(X, device="cuda:0"), torch.as_tensor(Y, device="cuda:0")
+    cold = p.t_SVGP(p.SquaredExponential(1.0, 1.0), p.Bernoulli(), Z)
+    warm = p.t_SVGP(p.SquaredExponential(1.0, 1.0), p.Bernoulli(), Z, cache_whitened=True)
+    for i in range(6):
+        if i == 3:  # external hyperparameter change between E-steps (docs/notebooks/regression_1D.py:186)
+            cold.kernel.lengthscales.assign(0.8)
+            warm.kernel.lengthscales.assign(0.8)
+        jit = 1e-9 if i != 4 else 1e-8
+        cold.natgrad_step((Xd, Yd), lr=0.7, jitter=jit)
+        warm.natgrad_step((Xd, Yd), lr=0.7, jitter=jit)
+        if i == 1:
+            warm.predict_f(Xd[:100])  # overwrites the work buffers: the cache must notice
+        assert relerr(warm.lambda_1.numpy(), cold.lambda_1.numpy()) < 1e-12
+        assert relerr(warm.lambda_2.cpu().numpy(), cold.lambda_2.cpu().numpy()) < 1e-12
+    assert warm._get_engine()._b_tag is not None

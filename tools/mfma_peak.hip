@@ -91,6 +91,35 @@ __global__ __launch_bounds__(256, 2) void k_f64_lds(double* out, const double* _
     if (threadIdx.x == 0) { clk[2 * blockIdx.x] = t1 - t0; clk[2 * blockIdx.x + 1] = r1 - r0; }
 }
 
+// 4 waves per SIMD: 8 accumulators per wave (32x64 wave tile: 2 A + 4 B fragment reads per 8 MFMAs), barrier every BAR iterations
+template <int BAR>
+__global__ __launch_bounds__(256, 4) void k_f64_lds8(double* out, int iters, unsigned long long* clk) {
+    __shared__ double sm[4608];
+    v4d acc[8];
+    for (int i = 0; i < 8; ++i) acc[i] = v4d{0, 0, 0, 0};
+    unsigned h = (blockIdx.x * 256 + threadIdx.x) * 2654435761u + 12345u;
+    for (int i = threadIdx.x; i < 4608; i += 256) { h = h * 1664525u + 1013904223u; sm[i] = ((double)(h >> 8) / 16777216.0 - 0.5); }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const double* base = sm + (lane & 15) * 17 + (lane >> 4);
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+        double f[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) f[i] = base[((it + i) & 15) * 272 + (i & 3) * 4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(f[i & 1]), "v"(f[2 + (i >> 1)]));
+        if (BAR > 0 && (it % BAR) == BAR - 1) __builtin_amdgcn_s_barrier();
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+    double s = 0;
+    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (threadIdx.x == 0) { clk[2 * blockIdx.x] = t1 - t0; clk[2 * blockIdx.x + 1] = r1 - r0; }
+}
+
 template <int NACC>
 __global__ __launch_bounds__(256) void k_f32(float* out, int iters, float seed, unsigned long long* clk) {
     v4f acc[NACC];
@@ -159,6 +188,9 @@ int main() {
     run("f64 + 8 ds_read, barrier / 64 MFMA, 1WG", [&](unsigned long long* c) { hipLaunchKernelGGL((k_f64_lds<8, 0, 4>), dim3(256), dim3(256), 0, 0, od, src, iters, c); }, 256, iters, 16, 2048.0);
     run("f64 + 8 ds_read, no barrier, 1WG/CU", [&](unsigned long long* c) { hipLaunchKernelGGL((k_f64_lds<8, 0, 0>), dim3(256), dim3(256), 0, 0, od, src, iters, c); }, 256, iters, 16, 2048.0);
     run("f64 + 8 ds_read, barrier / 16 MFMA, 2WG", [&](unsigned long long* c) { hipLaunchKernelGGL((k_f64_lds<8, 0, 1>), dim3(512), dim3(256), 0, 0, od, src, iters, c); }, 512, iters, 16, 2048.0);
+    run("8acc: 6 reads/8 MFMA, bar/64 MFMA, 4 waves/SIMD", [&](unsigned long long* c) { hipLaunchKernelGGL((k_f64_lds8<8>), dim3(1024), dim3(256), 0, 0, od, iters * 2, c); }, 1024, iters * 2, 8, 2048.0);
+    run("8acc: 6 reads/8 MFMA, bar/64 MFMA, 2 waves/SIMD", [&](unsigned long long* c) { hipLaunchKernelGGL((k_f64_lds8<8>), dim3(512), dim3(256), 0, 0, od, iters * 2, c); }, 512, iters * 2, 8, 2048.0);
+    run("8acc: 6 reads/8 MFMA, no barrier, 4 waves/SIMD", [&](unsigned long long* c) { hipLaunchKernelGGL((k_f64_lds8<0>), dim3(1024), dim3(256), 0, 0, od, iters * 2, c); }, 1024, iters * 2, 8, 2048.0);
     run("f64 + 8 ds_read + 1 gload16B /16 MFMA", [&](unsigned long long* c) { hipLaunchKernelGGL((k_f64_lds<8, 1>), dim3(512), dim3(256), 0, 0, od, src, iters, c); }, 512, iters, 16, 2048.0);
     for (int blocks : {256, 512}) {
         run("f64 16x16x4, 4 accumulators", [&](unsigned long long* c) { hipLaunchKernelGGL(k_f64<4>, dim3(blocks), dim3(256), 0, 0, od, iters * 4, 0.37, c); }, blocks, iters * 4, 4, 2048.0);
