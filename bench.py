@@ -38,7 +38,8 @@ WORKLOADS = {
                name="bernoulli_probit_N1e6_M1024_D16_P1 (BASELINE configs[2])"),
     "c5": dict(N=1_000_000, M=1024, D=8, P=8, lik="gaussian", dtype="f64",
                name="gaussian_multioutput_N1e6_M1024_D8_P8_shared_kernel (BASELINE configs[4])"),
-    "c1": dict(N=1000, M=32, D=1, P=1, lik="gaussian", dtype="f64", name="gaussian_1d_N1000_M32 (BASELINE configs[0])"),
+    "c1": dict(N=1000, M=32, D=1, P=1, lik="gaussian", dtype="f64", name="gaussian_1d_N1000_M32 (BASELINE configs[0])",
+               lengthscales=0.1, variance=0.3, noise=1.0),
 }
 PEAK_TFLOPS = {"f64": 78.6, "f32": 157.3}  # dense MFMA peaks (AMD datasheet; f32: MI355X_MICROARCH.md; f64 = f32/2)
 HBM_PEAK_GBS = 8000.0
@@ -47,6 +48,10 @@ HBM_PEAK_GBS = 8000.0
 def make_data(w, seed=0):
     """X = randn(N, D); w = randn(D, P); eps = randn(N, P); f = sin(X w); Z = X[:M]."""
     rng = np.random.RandomState(seed)
+    if w["D"] == 1 and w["M"] == 32:  # config C1 (SURVEY 8(d)): 1-D, X in [-1, 1], Y = sin(15 X) + eps, Z on a grid
+        X = rng.rand(w["N"], 1) * 2 - 1
+        Y = np.sin(15 * X) + rng.randn(w["N"], 1)
+        return X, Y, np.linspace(X.min(), X.max(), w["M"])[:, None]
     X = rng.randn(w["N"], w["D"])
     W = rng.randn(w["D"], w["P"])
     eps = rng.randn(w["N"], w["P"])
@@ -85,8 +90,9 @@ def cpu_baseline(w, budget_s=20.0):
         cores = os.cpu_count() or 1
     n_s = min(w["N"], max(2000, int(2.0e7 // (w["M"] * w["P"]))))  # bounds the [n, M, P] temporaries to ~160 MB each
     X, Y, Z = make_data(dict(w, N=n_s))
-    lik = O.Gaussian(variance=0.1) if w["lik"] == "gaussian" else O.Bernoulli()
-    model = O.t_SVGP(O.SquaredExponential(variance=1.0, lengthscales=1.0), lik, Z, num_latent_gps=w["P"])
+    lik = O.Gaussian(variance=w.get("noise", 0.1)) if w["lik"] == "gaussian" else O.Bernoulli()
+    model = O.t_SVGP(O.SquaredExponential(variance=w.get("variance", 1.0), lengthscales=w.get("lengthscales", 1.0)), lik,
+                     Z, num_latent_gps=w["P"])
     model.natgrad_step((X, Y), lr=0.8)  # warm-up (BLAS thread pools, page faults)
     times = []
     t_all = time.perf_counter()
@@ -145,8 +151,9 @@ def main():
     rows = hi - lo
     del X, Y
 
-    lik = pkg.Gaussian(variance=0.1) if w["lik"] == "gaussian" else pkg.Bernoulli()
-    model = pkg.t_SVGP(pkg.SquaredExponential(variance=1.0, lengthscales=1.0), lik, Z, num_latent_gps=w["P"],
+    lik = pkg.Gaussian(variance=w.get("noise", 0.1)) if w["lik"] == "gaussian" else pkg.Bernoulli()
+    model = pkg.t_SVGP(pkg.SquaredExponential(variance=w.get("variance", 1.0), lengthscales=w.get("lengthscales", 1.0)),
+                       lik, Z, num_latent_gps=w["P"],
                        num_data=w["N"], compute_dtype=dtype, device=device)
     eng = model._get_engine()
 
