@@ -1080,83 +1080,187 @@ __global__ __launch_bounds__(NTHREADS) void syrk_reduce_kernel(const T* __restri
 // microseconds of MFMA time): the critical path is 8 diagonal blocks, each ~M/8 dependent column steps.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int CH_NB = 128;
-constexpr int CH_LD = CH_NB + 1;  // LDS row stride of the diagonal block (conflict-free row and column walks)
+constexpr int CH_LD = CH_NB + 8;  // LDS row stride: with 8 threads per row a 32-lane pass (4 rows x 8 parts) covers all 64 banks once
 
 constexpr int CH_THREADS = 1024;  // 8 threads per row of the diagonal block
 constexpr int CH_TPR = 8;
+constexpr int CH_PW = 4;  // columns finished per barrier pair in the factorisation
 
-// dot product of two LDS vectors with stride: elements c = c0 + part, step CH_TPR; four independent partial sums
-__device__ __forceinline__ double strided_dot(const double* __restrict__ x, int xs, const double* __restrict__ y, int ys,
-                                              int c0, int c1, int part) {
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    int c = c0 + part;
-    for (; c + 3 * CH_TPR < c1; c += 4 * CH_TPR) {
-        a0 += x[c * xs] * y[c * ys];
-        a1 += x[(c + CH_TPR) * xs] * y[(c + CH_TPR) * ys];
-        a2 += x[(c + 2 * CH_TPR) * xs] * y[(c + 2 * CH_TPR) * ys];
-        a3 += x[(c + 3 * CH_TPR) * xs] * y[(c + 3 * CH_TPR) * ys];
-    }
-    for (; c < c1; c += CH_TPR) a0 += x[c * xs] * y[c * ys];
-    double acc = (a0 + a1) + (a2 + a3);
-    acc += __shfl_xor(acc, 1);
-    acc += __shfl_xor(acc, 2);
-    acc += __shfl_xor(acc, 4);
-    return acc;
+// 1/sqrt(x) to fp64 accuracy: hardware estimate (v_rsq_f64) + two Newton-Raphson steps; NaN for x <= 0 like sqrt.
+__device__ __forceinline__ double rsqrt_nr(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    double h = 0.5 * x;
+    y = y * fma(-h * y, y, 1.5);
+    y = y * fma(-h * y, y, 1.5);
+    return (x > 0.0) ? y : __builtin_nan("");
 }
 
+// Diagonal block: factor (left-looking, FOUR columns per barrier pair: every thread factors the 4x4 pivot block
+// redundantly in registers and solves its own row against it) and invert (barrier-free: row r of inv(L) only needs the
+// original columns of L and its own earlier entries, which are parked transposed in the unused upper triangle).
 __global__ __launch_bounds__(CH_THREADS) void potrf_diag_kernel(double* __restrict__ A, int lda, int64_t stride, int k,
                                                                 double* __restrict__ work, int* __restrict__ info) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    double* S = reinterpret_cast<double*>(smem_raw);  // [CH_NB][CH_LD]
+    double* S = reinterpret_cast<double*>(smem_raw);  // [CH_NB][CH_LD]; lower: L, strict upper: inv(L)^T (phase B)
     __shared__ int fail;
+    __shared__ double dinv[CH_NB];
+    __shared__ double Vb[2 * CH_PW * CH_NB];  // unscaled Schur values of the current four columns, [parity][q][row]
     const int t = threadIdx.x, b = blockIdx.x;
     double* Ab = A + (size_t)b * stride + (size_t)k * CH_NB * lda + (size_t)k * CH_NB;
+#ifdef TSVGP_DIAG_POTRF
+    unsigned long long stamp[6];
+#define PSTAMP(i) stamp[i] = __builtin_amdgcn_s_memtime();
+#else
+#define PSTAMP(i)
+#endif
+    PSTAMP(0)
     if (t == 0) fail = 0;
     for (int idx = t; idx < CH_NB * CH_NB; idx += CH_THREADS) {
         const int r = idx >> 7, c = idx & 127;
         S[r * CH_LD + c] = (c <= r) ? Ab[(size_t)r * lda + c] : 0.0;
     }
     __syncthreads();
-    // left-looking Cholesky: column j = (a_j - L[:, :j] L[j, :j]^T) / l_jj ; eight threads per row share the dot product
+    PSTAMP(1)
     const int row = t >> 3, part = t & 7;
-    for (int j = 0; j < CH_NB; ++j) {
-        // the dot products read columns < j only; column j is written below
-        const double acc = (row >= j) ? strided_dot(S + row * CH_LD, 1, S + j * CH_LD, 1, 0, j, part) : 0.0;
-        double v = 0.0;
-        if (row >= j && part == 0) v = S[row * CH_LD + j] - acc;
-        if (row == j && part == 0) {
-            if (!(v > 0.0)) {
-                if (fail == 0) fail = k * CH_NB + j + 1;
+    double* const Sr = S + row * CH_LD;
+
+    // ---------------- phase A: Cholesky, 4 columns per step ----------------
+    // Per step: (1) every row forms its four Schur values against the finished columns (loads issued in one batch,
+    // 8 threads per row) and parks them in Vb; (2) barrier; (3) every thread factors the 4x4 pivot block from Vb
+    // redundantly (reciprocal square roots by v_rsq_f64 + two Newton steps: no f64 divide / sqrt sequences on the
+    // critical path) and part 0 solves its own row against it into S; (4) barrier.
+    for (int j0 = 0; j0 < CH_NB; j0 += CH_PW) {
+        double* Vq = Vb + ((j0 / CH_PW) & 1) * (CH_PW * CH_NB);  // double buffered by step parity
+        if (row >= j0) {
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+            const double* p0 = S + j0 * CH_LD;
+            const int nit = (j0 + CH_TPR - 1 - part) / CH_TPR;  // number of c = part + 8 i < j0 for this thread
+            // groups of four terms: 20 LDS reads issued back to back, then 16 FMAs (tail terms clamped and zero-weighted)
+            for (int i0 = 0; i0 < nit; i0 += 4) {
+                double xs[4], q0[4], q1[4], q2[4], q3[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = (i0 + u < nit) ? i0 + u : nit - 1;
+                    const int c = part + CH_TPR * i;
+                    xs[u] = Sr[c];
+                    q0[u] = p0[c];
+                    q1[u] = p0[CH_LD + c];
+                    q2[u] = p0[2 * CH_LD + c];
+                    q3[u] = p0[3 * CH_LD + c];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const double x = (i0 + u < nit) ? xs[u] : 0.0;
+                    a0 += x * q0[u];
+                    a1 += x * q1[u];
+                    a2 += x * q2[u];
+                    a3 += x * q3[u];
+                }
             }
-            S[j * CH_LD + j] = sqrt(v);
+#pragma unroll
+            for (int o = 1; o < CH_TPR; o <<= 1) {
+                a0 += __shfl_xor(a0, o);
+                a1 += __shfl_xor(a1, o);
+                a2 += __shfl_xor(a2, o);
+                a3 += __shfl_xor(a3, o);
+            }
+            if (part < CH_PW) {
+                const double av = part == 0 ? a0 : part == 1 ? a1 : part == 2 ? a2 : a3;
+                Vq[part * CH_NB + row] = (j0 + part <= row) ? Sr[j0 + part] - av : 0.0;
+            }
         }
         __syncthreads();
-        if (row > j && part == 0) S[row * CH_LD + j] = v / S[j * CH_LD + j];
-        __syncthreads();  // the next column's dot products read column j
+        if (row >= j0) {
+            // the 4x4 pivot block (rows j0..j0+3 of Vq), factored redundantly by every thread
+            const double p00 = Vq[j0];
+            const double p10 = Vq[j0 + 1], p11 = Vq[CH_NB + j0 + 1];
+            const double p20 = Vq[j0 + 2], p21 = Vq[CH_NB + j0 + 2], p22 = Vq[2 * CH_NB + j0 + 2];
+            const double p30 = Vq[j0 + 3], p31 = Vq[CH_NB + j0 + 3], p32 = Vq[2 * CH_NB + j0 + 3],
+                         p33 = Vq[3 * CH_NB + j0 + 3];
+            const double v0 = Vq[row], v1 = Vq[CH_NB + row], v2 = Vq[2 * CH_NB + row], v3 = Vq[3 * CH_NB + row];
+            const double i0 = rsqrt_nr(p00);
+            const double l10 = p10 * i0, l20 = p20 * i0, l30 = p30 * i0;
+            const double d1 = p11 - l10 * l10;
+            const double i1 = rsqrt_nr(d1);
+            const double l21 = (p21 - l20 * l10) * i1, l31 = (p31 - l30 * l10) * i1;
+            const double d2 = p22 - l20 * l20 - l21 * l21;
+            const double i2 = rsqrt_nr(d2);
+            const double l32 = (p32 - l30 * l20 - l31 * l21) * i2;
+            const double d3 = p33 - l30 * l30 - l31 * l31 - l32 * l32;
+            const double i3 = rsqrt_nr(d3);
+            if (t == j0 * CH_TPR && fail == 0) {  // one thread reports the first non-positive pivot
+                int bad = !(p00 > 0.0) ? 1 : !(d1 > 0.0) ? 2 : !(d2 > 0.0) ? 3 : !(d3 > 0.0) ? 4 : 0;
+                if (bad) fail = k * CH_NB + j0 + bad;
+            }
+            if (part == 0) {
+                // own row against the pivot block; for the pivot rows this reproduces the factor's rows
+                // (x_q = d_q * rsqrt(d_q) = sqrt(d_q) on the diagonal)
+                const double x0 = v0 * i0;
+                const double x1 = (v1 - x0 * l10) * i1;
+                const double x2 = (v2 - x0 * l20 - x1 * l21) * i2;
+                const double x3 = (v3 - x0 * l30 - x1 * l31 - x2 * l32) * i3;
+                Sr[j0] = x0;
+                if (row >= j0 + 1) Sr[j0 + 1] = x1;
+                if (row >= j0 + 2) Sr[j0 + 2] = x2;
+                if (row >= j0 + 3) Sr[j0 + 3] = x3;
+            }
+        }
+        __syncthreads();  // the next step's Schur values read the four new columns
     }
+    PSTAMP(2)
+    // L_kk out (zeros above the diagonal), reciprocal diagonal for phase B
     for (int idx = t; idx < CH_NB * CH_NB; idx += CH_THREADS) {
         const int r = idx >> 7, c = idx & 127;
-        Ab[(size_t)r * lda + c] = S[r * CH_LD + c];  // L_kk, zeros above the diagonal
+        Ab[(size_t)r * lda + c] = (c <= r) ? S[r * CH_LD + c] : 0.0;
     }
+    if (t < CH_NB) dinv[t] = 1.0 / S[t * CH_LD + t];
     if (t == 0 && fail != 0 && info[b] == 0) info[b] = fail;
     __syncthreads();
-    // in-place inverse of the lower-triangular block (LAPACK trti2, lower): columns from the last to the first
-    for (int j = CH_NB - 1; j >= 0; --j) {
-        const double xjj = 1.0 / S[j * CH_LD + j];
-        // x_row = sum_{c = j+1..row} X[row][c] * L[c][j]   (X: the already inverted trailing block, same storage)
-        const double acc = (row > j) ? strided_dot(S + row * CH_LD, 1, S + j, CH_LD, j + 1, row + 1, part) : 0.0;
-        __syncthreads();
-        if (part == 0) {
-            if (row > j) S[row * CH_LD + j] = -acc * xjj;
-            if (row == j) S[j * CH_LD + j] = xjj;
+
+    PSTAMP(3)
+    // ---------------- phase B: X = inv(L), no workgroup barriers ----------------
+    // X[row][j] = -dinv[j] * ( dinv[row] * L[row][j] + sum_{c=j+1}^{row-1} X[row][c] * L[c][j] ),  X[row][c] parked at S[c][row]
+    {
+        const double drow = dinv[row];
+        for (int j = row - 1; j >= 0; --j) {
+            // terms c = j + 1 + part + 8 i < row; groups of four: 8 LDS reads issued back to back, then 4 FMAs
+            const int nit = (row - j - 1 + CH_TPR - 1 - part) / CH_TPR;
+            double acc0 = 0.0, acc1 = 0.0;
+            for (int i0 = 0; i0 < nit; i0 += 4) {
+                double xa[4], xb[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = (i0 + u < nit) ? i0 + u : nit - 1;
+                    const int c = j + 1 + part + CH_TPR * i;
+                    xa[u] = S[c * CH_LD + row];
+                    xb[u] = S[c * CH_LD + j];
+                }
+                acc0 += xa[0] * xb[0];
+                acc1 += (i0 + 1 < nit) ? xa[1] * xb[1] : 0.0;
+                acc0 += (i0 + 2 < nit) ? xa[2] * xb[2] : 0.0;
+                acc1 += (i0 + 3 < nit) ? xa[3] * xb[3] : 0.0;
+            }
+            double acc = acc0 + acc1;
+#pragma unroll
+            for (int o = 1; o < CH_TPR; o <<= 1) acc += __shfl_xor(acc, o);
+            if (part == 0) S[j * CH_LD + row] = -dinv[j] * (drow * Sr[j] + acc);
+            __builtin_amdgcn_wave_barrier();  // the 8 threads of a row share one wave: in-order LDS makes it visible
         }
-        __syncthreads();
     }
+    __syncthreads();
+    PSTAMP(4)
     double* Wb = work + (size_t)b * CH_NB * CH_NB;
     for (int idx = t; idx < CH_NB * CH_NB; idx += CH_THREADS) {
         const int r = idx >> 7, c = idx & 127;
-        Wb[idx] = S[r * CH_LD + c];
+        Wb[idx] = (c < r) ? S[c * CH_LD + r] : (c == r ? dinv[r] : 0.0);
     }
+#ifdef TSVGP_DIAG_POTRF
+    __syncthreads();
+    PSTAMP(5)
+    if (t == 0 && k == 0)
+        for (int i = 0; i < 6; ++i) reinterpret_cast<unsigned long long*>(Wb)[i] = stamp[i];
+#endif
+#undef PSTAMP
 }
 
 // 128x128x128 tile products for the panel solve and the trailing update; operands with arbitrary leading dimension.
