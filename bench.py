@@ -136,11 +136,17 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
+    if os.environ.get("TSVGP_BENCH_BACKEND", "nccl") != "nccl":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)  # rehearsal: ranks may share a GPU
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        backend = os.environ.get("TSVGP_BENCH_BACKEND", "nccl")  # "gloo" only to rehearse the multi-rank path on one GPU
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     dtype = torch.float64 if w["dtype"] == "f64" else torch.float32
     esize = 8 if w["dtype"] == "f64" else 4

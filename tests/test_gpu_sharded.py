@@ -1,0 +1,47 @@
+"""The N-sharded E-step on the GPU with more than one process: two ranks share cuda:0 (this box has one GPU) and
+all-reduce over ``gloo``; on an 8-GPU node the same code runs one rank per GPU over RCCL (bench.py --gpus N).
+Checks the sharded HIP path end to end against the single-process HIP path and the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import tsvgp_oracle as O
+from tests.helpers import pkg, relerr, synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        p = pkg()
+        X, Y, Z = synthetic(N=5001, M=96, D=4, lik="bernoulli", seed=9)
+        Xs, Ys = p.distributed.shard_rows(X, Y)
+        m = p.t_SVGP(p.SquaredExponential(1.0, 1.0), p.Bernoulli(), Z, num_data=5001, device="cuda:0")
+        Xd, Yd = torch.as_tensor(Xs, device="cuda:0"), torch.as_tensor(Ys, device="cuda:0")
+        for _ in range(3):
+            m.natgrad_step((Xd, Yd), lr=0.8)
+        e = float(m.elbo((Xd, Yd)))
+        if rank == 0:
+            np.savez(out, l1=m.lambda_1.numpy(), L2=m.lambda_2.cpu().numpy(), elbo=e)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_match_single_process(tmp_path):
+    out = str(tmp_path / "r0.npz")
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    got = np.load(out)
+    X, Y, Z = synthetic(N=5001, M=96, D=4, lik="bernoulli", seed=9)
+    ora = O.t_SVGP(O.SquaredExponential(1.0, 1.0), O.Bernoulli(), Z, num_data=5001)
+    for _ in range(3):
+        ora.natgrad_step((X, Y), lr=0.8)
+    assert relerr(got["l1"], ora.lambda_1) < 1e-8
+    assert relerr(got["L2"], ora.lambda_2) < 1e-8
+    assert abs(float(got["elbo"]) - ora.elbo((X, Y))) < 1e-9 * abs(ora.elbo((X, Y)))
