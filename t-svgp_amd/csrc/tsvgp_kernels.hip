@@ -1099,7 +1099,8 @@ __device__ __forceinline__ double rsqrt_nr(double x) {
 // redundantly in registers and solves its own row against it) and invert (barrier-free: row r of inv(L) only needs the
 // original columns of L and its own earlier entries, which are parked transposed in the unused upper triangle).
 __global__ __launch_bounds__(CH_THREADS) void potrf_diag_kernel(double* __restrict__ A, int lda, int64_t stride, int k,
-                                                                double* __restrict__ work, int* __restrict__ info) {
+                                                                double* __restrict__ work, int* __restrict__ info,
+                                                                int need_inverse) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     double* S = reinterpret_cast<double*>(smem_raw);  // [CH_NB][CH_LD]; lower: L, strict upper: inv(L)^T (phase B)
     __shared__ int fail;
@@ -1215,6 +1216,7 @@ __global__ __launch_bounds__(CH_THREADS) void potrf_diag_kernel(double* __restri
     }
     if (t < CH_NB) dinv[t] = 1.0 / S[t * CH_LD + t];
     if (t == 0 && fail != 0 && info[b] == 0) info[b] = fail;
+    if (!need_inverse) return;  // the last block column has no panel below it
     __syncthreads();
 
     PSTAMP(3)
@@ -1532,7 +1534,8 @@ int potrf(double* A, int M, int lda, int batch, int64_t stride, int* info, doubl
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(info, 0, sizeof(int) * batch, st) != hipSuccess) return TSVGP_ELAUNCH;
     for (int k = 0; k < nt; ++k) {
-        hipLaunchKernelGGL(potrf_diag_kernel, dim3(batch), dim3(CH_THREADS), smem, st, A, lda, stride, k, work, info);
+        hipLaunchKernelGGL(potrf_diag_kernel, dim3(batch), dim3(CH_THREADS), smem, st, A, lda, stride, k, work, info,
+                           (k + 1 < nt) ? 1 : 0);
         const int below = nt - k - 1;
         if (below > 0) {
             hipLaunchKernelGGL(chol_tile_kernel<0>, dim3(below, batch), dim3(NTHREADS), 0, st, A, lda, stride, k, nt,
