@@ -208,7 +208,8 @@ class EStepEngine:
         X [N, D], Y [N, P] (or None when lik_id == NONE), Z [M, D];
         whiten_Linv [M, M] fp64 = inv(chol(Kuu + jitter I)) or None (moments then act on Kfu directly);
         moment_Tm [P, M, M] fp64 and gamma [M, P] fp64: operands of the fused moments kernel;
-        sites=True also accumulates (acc2, acc1) from the whitened B (requires whiten_Linv).
+        sites=True also accumulates (acc2, acc1) = (sum g1 a a^T, sum g0 a) over the rows a of the same operand the
+        moments used: the whitened B when whiten_Linv is given, Kfu itself otherwise (the "direct" projection).
         b_tag: a hashable description of (X, Z, kernel parameters, jitter).  When it equals the tag of the B buffer left
         by the previous call, the fill and the whitening are skipped and B is reused ("warm" E-step: consecutive
         E-steps with unchanged hyperparameters, as in the reference's E/M loop, experiments/uci_regression.py:152-153).
@@ -227,26 +228,28 @@ class EStepEngine:
             Y = Y.to(device=dev, dtype=T).contiguous()
             if Y.dim() != 2 or Y.shape[0] != N or Y.shape[1] != P:
                 raise ValueError(f"Y must be [N, P] = [{N}, {P}], got {tuple(Y.shape)}")
-        if sites and whiten_Linv is None:
-            raise ValueError("site accumulation needs the whitening factor")
         Np, Mp = B.round_up(N), B.round_up(M)
         inv_ls = kernel.inv_lengthscales(D, T, dev)
         variance = float(kernel.variance.value)
 
-        reuse = (b_tag is not None and whiten_Linv is not None and self._b_tag == b_tag
-                 and self._buf.get("B") is not None and tuple(self._buf["B"].shape) == (Np, Mp))
+        # The N x M operand of the moments / site kernels: the whitened B = Kfu L^-T, or Kfu itself ("direct" route).
+        # A tagged operand left by the previous call is reused when the tag matches (warm E-steps).
+        want = "B" if whiten_Linv is not None else "Kfu"
+        reuse = (b_tag is not None and self._b_tag == (want, b_tag) and self._buf.get(want) is not None
+                 and tuple(self._buf[want].shape) == (Np, Mp))
         if reuse:
-            A = self._buf["B"]
+            A = self._buf[want]
         else:
+            self._b_tag = None
             Kfu = self._get("Kfu", (Np, Mp), T)
             self.se_fill(X, Z, inv_ls, variance, Kfu)
             A = Kfu
             if whiten_Linv is not None:
-                self._b_tag = None
                 Bw = self._get("B", (Np, Mp), T)
                 self.trmm(Kfu, self._pad_square(whiten_Linv, Mp, "pad_Linv"), Bw, B.TRI_LOWER)
                 A = Bw
-                self._b_tag = b_tag
+            if b_tag is not None:
+                self._b_tag = (want, b_tag)
 
         Tm = self._pad_square(moment_Tm, Mp, "pad_Tm")
         gam = torch.zeros((Mp, P), dtype=T, device=dev)

@@ -32,6 +32,7 @@ from ..base import default_device, default_float, default_jitter, to_tensor
 from ..inducing_variables import inducingpoint_wrapper
 from ..sites import DenseSites
 from ..util import (
+    chol_solve,
     cholesky_deferred,
     gradient_transformation_mean_var_to_expectation,
     kl_from_dense_site,
@@ -87,7 +88,7 @@ class t_SVGP(base_SVGP):
 
     def __init__(self, kernel, likelihood, inducing_variable, *, mean_function=None, num_latent_gps: int = 1,
                  lambda_1=None, lambda_2_sqrt=None, num_data=None, force=False, compute_dtype=None, device=None,
-                 cache_whitened=False):
+                 cache_whitened=False, projection="auto"):
         super().__init__(kernel, likelihood, inducing_variable, mean_function=mean_function,
                          num_latent_gps=num_latent_gps, num_data=num_data, compute_dtype=compute_dtype, device=device)
         self.num_inducing = self.inducing_variable.num_inducing
@@ -99,6 +100,16 @@ class t_SVGP(base_SVGP):
         # call; with the cache off -- the default -- so does this class).
         self.cache_whitened = cache_whitened
         self._warm = None
+        # How the projection A = K_fu K_uu^-1 of tsvgp.py:268-271 enters the site sums:
+        #   "whitened": B = K_fu L^-T by an N-sized triangular product, sums over b b^T, two M x M back-solves
+        #               (error ~ sqrt(cond K_uu) eps: safe for any K_uu the reference can factorise);
+        #   "direct":   sums over k k^T on K_fu itself, then K_uu^-1 (.) K_uu^-1 by M x M Cholesky solves
+        #               (error ~ cond(K_uu) eps; one N M^2 product fewer);
+        #   "auto":     direct when cond(K_uu + jitter I) is small enough for the dtype, else whitened.
+        if projection not in ("auto", "whitened", "direct"):
+            raise ValueError("projection must be 'auto', 'whitened' or 'direct'")
+        self.projection = projection
+        self._cond_cache = None
         self.name = "t_svgp"  # tf.Module derives this from the class name (experiments/uci_regression.py:150)
 
     def _init_variational_parameters(self, num_inducing, lambda_1, lambda_2_sqrt, **kwargs):
@@ -140,7 +151,27 @@ class t_SVGP(base_SVGP):
         return (X.data_ptr(), tuple(X.shape), X._version, X.dtype, k.variance.version, k.lengthscales.version,
                 id(self.inducing_variable.Z), self.inducing_variable.Z.version, float(jitter), self.compute_dtype)
 
-    def _site_operands(self, whiten_jitter=None, dense_moments=False, warm_key=None):
+    # The direct route's error grows like cond(K_uu)^2 eps (K^-1 (sum g k k^T) K^-1 cancels two factors of K):
+    # cond <= 1e3 keeps it <= ~1e-9 relative in fp64, cond <= 30 <= ~1e-4 in fp32 (the stated tolerances).
+    DIRECT_MAX_COND = {torch.float64: 1.0e3, torch.float32: 30.0}
+
+    def _use_direct(self, jitter) -> bool:
+        """Chooses the projection route.  In "auto" mode the 2-norm condition number of K_uu + jitter I is computed
+        (symmetric eigenvalues, M x M, one host read) only when the kernel parameters, Z or the jitter changed."""
+        if self.projection != "auto":
+            return self.projection == "direct"
+        k = self.kernel
+        key = (k.variance.version, k.lengthscales.version, id(self.inducing_variable.Z), self.inducing_variable.Z.version,
+               float(jitter))
+        if self._cond_cache is None or self._cond_cache[0] != key:
+            Kzz = self._get_engine().kuu(self._Z(), self.kernel)
+            ev = torch.linalg.eigvalsh(Kzz + jitter * torch.eye(Kzz.shape[0], dtype=Kzz.dtype, device=Kzz.device))
+            lo, hi = float(ev[0]), float(ev[-1])
+            cond = hi / lo if lo > 0 else float("inf")
+            self._cond_cache = (key, cond)
+        return self._cond_cache[1] <= self.DIRECT_MAX_COND[self.compute_dtype]
+
+    def _site_operands(self, whiten_jitter=None, dense_moments=False, warm_key=None, direct=False):
         """Everything the N-pass needs that depends only on (theta, Z, lambda): O(M^3), fp64, replicated.
         No host synchronisation happens here: Cholesky statuses are collected in ops["infos"] and checked once per
         call by ``_check_step`` (TF raises immediately; here the raise comes at the end of the same call)."""
@@ -170,10 +201,29 @@ class t_SVGP(base_SVGP):
         DKl = torch.einsum("pmk,kp->pm", Dm @ K6, l1)
         beta = l1 - torch.einsum("pkm,pk->mp", Dm, DKl)  # K6^-1 m = l1 - D^T D K6 l1
         ops = dict(Z=Z, Kzz=Kzz, K6=K6, D=Dm, chol_W=chol_W, beta=beta, Id=Id, infos=infos, G_info=None, potrf=potrf)
-        if whiten_jitter is not None:
-            ops["L9"] = L9  # chol(K_uu + jitter I), tsvgp.py:268-270
-            ops["Linv9"] = warm[1]["Linv9"] if warm else torch.linalg.solve_triangular(L9, Id, upper=False)
+        if whiten_jitter is not None and direct:
+            # direct projection: the moments act on K_fu with a triangular factor of D^T D (+ relative jitter), the sums
+            # are mapped by K9^-1 (.) K9^-1 afterwards; no N-sized whitening, no inverse of L9
+            ops["L9"], ops["Linv9"], ops["gamma"] = L9, None, beta
             if warm_key is not None and not warm:
+                self._warm = (warm_key, dict(Kzz=Kzz, L9=L9, Linv9=None))
+            if dense_moments:
+                ops["moment_Tm"], ops["moment_mode"] = Dm, B.TRI_DENSE
+            else:
+                # var = knn - k^T Q k, Q = D^T D = F F^T (+ eps I).  k^T Q k <= lmax(Q) |k|^2 <= cond(K_uu) knn, so the jitter
+                # eps = 1e-14 max diag(Q) moves var by <= 1e-14 cond(K_uu) knn -- the direct route only runs for small cond
+                Q = Dm.transpose(-1, -2) @ Dm
+                dscale = torch.diagonal(Q, dim1=-2, dim2=-1).amax(dim=-1).clamp_min(1e-300)
+                Q = 0.5 * (Q + Q.transpose(-1, -2)) + (1e-14 * dscale)[:, None, None] * Id
+                ginfo = []
+                Fq = cholesky_deferred(Q, ginfo, potrf)
+                ops["G_info"] = ginfo[0]
+                ops["moment_Tm"], ops["moment_mode"] = Fq.transpose(-1, -2).contiguous(), B.TRI_UPPER
+        elif whiten_jitter is not None:
+            ops["L9"] = L9  # chol(K_uu + jitter I), tsvgp.py:268-270
+            ops["Linv9"] = (warm[1]["Linv9"] if (warm and warm[1]["Linv9"] is not None)
+                            else torch.linalg.solve_triangular(L9, Id, upper=False))
+            if warm_key is not None and (not warm or warm[1]["Linv9"] is None):
                 self._warm = (warm_key, dict(Kzz=Kzz, L9=L9, Linv9=ops["Linv9"]))
             ops["gamma"] = L9.transpose(-1, -2) @ beta
             T = Dm @ L9
@@ -191,20 +241,27 @@ class t_SVGP(base_SVGP):
                 ops["moment_Tm"], ops["moment_mode"] = F.transpose(-1, -2).contiguous(), B.TRI_UPPER
         return ops
 
-    def _check_step(self, ops, nonpos, extra_infos=()):
+    def _check_step(self, ops, nonpos, extra_infos=(), soft_final=False):
         """ONE device->host read per call: Cholesky statuses, the moments-factor status and the count of non-positive
-        variances.  Returns False when only the moments factor F failed (the caller retries with the dense product);
-        raises FloatingPointError for what TensorFlow raises on (tsvgp.py:113 assert_positive; failed Cholesky)."""
-        parts = list(ops["infos"]) + list(extra_infos)
-        g = ops["G_info"] if ops["G_info"] is not None else torch.zeros(1, dtype=torch.float64, device=self.device)
-        flags = torch.cat([torch.cat(parts).sum().reshape(1), g.reshape(1),
-                           nonpos.reshape(1).to(torch.float64)]).cpu()
-        if float(flags[0]) != 0:
+        variances.  Returns True when the step stands; False when only the moments factor F failed (the caller retries
+        with the dense product); "whiten" when soft_final is set and the final factorisation failed (the direct
+        projection lost definiteness: the caller retries with the whitened route); raises FloatingPointError for what
+        TensorFlow raises on (tsvgp.py:113 assert_positive; failed Cholesky)."""
+        zero = torch.zeros(1, dtype=torch.float64, device=self.device)
+        g = ops["G_info"] if ops["G_info"] is not None else zero
+        final = torch.cat(list(extra_infos)).sum().reshape(1) if len(extra_infos) else zero
+        flags = torch.cat([torch.cat(list(ops["infos"])).sum().reshape(1), g.reshape(1),
+                           nonpos.reshape(1).to(torch.float64), final]).cpu()
+        if float(flags[0]) != 0:  # chol(W) or chol(K_uu + jitter I)
             raise FloatingPointError("Cholesky decomposition was not successful (matrix not positive definite)")
-        if float(flags[1]) != 0:
+        if float(flags[1]) != 0:  # only the moments factor failed: everything downstream is garbage, retry dense
             return False
         if not (float(flags[2]) == 0):  # a NaN count also lands here
             raise FloatingPointError(f"non-positive predictive variance at {float(flags[2]):.0f} point(s)")
+        if float(flags[3]) != 0:  # chol(-2 lambda_2 + jitter I), tsvgp.py:300
+            if soft_final:
+                return "whiten"
+            raise FloatingPointError("Cholesky decomposition was not successful (matrix not positive definite)")
         return True
 
     def get_mean_chol_cov_inducing_posterior(self):
@@ -287,27 +344,39 @@ class t_SVGP(base_SVGP):
         synchronisation; one device->host read of the status flags ends it."""
         X, Y = self._as_device(data[0]), self._as_device(data[1])
         old_l1, old_L = self.lambda_1.value, self.lambda_2_sqrt.value
-        for dense in (False, True):
-            # (Overlapping the K(X, Z) fill with this latency-bound prelude on a second stream was measured and is not
-            # used: the fill's workgroups occupy every CU, so the prelude's single-workgroup kernels just queue.)
+        direct = self._use_direct(jitter)
+        # (projection route, dense moments?) in the order they are tried; everything after the first is a fallback
+        attempts = [(direct, False), (direct, True)] + ([(False, False), (False, True)] if direct else [])
+        i = 0
+        while i < len(attempts):
+            use_direct, dense = attempts[i]
             warm_key = self._warm_key(X, jitter)
-            ops = self._site_operands(whiten_jitter=jitter, dense_moments=dense, warm_key=warm_key)
+            ops = self._site_operands(whiten_jitter=jitter, dense_moments=dense, warm_key=warm_key, direct=use_direct)
             st = self._get_engine().run(X, Y, ops["Z"], self.kernel, moment_Tm=ops["moment_Tm"],
                                         moment_mode=ops["moment_mode"], gamma=ops["gamma"],
                                         lik_id=self.likelihood.lik_id, lik_param=self.likelihood.lik_param,
                                         whiten_Linv=ops["Linv9"], sites=True, b_tag=warm_key)
             try:
-                done = self._apply_site_update(st, ops, lr, jitter)
+                verdict = self._apply_site_update(st, ops, lr, jitter, soft_final=use_direct)
             except FloatingPointError:
                 self.lambda_1.assign(old_l1)  # the reference raises before its assigns: leave the state untouched
                 self.sites.assign_lambda_2_sqrt(old_L)
                 raise
-            if done:
+            if verdict is True:
                 return
             self.lambda_1.assign(old_l1)
             self.sites.assign_lambda_2_sqrt(old_L)
+            if verdict == "whiten":
+                # the direct projection lost the definiteness of -2 lambda_2 + jitter I (its error is ~cond(K_uu)^2 eps
+                # of |G1|, the jitter is absolute): redo with the whitened route and stay there until parameters change
+                if self._cond_cache is not None:
+                    self._cond_cache = (self._cond_cache[0], float("inf"))
+                i = 2
+            else:
+                i += 1
+        raise FloatingPointError("Cholesky decomposition was not successful (matrix not positive definite)")
 
-    def _apply_site_update(self, st, ops, lr, jitter):
+    def _apply_site_update(self, st, ops, lr, jitter, soft_final=False):
         """All-reduce of the packed accumulators (RCCL) + the replicated M x M epilogue (tsvgp.py:278-303).
         Returns False if the step has to be redone with the dense moments product."""
         P, M = self.num_latent_gps, self.num_inducing
@@ -317,11 +386,19 @@ class t_SVGP(base_SVGP):
         acc2, acc1, _, nonpos, rows = D_.unpack_stats(packed, P, M, True)
 
         Linv9, Kzz, beta = ops["Linv9"], ops["Kzz"], ops["beta"]
-        # G1 = L9^-T acc2 L9^-1,  G0 = L9^-T acc1   (tsvgp.py:279-280 in whitened coordinates)
-        Linv9t = Linv9.transpose(-1, -2)
-        G1 = Linv9t @ acc2 @ Linv9
+        if Linv9 is None:
+            # direct projection: acc2 = sum g1 k k^T, acc1 = sum g0 k  ->  G1 = K9^-1 acc2 K9^-1, G0 = K9^-1 acc1
+            # (two triangular solves per application: torch.cholesky_solve returned wrong values for small batched
+            # right-hand sides on this ROCm build -- tools/check_cholesky_solve.py, 188 of 300 calls at M=12, P=2)
+            L9 = ops["L9"]
+            G1 = chol_solve(L9, chol_solve(L9, acc2).transpose(-1, -2))
+            G0 = chol_solve(L9, acc1.transpose(-1, -2))  # [M, P]
+        else:
+            # G1 = L9^-T acc2 L9^-1,  G0 = L9^-T acc1   (tsvgp.py:279-280 in whitened coordinates)
+            Linv9t = Linv9.transpose(-1, -2)
+            G1 = Linv9t @ acc2 @ Linv9
+            G0 = Linv9t @ acc1.transpose(-1, -2)  # [M, P]
         G1 = 0.5 * (G1 + G1.transpose(-1, -2))
-        G0 = Linv9t @ acc1.transpose(-1, -2)  # [M, P]
         meanZ = Kzz @ beta  # predict_f(Z) mean, tsvgp.py:249-254
         grad_mu = gradient_transformation_mean_var_to_expectation(meanZ, [G0, G1])  # tsvgp.py:284
 
@@ -336,4 +413,4 @@ class t_SVGP(base_SVGP):
         self.lambda_1.assign(lambda_1)  # tsvgp.py:302
         self.sites.assign_lambda_2_sqrt(lambda_2_sqrt)  # tsvgp.py:303
         # tsvgp.py:304 recomputes the posterior and discards it: dead work, not reproduced.
-        return self._check_step(ops, nonpos, final_info)
+        return self._check_step(ops, nonpos, final_info, soft_final=soft_final)

@@ -32,6 +32,12 @@ def cholesky_deferred(a: torch.Tensor, infos: list, potrf=None) -> torch.Tensor:
     return L
 
 
+def chol_solve(L: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """(L L^T)^-1 b by two triangular solves (``tf.linalg.cholesky_solve(L, b)``).  L [M, M], b [..., M, K]."""
+    x = torch.linalg.solve_triangular(L, b, upper=False)
+    return torch.linalg.solve_triangular(L.transpose(-1, -2), x, upper=True)
+
+
 def _check_site_shapes(K, lambda_1, lambda_2_sqrt, who):
     if K.dim() < 2 or K.shape[-1] != K.shape[-2]:
         raise ValueError(f"{who}: K must be [..., M, M]")

@@ -224,3 +224,36 @@ def test_warm_cache_matches_cold_and_invalidates():
         assert relerr(warm.lambda_1.numpy(), cold.lambda_1.numpy()) < 1e-12
         assert relerr(warm.lambda_2.cpu().numpy(), cold.lambda_2.cpu().numpy()) < 1e-12
     assert warm._get_engine()._b_tag is not None
+
+
+@pytest.mark.parametrize("lik,P", [("gaussian", 2), ("bernoulli", 1)])
+@pytest.mark.parametrize("projection", ["whitened", "direct"])
+def test_both_projection_routes_match_oracle(lik, P, projection):
+    """The whitened route (N-sized triangular product) and the direct route (sums on K_fu, K_uu^-1 applied afterwards)
+    are the same algebra; on a well-conditioned K_uu both meet the fp64 tolerance against the oracle."""
+    p = pkg()
+    rng = np.random.RandomState(11)
+    X, Y, _ = synthetic(N=1200, M=64, D=6, P=P, lik=lik, seed=6)
+    Z = rng.randn(64, 6) * 1.5  # spread inducing points: cond(K_uu) of order 10
+    hip = p.t_SVGP(p.SquaredExponential(1.0, 1.0), p.Gaussian(0.1) if lik == "gaussian" else p.Bernoulli(), Z,
+                   num_latent_gps=P, projection=projection)
+    ora = O.t_SVGP(O.SquaredExponential(1.0, 1.0), O.Gaussian(0.1) if lik == "gaussian" else O.Bernoulli(), Z,
+                   num_latent_gps=P)
+    for _ in range(5):
+        hip.natgrad_step((X, Y), lr=0.8)
+        ora.natgrad_step((X, Y), lr=0.8)
+        _compare_state(hip, ora, 1e-8)
+    e_h, e_o = float(hip.elbo((X, Y))), float(ora.elbo((X, Y)))
+    assert abs(e_h - e_o) / abs(e_o) < 1e-9
+
+
+def test_auto_projection_gate():
+    """"auto" picks the direct route only when cond(K_uu + jitter I) is small; ill-conditioned K_uu stays whitened."""
+    p = pkg()
+    rng = np.random.RandomState(12)
+    well = p.t_SVGP(p.SquaredExponential(1.0, 1.0), p.Gaussian(0.1), rng.randn(50, 8) * 2.0)
+    ill = p.t_SVGP(p.SquaredExponential(1.0, 2.0), p.Gaussian(0.1), rng.rand(50, 1) * 2 - 1)  # test_tsvgp.py geometry
+    assert well._use_direct(1e-9) and not ill._use_direct(1e-9)
+    assert well._cond_cache[1] < 1e3 and ill._cond_cache[1] > 1e6
+    well.kernel.lengthscales.assign(50.0)  # nearly constant kernel: the cached decision must be re-evaluated
+    assert not well._use_direct(1e-9)
