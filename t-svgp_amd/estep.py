@@ -202,14 +202,16 @@ class EStepEngine:
 
     # ------------------------------------------------------------------ one N-pass
     def run(self, X, Y, Z, kernel, *, moment_Tm, moment_mode, gamma, lik_id=B.LIK_NONE, lik_param=0.0,
-            whiten_Linv=None, sites=False, want_moments=False, want_grads=False, b_tag=None) -> EStepStats:
+            whiten_T=None, whiten_mode=B.TRI_UPPER, sites=False, want_moments=False, want_grads=False,
+            b_tag=None) -> EStepStats:
         """One pass over the shard's rows.
 
         X [N, D], Y [N, P] (or None when lik_id == NONE), Z [M, D];
-        whiten_Linv [M, M] fp64 = inv(chol(Kuu + jitter I)) or None (moments then act on Kfu directly);
+        whiten_T [M, M] fp64: the inverted triangular factor of Kuu + jitter I (B[n, i] = sum_j Kfu[n, j] whiten_T[i, j]
+        over the triangle ``whiten_mode`` names), or None (moments then act on Kfu directly);
         moment_Tm [P, M, M] fp64 and gamma [M, P] fp64: operands of the fused moments kernel;
         sites=True also accumulates (acc2, acc1) = (sum g1 a a^T, sum g0 a) over the rows a of the same operand the
-        moments used: the whitened B when whiten_Linv is given, Kfu itself otherwise (the "direct" projection).
+        moments used: the whitened B when whiten_T is given, Kfu itself otherwise (the "direct" projection).
         b_tag: a hashable description of (X, Z, kernel parameters, jitter).  When it equals the tag of the B buffer left
         by the previous call, the fill and the whitening are skipped and B is reused ("warm" E-step: consecutive
         E-steps with unchanged hyperparameters, as in the reference's E/M loop, experiments/uci_regression.py:152-153).
@@ -232,9 +234,9 @@ class EStepEngine:
         inv_ls = kernel.inv_lengthscales(D, T, dev)
         variance = float(kernel.variance.value)
 
-        # The N x M operand of the moments / site kernels: the whitened B = Kfu L^-T, or Kfu itself ("direct" route).
+        # The N x M operand of the moments / site kernels: the whitened B = Kfu U^-T, or Kfu itself ("direct" route).
         # A tagged operand left by the previous call is reused when the tag matches (warm E-steps).
-        want = "B" if whiten_Linv is not None else "Kfu"
+        want = "B" if whiten_T is not None else "Kfu"
         reuse = (b_tag is not None and self._b_tag == (want, b_tag) and self._buf.get(want) is not None
                  and tuple(self._buf[want].shape) == (Np, Mp))
         if reuse:
@@ -244,9 +246,9 @@ class EStepEngine:
             Kfu = self._get("Kfu", (Np, Mp), T)
             self.se_fill(X, Z, inv_ls, variance, Kfu)
             A = Kfu
-            if whiten_Linv is not None:
+            if whiten_T is not None:
                 Bw = self._get("B", (Np, Mp), T)
-                self.trmm(Kfu, self._pad_square(whiten_Linv, Mp, "pad_Linv"), Bw, B.TRI_LOWER)
+                self.trmm(Kfu, self._pad_square(whiten_T, Mp, "pad_Linv"), Bw, whiten_mode)
                 A = Bw
             if b_tag is not None:
                 self._b_tag = (want, b_tag)

@@ -5,19 +5,24 @@ Same constructor, properties and methods as the reference's ``t_SVGP`` so a driv
 runs unchanged, but every N-sized operation goes through the HIP kernels behind ``include/tsvgp_hip.h`` and the
 M x M site algebra runs on the GPU in fp64 through torch.  There is no CPU fallback.
 
-Algebra of one E-step (P latents, shared kernel; K6 = Kuu + 1e-6 I, K9 = Kuu + jitter I, L9 = chol(K9)):
+Algebra of one E-step (P latents, shared kernel; K6 = Kuu + 1e-6 I, K9 = Kuu + jitter I).  Factorisations are taken
+in upper form, W = U_W U_W^T and K9 = U9 U9^T (``util.rev_cholesky``), which makes every N-sized product triangular:
 
-  reference (tsvgp.py:234-304)                       here
+  reference (tsvgp.py:234-304)                       here (whitened route)
   -------------------------------------------------  ----------------------------------------------------------
-  (m, chol S) = posterior_from_dense_site(K6, ...)   D = chol(W)^-1 L^T, W = I + L^T K6 L        (util.py:168-175)
-  mean = Kfu K6^-1 m                                 mean = B gamma,  gamma = L9^T beta,  beta = l1 - D^T D K6 l1
-  var  = knn - |Lm^-1 k|^2 + |chol S^T K6^-1 k|^2    var  = knn - |F^T b|^2,  F F^T = (D L9)^T (D L9)   [= knn - |D k|^2]
-  A = Kfu K9^-1;  G1 = sum g1 a a^T                  B = Kfu L9^-T (HIP trmm);  acc2 = sum g1 b b^T (HIP syrk)
-                                                     G1 = L9^-T acc2 L9^-1   (two M x M triangular solves)
-  G0 = sum g0 a                                      G0 = L9^-T acc1
+  (m, chol S) = posterior_from_dense_site(K6, ...)   D = U_W^-1 L^T (upper), W = I + L^T K6 L       (util.py:168-175)
+  mean = Kfu K6^-1 m                                 mean = B gamma,  gamma = U9^T beta,  beta = l1 - D^T D K6 l1
+  var  = knn - |Lm^-1 k|^2 + |chol S^T K6^-1 k|^2    var  = knn - |T b|^2,  T = D U9 (upper)          [= knn - |D k|^2]
+  A = Kfu K9^-1;  G1 = sum g1 a a^T                  B = Kfu U9^-T (HIP trmm);  acc2 = sum g1 b b^T (HIP syrk)
+                                                     G1 = U9^-T acc2 U9^-1
+  G0 = sum g0 a                                      G0 = U9^-T acc1
   lambda update + (-chol)                            identical (tsvgp.py:293-300)
 
-Accumulating in whitened coordinates (B, not Kfu) keeps the M x M back-solves at cond(L9) = sqrt(cond(K9)).
+Accumulating in whitened coordinates (B, not Kfu) keeps the M x M back-solves at cond(U9) = sqrt(cond(K9)).
+
+Direct route (``projection="auto"`` picks it when cond(K9) <= DIRECT_MAX_COND): no N-sized whitening at all,
+  mean = Kfu beta,  var = knn - |D k|^2 (D upper),  acc2 = sum g1 k k^T,  G1 = K9^-1 acc2 K9^-1,  G0 = K9^-1 acc1,
+whose error grows like cond(K9)^2 eps; it falls back to the whitened route if the final factorisation fails.
 """
 from __future__ import annotations
 
@@ -32,11 +37,12 @@ from ..base import default_device, default_float, default_jitter, to_tensor
 from ..inducing_variables import inducingpoint_wrapper
 from ..sites import DenseSites
 from ..util import (
-    chol_solve,
+    chol_solve_upper,
     cholesky_deferred,
     gradient_transformation_mean_var_to_expectation,
     kl_from_dense_site,
     posterior_from_dense_site,
+    rev_cholesky,
 )
 
 
@@ -144,7 +150,7 @@ class t_SVGP(base_SVGP):
         return self.inducing_variable.Z.value.to(self.device)
 
     def _warm_key(self, X, jitter):
-        """Cache key of everything B = K(X, Z) L9^-T depends on; None when caching is off or X is not a device tensor."""
+        """Cache key of everything B = K(X, Z) U9^-T depends on; None when caching is off or X is not a device tensor."""
         if not self.cache_whitened or not isinstance(X, torch.Tensor) or X.device != self.device:
             return None
         k = self.kernel
@@ -171,10 +177,15 @@ class t_SVGP(base_SVGP):
             self._cond_cache = (key, cond)
         return self._cond_cache[1] <= self.DIRECT_MAX_COND[self.compute_dtype]
 
-    def _site_operands(self, whiten_jitter=None, dense_moments=False, warm_key=None, direct=False):
+    def _site_operands(self, whiten_jitter=None, warm_key=None, direct=False):
         """Everything the N-pass needs that depends only on (theta, Z, lambda): O(M^3), fp64, replicated.
         No host synchronisation happens here: Cholesky statuses are collected in ops["infos"] and checked once per
-        call by ``_check_step`` (TF raises immediately; here the raise comes at the end of the same call)."""
+        call by ``_check_step`` (TF raises immediately; here the raise comes at the end of the same call).
+
+        Both factorisations are taken in UPPER form, A = U U^T (``rev_cholesky``).  With W = U_W U_W^T the projection
+        D = U_W^-1 L^T (util.py:168-175 up to an orthogonal factor: D^T D = L W^-1 L^T either way) is itself upper
+        triangular, and so is T = D U9 for K_uu + jitter I = U9 U9^T: the predictive variance knn - |D k|^2 =
+        knn - |T b|^2 is a triangular product without any further factorisation."""
         eng = self._get_engine()
         Z = self._Z()
         M = Z.shape[0]
@@ -186,79 +197,52 @@ class t_SVGP(base_SVGP):
         l1 = self.lambda_1.value
         L = self.lambda_2_sqrt.value
         potrf = getattr(eng, "cholesky", None)  # HIP blocked Cholesky (tsvgp_potrf_f64)
-        # W = I + L^T K6 L (util.py:171-172, formed without chol(K6)).  chol(W) and chol(K_uu + jitter I) are
-        # independent and both latency bound (one workgroup per diagonal block): factor them in ONE batched call.
+        # W = I + L^T K6 L (util.py:171-172, formed without chol(K6)).  The factorisations of W and K_uu + jitter I are
+        # independent and both latency bound (one workgroup per diagonal block): do them in ONE batched call.
         W = Id + L.transpose(-1, -2) @ (K6 @ L)
         W = 0.5 * (W + W.transpose(-1, -2))
         if whiten_jitter is not None and warm:
-            chol_W, L9 = cholesky_deferred(W, infos, potrf), warm[1]["L9"]
+            U_W, U9 = rev_cholesky(W, infos, potrf), warm[1]["U9"]
         elif whiten_jitter is not None:
-            both = cholesky_deferred(torch.cat([W, (Kzz + whiten_jitter * Id)[None]], dim=0), infos, potrf)
-            chol_W, L9 = both[:-1], both[-1]
+            both = rev_cholesky(torch.cat([W, (Kzz + whiten_jitter * Id)[None]], dim=0), infos, potrf)
+            U_W, U9 = both[:-1], both[-1]
         else:
-            chol_W, L9 = cholesky_deferred(W, infos, potrf), None
-        Dm = torch.linalg.solve_triangular(chol_W, L.transpose(-1, -2), upper=False)  # D = chol(W)^-1 L^T, [P, M, M]
+            U_W, U9 = rev_cholesky(W, infos, potrf), None
+        Dm = torch.linalg.solve_triangular(U_W, L.transpose(-1, -2), upper=True).triu()  # D = U_W^-1 L^T, [P, M, M]
         DKl = torch.einsum("pmk,kp->pm", Dm @ K6, l1)
         beta = l1 - torch.einsum("pkm,pk->mp", Dm, DKl)  # K6^-1 m = l1 - D^T D K6 l1
-        ops = dict(Z=Z, Kzz=Kzz, K6=K6, D=Dm, chol_W=chol_W, beta=beta, Id=Id, infos=infos, G_info=None, potrf=potrf)
+        ops = dict(Z=Z, Kzz=Kzz, K6=K6, D=Dm, U_W=U_W, beta=beta, Id=Id, infos=infos, potrf=potrf,
+                   moment_mode=B.TRI_UPPER, whiten_mode=B.TRI_UPPER)
         if whiten_jitter is not None and direct:
-            # direct projection: the moments act on K_fu with a triangular factor of D^T D (+ relative jitter), the sums
-            # are mapped by K9^-1 (.) K9^-1 afterwards; no N-sized whitening, no inverse of L9
-            ops["L9"], ops["Linv9"], ops["gamma"] = L9, None, beta
+            # direct projection: the moments act on K_fu with D itself, the sums are mapped by K9^-1 (.) K9^-1
+            # afterwards; no N-sized whitening, no inverse of U9
+            ops["U9"], ops["Uinv9"], ops["gamma"], ops["moment_Tm"] = U9, None, beta, Dm
             if warm_key is not None and not warm:
-                self._warm = (warm_key, dict(Kzz=Kzz, L9=L9, Linv9=None))
-            if dense_moments:
-                ops["moment_Tm"], ops["moment_mode"] = Dm, B.TRI_DENSE
-            else:
-                # var = knn - k^T Q k, Q = D^T D = F F^T (+ eps I).  k^T Q k <= lmax(Q) |k|^2 <= cond(K_uu) knn, so the jitter
-                # eps = 1e-14 max diag(Q) moves var by <= 1e-14 cond(K_uu) knn -- the direct route only runs for small cond
-                Q = Dm.transpose(-1, -2) @ Dm
-                dscale = torch.diagonal(Q, dim1=-2, dim2=-1).amax(dim=-1).clamp_min(1e-300)
-                Q = 0.5 * (Q + Q.transpose(-1, -2)) + (1e-14 * dscale)[:, None, None] * Id
-                ginfo = []
-                Fq = cholesky_deferred(Q, ginfo, potrf)
-                ops["G_info"] = ginfo[0]
-                ops["moment_Tm"], ops["moment_mode"] = Fq.transpose(-1, -2).contiguous(), B.TRI_UPPER
+                self._warm = (warm_key, dict(Kzz=Kzz, U9=U9, Uinv9=None))
         elif whiten_jitter is not None:
-            ops["L9"] = L9  # chol(K_uu + jitter I), tsvgp.py:268-270
-            ops["Linv9"] = (warm[1]["Linv9"] if (warm and warm[1]["Linv9"] is not None)
-                            else torch.linalg.solve_triangular(L9, Id, upper=False))
-            if warm_key is not None and (not warm or warm[1]["Linv9"] is None):
-                self._warm = (warm_key, dict(Kzz=Kzz, L9=L9, Linv9=ops["Linv9"]))
-            ops["gamma"] = L9.transpose(-1, -2) @ beta
-            T = Dm @ L9
-            if dense_moments:
-                ops["moment_Tm"], ops["moment_mode"] = T, B.TRI_DENSE
-            else:
-                # var = knn - |T b|^2 = knn - |F^T b|^2 with F F^T = T^T T + eps I.  |b|^2 <= knn (1 + o(1)), so the
-                # jitter eps = 1e-14 moves var by <= 1e-14 knn (rounding level) and keeps the factorisation safe when
-                # the site precision is numerically rank deficient (e.g. the initial lambda_2_sqrt = -1e-10 I).
-                G = T.transpose(-1, -2) @ T
-                G = 0.5 * (G + G.transpose(-1, -2)) + 1e-14 * Id
-                ginfo = []
-                F = cholesky_deferred(G, ginfo, potrf)
-                ops["G_info"] = ginfo[0]
-                ops["moment_Tm"], ops["moment_mode"] = F.transpose(-1, -2).contiguous(), B.TRI_UPPER
+            ops["U9"] = U9  # K_uu + jitter I = U9 U9^T, tsvgp.py:268-270
+            ops["Uinv9"] = (warm[1]["Uinv9"] if (warm and warm[1]["Uinv9"] is not None)
+                            else torch.linalg.solve_triangular(U9, Id, upper=True).triu())
+            if warm_key is not None and (not warm or warm[1]["Uinv9"] is None):
+                self._warm = (warm_key, dict(Kzz=Kzz, U9=U9, Uinv9=ops["Uinv9"]))
+            ops["gamma"] = U9.transpose(-1, -2) @ beta  # mean = k^T beta = b^T U9^T beta with b = U9^-1 k
+            ops["moment_Tm"] = (Dm @ U9).triu()  # var = knn - |D k|^2 = knn - |T b|^2
         return ops
 
     def _check_step(self, ops, nonpos, extra_infos=(), soft_final=False):
-        """ONE device->host read per call: Cholesky statuses, the moments-factor status and the count of non-positive
-        variances.  Returns True when the step stands; False when only the moments factor F failed (the caller retries
-        with the dense product); "whiten" when soft_final is set and the final factorisation failed (the direct
-        projection lost definiteness: the caller retries with the whitened route); raises FloatingPointError for what
-        TensorFlow raises on (tsvgp.py:113 assert_positive; failed Cholesky)."""
+        """ONE device->host read per call: Cholesky statuses and the count of non-positive variances.
+        Returns True when the step stands; "whiten" when soft_final is set and the final factorisation failed (the
+        direct projection lost definiteness: the caller retries with the whitened route); raises FloatingPointError
+        for what TensorFlow raises on (tsvgp.py:113 assert_positive; failed Cholesky)."""
         zero = torch.zeros(1, dtype=torch.float64, device=self.device)
-        g = ops["G_info"] if ops["G_info"] is not None else zero
         final = torch.cat(list(extra_infos)).sum().reshape(1) if len(extra_infos) else zero
-        flags = torch.cat([torch.cat(list(ops["infos"])).sum().reshape(1), g.reshape(1),
-                           nonpos.reshape(1).to(torch.float64), final]).cpu()
-        if float(flags[0]) != 0:  # chol(W) or chol(K_uu + jitter I)
+        flags = torch.cat([torch.cat(list(ops["infos"])).sum().reshape(1), nonpos.reshape(1).to(torch.float64),
+                           final]).cpu()
+        if float(flags[0]) != 0:  # factorisation of W or of K_uu + jitter I
             raise FloatingPointError("Cholesky decomposition was not successful (matrix not positive definite)")
-        if float(flags[1]) != 0:  # only the moments factor failed: everything downstream is garbage, retry dense
-            return False
-        if not (float(flags[2]) == 0):  # a NaN count also lands here
-            raise FloatingPointError(f"non-positive predictive variance at {float(flags[2]):.0f} point(s)")
-        if float(flags[3]) != 0:  # chol(-2 lambda_2 + jitter I), tsvgp.py:300
+        if not (float(flags[1]) == 0):  # a NaN count also lands here
+            raise FloatingPointError(f"non-positive predictive variance at {float(flags[1]):.0f} point(s)")
+        if float(flags[2]) != 0:  # chol(-2 lambda_2 + jitter I), tsvgp.py:300
             if soft_final:
                 return "whiten"
             raise FloatingPointError("Cholesky decomposition was not successful (matrix not positive definite)")
@@ -274,7 +258,7 @@ class t_SVGP(base_SVGP):
     def prior_kl(self):
         """KL[q(u) || p(u)] (tsvgp.py:65-70)."""
         ops = self._site_operands()
-        kl = kl_from_dense_site(ops["K6"], self.lambda_1.value, ops["D"], ops["chol_W"], ops["beta"])
+        kl = kl_from_dense_site(ops["K6"], self.lambda_1.value, ops["D"], ops["U_W"], ops["beta"])
         self._check_step(ops, torch.zeros(1, dtype=torch.float64, device=self.device))
         return kl
 
@@ -290,13 +274,11 @@ class t_SVGP(base_SVGP):
         if full_cov or full_output_cov:
             raise NotImplementedError("full covariances are not on the E-step hot path")
         Xnew = self._as_device(Xnew)
-        for dense in (False, True):
-            ops = self._site_operands(whiten_jitter=1e-9, dense_moments=dense)
-            st = self._get_engine().run(Xnew, None, ops["Z"], self.kernel, moment_Tm=ops["moment_Tm"],
-                                        moment_mode=ops["moment_mode"], gamma=ops["gamma"], whiten_Linv=ops["Linv9"],
-                                        want_moments=True)
-            if self._check_step(ops, st.nonpos):
-                break
+        ops = self._site_operands(whiten_jitter=1e-9)
+        st = self._get_engine().run(Xnew, None, ops["Z"], self.kernel, moment_Tm=ops["moment_Tm"],
+                                    moment_mode=ops["moment_mode"], gamma=ops["gamma"], whiten_T=ops["Uinv9"],
+                                    whiten_mode=ops["whiten_mode"], want_moments=True)
+        self._check_step(ops, st.nonpos)
         return st.mean, st.var
 
     def new_predict_f(self, Xnew, full_cov=False, full_output_cov=False):
@@ -305,7 +287,7 @@ class t_SVGP(base_SVGP):
             raise NotImplementedError("full covariances are not on the E-step hot path")
         ops = self._site_operands()
         st = self._get_engine().run(self._as_device(Xnew), None, ops["Z"], self.kernel, moment_Tm=ops["D"],
-                                    moment_mode=B.TRI_DENSE, gamma=ops["beta"], want_moments=True)
+                                    moment_mode=ops["moment_mode"], gamma=ops["beta"], want_moments=True)
         self._check_step(ops, st.nonpos)
         return st.mean, st.var
 
@@ -323,9 +305,9 @@ class t_SVGP(base_SVGP):
         With more than one rank ``data`` is this rank's row shard and the sum is all-reduced."""
         X, Y = data
         ops = self._site_operands()
-        kl = kl_from_dense_site(ops["K6"], self.lambda_1.value, ops["D"], ops["chol_W"], ops["beta"])
+        kl = kl_from_dense_site(ops["K6"], self.lambda_1.value, ops["D"], ops["U_W"], ops["beta"])
         st = self._get_engine().run(self._as_device(X), self._as_device(Y), ops["Z"], self.kernel,
-                                    moment_Tm=ops["D"], moment_mode=B.TRI_DENSE, gamma=ops["beta"],
+                                    moment_Tm=ops["D"], moment_mode=ops["moment_mode"], gamma=ops["beta"],
                                     lik_id=self.likelihood.lik_id, lik_param=self.likelihood.lik_param)
         packed = D_.pack_stats(st, with_sites=False)
         if self._reduce():
@@ -345,17 +327,14 @@ class t_SVGP(base_SVGP):
         X, Y = self._as_device(data[0]), self._as_device(data[1])
         old_l1, old_L = self.lambda_1.value, self.lambda_2_sqrt.value
         direct = self._use_direct(jitter)
-        # (projection route, dense moments?) in the order they are tried; everything after the first is a fallback
-        attempts = [(direct, False), (direct, True)] + ([(False, False), (False, True)] if direct else [])
-        i = 0
-        while i < len(attempts):
-            use_direct, dense = attempts[i]
+        for use_direct in ((True, False) if direct else (False,)):  # the whitened route is the fallback of the direct one
             warm_key = self._warm_key(X, jitter)
-            ops = self._site_operands(whiten_jitter=jitter, dense_moments=dense, warm_key=warm_key, direct=use_direct)
+            ops = self._site_operands(whiten_jitter=jitter, warm_key=warm_key, direct=use_direct)
             st = self._get_engine().run(X, Y, ops["Z"], self.kernel, moment_Tm=ops["moment_Tm"],
                                         moment_mode=ops["moment_mode"], gamma=ops["gamma"],
                                         lik_id=self.likelihood.lik_id, lik_param=self.likelihood.lik_param,
-                                        whiten_Linv=ops["Linv9"], sites=True, b_tag=warm_key)
+                                        whiten_T=ops["Uinv9"], whiten_mode=ops["whiten_mode"], sites=True,
+                                        b_tag=warm_key)
             try:
                 verdict = self._apply_site_update(st, ops, lr, jitter, soft_final=use_direct)
             except FloatingPointError:
@@ -364,40 +343,37 @@ class t_SVGP(base_SVGP):
                 raise
             if verdict is True:
                 return
+            # "whiten": the direct projection lost the definiteness of -2 lambda_2 + jitter I (its error is
+            # ~cond(K_uu)^2 eps of |G1|, the jitter is absolute): redo with the whitened route and stay there until
+            # the parameters change
             self.lambda_1.assign(old_l1)
             self.sites.assign_lambda_2_sqrt(old_L)
-            if verdict == "whiten":
-                # the direct projection lost the definiteness of -2 lambda_2 + jitter I (its error is ~cond(K_uu)^2 eps
-                # of |G1|, the jitter is absolute): redo with the whitened route and stay there until parameters change
-                if self._cond_cache is not None:
-                    self._cond_cache = (self._cond_cache[0], float("inf"))
-                i = 2
-            else:
-                i += 1
+            if self._cond_cache is not None:
+                self._cond_cache = (self._cond_cache[0], float("inf"))
         raise FloatingPointError("Cholesky decomposition was not successful (matrix not positive definite)")
 
     def _apply_site_update(self, st, ops, lr, jitter, soft_final=False):
         """All-reduce of the packed accumulators (RCCL) + the replicated M x M epilogue (tsvgp.py:278-303).
-        Returns False if the step has to be redone with the dense moments product."""
+        Returns ``_check_step``'s verdict."""
         P, M = self.num_latent_gps, self.num_inducing
         packed = D_.pack_stats(st, with_sites=True)
         if self._reduce():
             D_.all_reduce_sum(packed)
         acc2, acc1, _, nonpos, rows = D_.unpack_stats(packed, P, M, True)
 
-        Linv9, Kzz, beta = ops["Linv9"], ops["Kzz"], ops["beta"]
-        if Linv9 is None:
+        Uinv9, Kzz, beta = ops["Uinv9"], ops["Kzz"], ops["beta"]
+        if Uinv9 is None:
             # direct projection: acc2 = sum g1 k k^T, acc1 = sum g0 k  ->  G1 = K9^-1 acc2 K9^-1, G0 = K9^-1 acc1
             # (two triangular solves per application: torch.cholesky_solve returned wrong values for small batched
             # right-hand sides on this ROCm build -- tools/check_cholesky_solve.py, 188 of 300 calls at M=12, P=2)
-            L9 = ops["L9"]
-            G1 = chol_solve(L9, chol_solve(L9, acc2).transpose(-1, -2))
-            G0 = chol_solve(L9, acc1.transpose(-1, -2))  # [M, P]
+            U9 = ops["U9"]
+            G1 = chol_solve_upper(U9, chol_solve_upper(U9, acc2).transpose(-1, -2))
+            G0 = chol_solve_upper(U9, acc1.transpose(-1, -2))  # [M, P]
         else:
-            # G1 = L9^-T acc2 L9^-1,  G0 = L9^-T acc1   (tsvgp.py:279-280 in whitened coordinates)
-            Linv9t = Linv9.transpose(-1, -2)
-            G1 = Linv9t @ acc2 @ Linv9
-            G0 = Linv9t @ acc1.transpose(-1, -2)  # [M, P]
+            # G1 = U9^-T acc2 U9^-1,  G0 = U9^-T acc1   (tsvgp.py:279-280 in whitened coordinates)
+            Uinv9t = Uinv9.transpose(-1, -2)
+            G1 = Uinv9t @ acc2 @ Uinv9
+            G0 = Uinv9t @ acc1.transpose(-1, -2)  # [M, P]
         G1 = 0.5 * (G1 + G1.transpose(-1, -2))
         meanZ = Kzz @ beta  # predict_f(Z) mean, tsvgp.py:249-254
         grad_mu = gradient_transformation_mean_var_to_expectation(meanZ, [G0, G1])  # tsvgp.py:284

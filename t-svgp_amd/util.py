@@ -32,10 +32,17 @@ def cholesky_deferred(a: torch.Tensor, infos: list, potrf=None) -> torch.Tensor:
     return L
 
 
-def chol_solve(L: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
-    """(L L^T)^-1 b by two triangular solves (``tf.linalg.cholesky_solve(L, b)``).  L [M, M], b [..., M, K]."""
-    x = torch.linalg.solve_triangular(L, b, upper=False)
-    return torch.linalg.solve_triangular(L.transpose(-1, -2), x, upper=True)
+def rev_cholesky(a: torch.Tensor, infos: list, potrf=None) -> torch.Tensor:
+    """Upper-form Cholesky a = U U^T, U upper triangular: the lower factor of the index-reversed matrix, reversed back
+    (J a J = C C^T  =>  a = (J C J)(J C J)^T).  Status handling as in ``cholesky_deferred``."""
+    C = cholesky_deferred(torch.flip(a, (-2, -1)), infos, potrf)
+    return torch.flip(C, (-2, -1))
+
+
+def chol_solve_upper(U: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """(U U^T)^-1 b by two triangular solves.  U [M, M] upper, b [..., M, K]."""
+    x = torch.linalg.solve_triangular(U, b, upper=True)
+    return torch.linalg.solve_triangular(U.transpose(-1, -2), x, upper=False)
 
 
 def _check_site_shapes(K, lambda_1, lambda_2_sqrt, who):

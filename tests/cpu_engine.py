@@ -17,14 +17,15 @@ class NumpyShardEngine:
         k = O.SquaredExponential(variance=float(kernel.variance.value), lengthscales=kernel.lengthscales.numpy())
         return torch.as_tensor(k.K(Z.cpu().numpy()))
 
-    def run(self, X, Y, Z, kernel, *, moment_Tm, moment_mode, gamma, lik_id=0, lik_param=0.0, whiten_Linv=None,
-            sites=False, want_moments=False, want_grads=False, b_tag=None):
+    def run(self, X, Y, Z, kernel, *, moment_Tm, moment_mode, gamma, lik_id=0, lik_param=0.0, whiten_T=None,
+            whiten_mode=1, sites=False, want_moments=False, want_grads=False, b_tag=None):
         k = O.SquaredExponential(variance=float(kernel.variance.value), lengthscales=kernel.lengthscales.numpy())
         Xn, Zn = X.cpu().numpy(), Z.cpu().numpy()
         A = k.K(Xn, Zn)
-        if whiten_Linv is not None:
-            A = A @ whiten_Linv.cpu().numpy().T
-        Tm = moment_Tm.cpu().numpy()
+        tri = {0: np.tril, 1: np.triu, 2: lambda a: a}  # the kernels only read the triangle the mode names
+        if whiten_T is not None:
+            A = A @ tri[whiten_mode](whiten_T.cpu().numpy()).T
+        Tm = tri[moment_mode](moment_Tm.cpu().numpy())
         C = np.einsum("nj,pij->pni", A, Tm)
         q = np.sum(C * C, axis=-1).T
         mean = A @ gamma.cpu().numpy()

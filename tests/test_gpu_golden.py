@@ -27,13 +27,13 @@ def test_hip_matches_fixture(path):
             ops = model._site_operands(whiten_jitter=1e-9)
             st = model._get_engine().run(model._as_device(X), model._as_device(Y), ops["Z"], model.kernel,
                                          moment_Tm=ops["moment_Tm"], moment_mode=ops["moment_mode"], gamma=ops["gamma"],
-                                         lik_id=lik_id, lik_param=model.likelihood.lik_param, whiten_Linv=ops["Linv9"],
+                                         lik_id=lik_id, lik_param=model.likelihood.lik_param, whiten_T=ops["Uinv9"], whiten_mode=ops["whiten_mode"],
                                          sites=True, want_moments=True, want_grads=True)
             for key, val in (("mean", st.mean), ("var", st.var), ("g0", st.g0), ("g1", st.g1)):
                 assert relerr(val.cpu().numpy(), fx[f"s{step}_{key}"]) < 1e-8, (step, key)
-            L9 = ops["L9"].cpu().numpy()
-            G1 = np.stack([np.linalg.solve(L9.T, np.linalg.solve(L9.T, a).T).T for a in st.acc2.cpu().numpy()])
-            G0 = np.linalg.solve(L9.T, st.acc1.cpu().numpy().T)
+            U9 = ops["U9"].cpu().numpy()
+            G1 = np.stack([np.linalg.solve(U9.T, np.linalg.solve(U9.T, a).T).T for a in st.acc2.cpu().numpy()])
+            G0 = np.linalg.solve(U9.T, st.acc1.cpu().numpy().T)
             assert relerr(G1, fx[f"s{step}_G1"]) < 1e-8 and relerr(G0, fx[f"s{step}_G0"]) < 1e-8
         model.natgrad_step((X, Y), lr=lr)
         if step in steps:

@@ -62,16 +62,16 @@ def test_intermediates_match_oracle_fp64():
     B = pkg()._backend
     st = hip._get_engine().run(hip._as_device(X), hip._as_device(Y), ops["Z"], hip.kernel, moment_Tm=ops["moment_Tm"],
                                moment_mode=ops["moment_mode"], gamma=ops["gamma"], lik_id=B.LIK_BERNOULLI,
-                               whiten_Linv=ops["Linv9"], sites=True, want_moments=True, want_grads=True)
+                               whiten_T=ops["Uinv9"], whiten_mode=ops["whiten_mode"], sites=True, want_moments=True, want_grads=True)
     ora.natgrad_step((X, Y), lr=0.5)  # fills ora.last with the intermediates of the same state
     last = ora.last
     assert relerr(st.mean.cpu().numpy(), last["mean"]) < 1e-8
     assert relerr(st.var.cpu().numpy(), last["var"]) < 1e-8
     assert relerr(st.g0.cpu().numpy(), last["g0"]) < 1e-8
     assert relerr(st.g1.cpu().numpy(), last["g1"]) < 1e-8
-    L9 = ops["L9"].cpu().numpy()
-    G1 = np.stack([np.linalg.solve(L9.T, np.linalg.solve(L9.T, a).T).T for a in st.acc2.cpu().numpy()])
-    G0 = np.linalg.solve(L9.T, st.acc1.cpu().numpy().T)
+    U9 = ops["U9"].cpu().numpy()
+    G1 = np.stack([np.linalg.solve(U9.T, np.linalg.solve(U9.T, a).T).T for a in st.acc2.cpu().numpy()])
+    G0 = np.linalg.solve(U9.T, st.acc1.cpu().numpy().T)
     assert relerr(G1, last["G1"]) < 1e-8
     assert relerr(G0, last["G0"]) < 1e-8
 
