@@ -1072,19 +1072,16 @@ __global__ __launch_bounds__(NTHREADS) void syrk_reduce_kernel(const T* __restri
 // Blocked Cholesky of the M x M site matrices (K_uu + jitter I, W, the moments Gram, -2 lambda_2 + jitter I):
 // replaces tf.linalg.cholesky of reference src/models/tsvgp.py:270,300 and src/util.py:377-388 on the GPU.
 // Right-looking, 128-wide block columns, three kernels per block column k:
-//   potrf_diag_kernel   one workgroup: factor the 128x128 diagonal block in LDS (left-looking, one barrier per
-//                       column), write L_kk, then invert it in place (trti2) and write inv(L_kk) to `work`
-//   chol_tile_kernel<PANEL>   A[i,k] <- A[i,k] * inv(L_kk)^T            (one workgroup per tile below the diagonal)
-//   chol_tile_kernel<UPDATE>  A[i,j] <- A[i,j] - A[i,k] * A[j,k]^T      (one workgroup per trailing lower tile)
-// The tile products reuse the MFMA chunk code of the E-step kernels.  Latency bound by design (M^3/3 flops is
+//   potrf_diag_kernel   one workgroup: factor the 128x128 diagonal block in LDS / registers (32-wide sub-blocks),
+//                       write L_kk, then assemble inv(L_kk) and write it to `work`
+//   chol_tile_kernel<PANEL>   A[i,k] <- A[i,k] * inv(L_kk)^T            (one wave per 32x32 tile below the diagonal)
+//   chol_tile_kernel<UPDATE>  A[i,j] <- A[i,j] - A[i,k] * A[j,k]^T      (one wave per trailing lower 32x32 tile)  Latency bound by design (M^3/3 flops is
 // microseconds of MFMA time): the critical path is 8 diagonal blocks, each ~M/8 dependent column steps.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int CH_NB = 128;
-constexpr int CH_LD = CH_NB + 8;  // LDS row stride: with 8 threads per row a 32-lane pass (4 rows x 8 parts) covers all 64 banks once
-
-constexpr int CH_THREADS = 1024;  // 8 threads per row of the diagonal block
-constexpr int CH_TPR = 8;
-constexpr int CH_PW = 4;  // columns finished per barrier pair in the factorisation
+constexpr int CH_SB = 32;          // sub-block factored in one wave's registers
+constexpr int CH_LD = CH_NB + 1;   // odd LDS row stride: one-lane-per-row column sweeps touch 32 different banks
+constexpr int CH_THREADS = 512;    // 8 waves
 
 // 1/sqrt(x) to fp64 accuracy: hardware estimate (v_rsq_f64) + two Newton-Raphson steps; NaN for x <= 0 like sqrt.
 __device__ __forceinline__ double rsqrt_nr(double x) {
@@ -1095,241 +1092,371 @@ __device__ __forceinline__ double rsqrt_nr(double x) {
     return (x > 0.0) ? y : __builtin_nan("");
 }
 
-// Diagonal block: factor (left-looking, FOUR columns per barrier pair: every thread factors the 4x4 pivot block
-// redundantly in registers and solves its own row against it) and invert (barrier-free: row r of inv(L) only needs the
-// original columns of L and its own earlier entries, which are parked transposed in the unused upper triangle).
+// value of `v` in lane `src` (compile-time lane), as a wave-uniform double
+__device__ __forceinline__ double readlane_d(double v, int src) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+
+// One wave factors the 32x32 diagonal sub-block at (s0, s0) of S in registers: lane r (mod 32) owns row r.  Four
+// columns per step: the 4x4 pivot block is broadcast with v_readlane and factored redundantly by every lane
+// (reciprocal square roots by v_rsq_f64 + two Newton steps: no f64 divide / sqrt sequences on the critical path),
+// each lane solves its own row against it, and the rank-4 update of the remaining columns takes its second factor
+// from a small LDS scratch (wave-uniform reads).  No workgroup barriers inside.
+__device__ __forceinline__ void chol_factor32(double* __restrict__ S, double* __restrict__ dinv, double* __restrict__ xs,
+                                              int s0, int lane, int* fail, int col_base) {
+    const int r = lane & 31;
+    double* const row = S + (s0 + r) * CH_LD + s0;
+    double a[CH_SB];
+#pragma unroll
+    for (int c = 0; c < CH_SB; ++c) a[c] = row[c];
+    int bad = 0;
+#pragma unroll
+    for (int j0 = 0; j0 < CH_SB; j0 += 4) {
+        const double p00 = readlane_d(a[j0], j0), p10 = readlane_d(a[j0], j0 + 1), p20 = readlane_d(a[j0], j0 + 2),
+                     p30 = readlane_d(a[j0], j0 + 3);
+        const double p11 = readlane_d(a[j0 + 1], j0 + 1), p21 = readlane_d(a[j0 + 1], j0 + 2),
+                     p31 = readlane_d(a[j0 + 1], j0 + 3);
+        const double p22 = readlane_d(a[j0 + 2], j0 + 2), p32 = readlane_d(a[j0 + 2], j0 + 3);
+        const double p33 = readlane_d(a[j0 + 3], j0 + 3);
+        const double i0 = rsqrt_nr(p00);
+        const double l10 = p10 * i0, l20 = p20 * i0, l30 = p30 * i0;
+        const double d1 = p11 - l10 * l10;
+        const double i1 = rsqrt_nr(d1);
+        const double l21 = (p21 - l20 * l10) * i1, l31 = (p31 - l30 * l10) * i1;
+        const double d2 = p22 - l20 * l20 - l21 * l21;
+        const double i2 = rsqrt_nr(d2);
+        const double l32 = (p32 - l30 * l20 - l31 * l21) * i2;
+        const double d3 = p33 - l30 * l30 - l31 * l31 - l32 * l32;
+        const double i3 = rsqrt_nr(d3);
+        if (bad == 0) bad = !(p00 > 0.0) ? j0 + 1 : !(d1 > 0.0) ? j0 + 2 : !(d2 > 0.0) ? j0 + 3 : !(d3 > 0.0) ? j0 + 4 : 0;
+        // own row against the pivot block; for the pivot rows this reproduces the factor's rows
+        // (x_q = d_q * rsqrt(d_q) = sqrt(d_q) on the diagonal)
+        const double x0 = a[j0] * i0;
+        const double x1 = (a[j0 + 1] - x0 * l10) * i1;
+        const double x2 = (a[j0 + 2] - x0 * l20 - x1 * l21) * i2;
+        const double x3 = (a[j0 + 3] - x0 * l30 - x1 * l31 - x2 * l32) * i3;
+        a[j0] = x0;
+        a[j0 + 1] = x1;
+        a[j0 + 2] = x2;
+        a[j0 + 3] = x3;
+        if (lane == 0) {
+            dinv[s0 + j0] = i0;
+            dinv[s0 + j0 + 1] = i1;
+            dinv[s0 + j0 + 2] = i2;
+            dinv[s0 + j0 + 3] = i3;
+        }
+        if (j0 + 4 < CH_SB) {
+            // the four new columns go through a 1 KB LDS scratch: row c's entries come back as one wave-uniform 32-byte
+            // read per column of the update (two LDS reads instead of eight v_readlane per column)
+            if (lane < CH_SB) *reinterpret_cast<v4d*>(xs + 4 * r) = v4d{x0, x1, x2, x3};
+            __builtin_amdgcn_wave_barrier();  // one wave, in-order LDS: the reads below see the writes
+#pragma unroll
+            for (int c = j0 + 4; c < CH_SB; ++c) {
+                const v4d y = *reinterpret_cast<const v4d*>(xs + 4 * c);
+                double v = a[c];
+                v = fma(-x0, y[0], v);
+                v = fma(-x1, y[1], v);
+                v = fma(-x2, y[2], v);
+                v = fma(-x3, y[3], v);
+                // pin the update here: otherwise the optimiser sinks the FMAs towards the final stores and the operands
+                // of the whole step stay live
+                asm volatile("" : "+v"(v));
+                a[c] = v;
+            }
+            __builtin_amdgcn_wave_barrier();  // the next step's writes come after these reads
+        }
+    }
+    if (lane < CH_SB) {
+#pragma unroll
+        for (int c = 0; c < CH_SB; ++c)
+            if (c <= r) row[c] = a[c];
+    }
+    if (lane == 0 && bad != 0 && *fail == 0) *fail = col_base + s0 + bad;  // first non-positive pivot, 1-based
+}
+
+// Row `gr` (below the sub-block) against the finished L_ss: x = a L_ss^-T by forward substitution, one lane per row;
+// the entries of L_ss are wave-uniform LDS reads (broadcast).
+__device__ __forceinline__ void chol_subst32(double* __restrict__ S, const double* __restrict__ dinv, int s0, int gr) {
+    asm volatile("" : "+v"(gr));  // nothing derived from the lane id is hoisted out of the caller's sub-block loop
+    double* const row = S + gr * CH_LD + s0;
+    const double* const Ls = S + s0 * CH_LD + s0;
+    double a[CH_SB];
+#pragma unroll
+    for (int c = 0; c < CH_SB; ++c) a[c] = row[c];
+    // row c: x[c] = (a[c] - sum_{kk<c} x[kk] L[c][kk]) / L[c][c]; four partial sums keep the FMA chain short, and the
+    // entries of row c of L_ss are contiguous (wide wave-uniform LDS reads)
+#pragma unroll
+    for (int c = 0; c < CH_SB; ++c) {
+        double v[4] = {a[c], 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < c; ++kk) v[kk & 3] = fma(-a[kk], Ls[c * CH_LD + kk], v[kk & 3]);
+        double x = ((v[0] + v[1]) + (v[2] + v[3])) * dinv[s0 + c];
+        asm volatile("" : "+v"(x));  // pins the row here (see chol_factor32): bounds the L_ss entries in flight
+        a[c] = x;
+    }
+#pragma unroll
+    for (int c = 0; c < CH_SB; ++c) row[c] = a[c];
+}
+
+// inv(L_ss) by columns: lane j (mod 32) solves L_ss x = e_j with wave-uniform reads of L_ss; X[r][j] is parked
+// transposed in the unused strict upper triangle of the sub-block (S[s0 + j][s0 + r], r > j); the diagonal is dinv.
+__device__ __forceinline__ void chol_inv32(double* __restrict__ S, const double* __restrict__ dinv, int s0, int lane) {
+    asm volatile("" : "+v"(lane));  // as in chol_subst32
+    const int j = lane & 31;
+    const double* const Ls = S + s0 * CH_LD + s0;
+    double x[CH_SB];
+#pragma unroll
+    for (int r = 0; r < CH_SB; ++r) {
+        double v[4] = {(r == j) ? 1.0 : 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < r; ++kk) v[kk & 3] = fma(-Ls[r * CH_LD + kk], x[kk], v[kk & 3]);
+        double xr = ((v[0] + v[1]) + (v[2] + v[3])) * dinv[s0 + r];
+        asm volatile("" : "+v"(xr));
+        x[r] = xr;
+    }
+    if (lane < CH_SB) {
+        double* const prow = S + (s0 + j) * CH_LD + s0;
+#pragma unroll
+        for (int r = 1; r < CH_SB; ++r)
+            if (r > j) prow[r] = x[r];
+    }
+}
+
+// X[r][c] of the inverse under construction: diagonal in dinv, strict lower part parked transposed above the diagonal
+__device__ __forceinline__ double chol_xval(const double* __restrict__ S, const double* __restrict__ dinv, int r, int c) {
+    const double* p = (r > c) ? S + c * CH_LD + r : dinv + r;  // one LDS read either way
+    const double v = *p;
+    return (r >= c) ? v : 0.0;
+}
+
+// Off-diagonal part of the inverse by 2x2 recursion,  X_lo = -X_hh (L_hl X_ll),  for the block with rows [h0, h0+n)
+// and columns [l0, l0+n), n = 16 NT.  One wave per 16-column tile J of the result: T(:, J) = L_hl X_ll(:, J) stays in
+// the accumulators and is fed straight back as the B operand of the second product (for v_mfma_f64_16x16x4 the C
+// layout of a 16x16 tile IS the B-operand layout of its four k-steps), so the two stages need no exchange.
+template <int NT>
+__device__ __forceinline__ void chol_inv_offdiag(double* __restrict__ S, const double* __restrict__ dinv, int h0, int l0,
+                                                 int J, int lane) {
+    const int li = lane & 15, lk = lane >> 4;
+    v4d T[NT];
+#pragma unroll
+    for (int I = 0; I < NT; ++I) T[I] = v4d{0, 0, 0, 0};
+    for (int kk = 4 * J; kk < 4 * NT; ++kk) {  // X_ll is lower triangular: k-steps below column tile J contribute zeros
+        const double bq = chol_xval(S, dinv, l0 + 4 * kk + lk, l0 + 16 * J + li);
+#pragma unroll
+        for (int I = 0; I < NT; ++I)
+            T[I] = Mfma<double>::run(S[(h0 + 16 * I + li) * CH_LD + l0 + 4 * kk + lk], bq, T[I]);
+    }
+    v4d O[NT];
+#pragma unroll
+    for (int I = 0; I < NT; ++I) {
+        O[I] = v4d{0, 0, 0, 0};
+#pragma unroll
+        for (int Kt = 0; Kt < NT; ++Kt) {
+            if (Kt > I) continue;  // X_hh is lower triangular
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                O[I] = Mfma<double>::run(-chol_xval(S, dinv, h0 + 16 * I + li, h0 + 16 * Kt + 4 * q + lk), T[Kt][q], O[I]);
+        }
+    }
+#pragma unroll
+    for (int I = 0; I < NT; ++I)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)  // X[h0 + i][l0 + j] parked at S[l0 + j][h0 + i]
+            S[(l0 + 16 * J + li) * CH_LD + h0 + 16 * I + lk + 4 * r] = O[I][r];
+}
+
+// Diagonal block: right-looking over four 32-wide sub-blocks, everything in LDS / registers:
+//   (1) wave 0 factors the 32x32 diagonal sub-block in registers (chol_factor32);
+//   (2) the rows below solve against it, one lane per row (chol_subst32); wave 7 meanwhile inverts L_ss (chol_inv32);
+//   (3) the trailing part of the block is updated with 16x16 MFMA tiles, A_ij -= L_is L_js^T, by all waves.
+// Then L_kk is written out and inv(L_kk) is assembled from the four sub-block inverses by two levels of the 2x2
+// recursion (chol_inv_offdiag) and written to `work` for the panel kernel.
 __global__ __launch_bounds__(CH_THREADS) void potrf_diag_kernel(double* __restrict__ A, int lda, int64_t stride, int k,
                                                                 double* __restrict__ work, int* __restrict__ info,
                                                                 int need_inverse) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    double* S = reinterpret_cast<double*>(smem_raw);  // [CH_NB][CH_LD]; lower: L, strict upper: inv(L)^T (phase B)
+    double* S = reinterpret_cast<double*>(smem_raw);  // [CH_NB][CH_LD]; lower: A -> L, strict upper: inv(L)^T
     __shared__ int fail;
     __shared__ double dinv[CH_NB];
-    __shared__ double Vb[2 * CH_PW * CH_NB];  // unscaled Schur values of the current four columns, [parity][q][row]
-    const int t = threadIdx.x, b = blockIdx.x;
+    __shared__ __attribute__((aligned(32))) double xs[4 * CH_SB];
+    const int t = threadIdx.x, lane = t & 63, b = blockIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     double* Ab = A + (size_t)b * stride + (size_t)k * CH_NB * lda + (size_t)k * CH_NB;
 #ifdef TSVGP_DIAG_POTRF
-    unsigned long long stamp[6];
-#define PSTAMP(i) stamp[i] = __builtin_amdgcn_s_memtime();
+    unsigned long long stamp[16];
+    int nstamp = 0;
+#define PSTAMP() stamp[nstamp++] = __builtin_amdgcn_s_memtime();
 #else
-#define PSTAMP(i)
+#define PSTAMP()
 #endif
-    PSTAMP(0)
+    PSTAMP()
     if (t == 0) fail = 0;
-    for (int idx = t; idx < CH_NB * CH_NB; idx += CH_THREADS) {
-        const int r = idx >> 7, c = idx & 127;
-        S[r * CH_LD + c] = (c <= r) ? Ab[(size_t)r * lda + c] : 0.0;
+    // 16-byte loads, eight in flight per thread; the strict upper triangle is read and dropped
+#pragma unroll
+    for (int it0 = 0; it0 < CH_NB * CH_NB / 2 / CH_THREADS; it0 += 8) {
+        v2d v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = t + (it0 + u) * CH_THREADS, r = idx >> 6, c = (idx & 63) * 2;
+            v[u] = *reinterpret_cast<const v2d*>(Ab + (size_t)r * lda + c);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = t + (it0 + u) * CH_THREADS, r = idx >> 6, c = (idx & 63) * 2;
+            S[r * CH_LD + c] = (c <= r) ? v[u][0] : 0.0;
+            S[r * CH_LD + c + 1] = (c + 1 <= r) ? v[u][1] : 0.0;
+        }
     }
     __syncthreads();
-    PSTAMP(1)
-    const int row = t >> 3, part = t & 7;
-    double* const Sr = S + row * CH_LD;
+    PSTAMP()
 
-    // ---------------- phase A: Cholesky, 4 columns per step ----------------
-    // Per step: (1) every row forms its four Schur values against the finished columns (loads issued in one batch,
-    // 8 threads per row) and parks them in Vb; (2) barrier; (3) every thread factors the 4x4 pivot block from Vb
-    // redundantly (reciprocal square roots by v_rsq_f64 + two Newton steps: no f64 divide / sqrt sequences on the
-    // critical path) and part 0 solves its own row against it into S; (4) barrier.
-    for (int j0 = 0; j0 < CH_NB; j0 += CH_PW) {
-        double* Vq = Vb + ((j0 / CH_PW) & 1) * (CH_PW * CH_NB);  // double buffered by step parity
-        if (row >= j0) {
-            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-            const double* p0 = S + j0 * CH_LD;
-            const int nit = (j0 + CH_TPR - 1 - part) / CH_TPR;  // number of c = part + 8 i < j0 for this thread
-            // groups of four terms: 20 LDS reads issued back to back, then 16 FMAs (tail terms clamped and zero-weighted)
-            for (int i0 = 0; i0 < nit; i0 += 4) {
-                double xs[4], q0[4], q1[4], q2[4], q3[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int i = (i0 + u < nit) ? i0 + u : nit - 1;
-                    const int c = part + CH_TPR * i;
-                    xs[u] = Sr[c];
-                    q0[u] = p0[c];
-                    q1[u] = p0[CH_LD + c];
-                    q2[u] = p0[2 * CH_LD + c];
-                    q3[u] = p0[3 * CH_LD + c];
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const double x = (i0 + u < nit) ? xs[u] : 0.0;
-                    a0 += x * q0[u];
-                    a1 += x * q1[u];
-                    a2 += x * q2[u];
-                    a3 += x * q3[u];
-                }
-            }
-#pragma unroll
-            for (int o = 1; o < CH_TPR; o <<= 1) {
-                a0 += __shfl_xor(a0, o);
-                a1 += __shfl_xor(a1, o);
-                a2 += __shfl_xor(a2, o);
-                a3 += __shfl_xor(a3, o);
-            }
-            if (part < CH_PW) {
-                const double av = part == 0 ? a0 : part == 1 ? a1 : part == 2 ? a2 : a3;
-                Vq[part * CH_NB + row] = (j0 + part <= row) ? Sr[j0 + part] - av : 0.0;
-            }
-        }
+    for (int s0 = 0; s0 < CH_NB; s0 += CH_SB) {
+        if (w == 0) chol_factor32(S, dinv, xs, s0, lane, &fail, k * CH_NB);
         __syncthreads();
-        if (row >= j0) {
-            // the 4x4 pivot block (rows j0..j0+3 of Vq), factored redundantly by every thread
-            const double p00 = Vq[j0];
-            const double p10 = Vq[j0 + 1], p11 = Vq[CH_NB + j0 + 1];
-            const double p20 = Vq[j0 + 2], p21 = Vq[CH_NB + j0 + 2], p22 = Vq[2 * CH_NB + j0 + 2];
-            const double p30 = Vq[j0 + 3], p31 = Vq[CH_NB + j0 + 3], p32 = Vq[2 * CH_NB + j0 + 3],
-                         p33 = Vq[3 * CH_NB + j0 + 3];
-            const double v0 = Vq[row], v1 = Vq[CH_NB + row], v2 = Vq[2 * CH_NB + row], v3 = Vq[3 * CH_NB + row];
-            const double i0 = rsqrt_nr(p00);
-            const double l10 = p10 * i0, l20 = p20 * i0, l30 = p30 * i0;
-            const double d1 = p11 - l10 * l10;
-            const double i1 = rsqrt_nr(d1);
-            const double l21 = (p21 - l20 * l10) * i1, l31 = (p31 - l30 * l10) * i1;
-            const double d2 = p22 - l20 * l20 - l21 * l21;
-            const double i2 = rsqrt_nr(d2);
-            const double l32 = (p32 - l30 * l20 - l31 * l21) * i2;
-            const double d3 = p33 - l30 * l30 - l31 * l31 - l32 * l32;
-            const double i3 = rsqrt_nr(d3);
-            if (t == j0 * CH_TPR && fail == 0) {  // one thread reports the first non-positive pivot
-                int bad = !(p00 > 0.0) ? 1 : !(d1 > 0.0) ? 2 : !(d2 > 0.0) ? 3 : !(d3 > 0.0) ? 4 : 0;
-                if (bad) fail = k * CH_NB + j0 + bad;
-            }
-            if (part == 0) {
-                // own row against the pivot block; for the pivot rows this reproduces the factor's rows
-                // (x_q = d_q * rsqrt(d_q) = sqrt(d_q) on the diagonal)
-                const double x0 = v0 * i0;
-                const double x1 = (v1 - x0 * l10) * i1;
-                const double x2 = (v2 - x0 * l20 - x1 * l21) * i2;
-                const double x3 = (v3 - x0 * l30 - x1 * l31 - x2 * l32) * i3;
-                Sr[j0] = x0;
-                if (row >= j0 + 1) Sr[j0 + 1] = x1;
-                if (row >= j0 + 2) Sr[j0 + 2] = x2;
-                if (row >= j0 + 3) Sr[j0 + 3] = x3;
-            }
+        PSTAMP()
+        const int nbelow = CH_NB - s0 - CH_SB;
+        if (t < nbelow)
+            chol_subst32(S, dinv, s0, s0 + CH_SB + t);
+        else if (w == 7 && need_inverse)
+            chol_inv32(S, dinv, s0, lane);
+        __syncthreads();
+        PSTAMP()
+        // trailing update on the lower 16x16 tiles of rows/columns [s0 + 32, 128)
+        const int n16 = nbelow / 16, ntile = n16 * (n16 + 1) / 2;
+        for (int ti = w; ti < ntile; ti += CH_THREADS / 64) {
+            int I = 0;
+            while ((I + 1) * (I + 2) / 2 <= ti) ++I;
+            const int J = ti - I * (I + 1) / 2;
+            const int i0 = s0 + CH_SB + 16 * I, j0 = s0 + CH_SB + 16 * J;
+            int lane_ = lane;
+            asm volatile("" : "+v"(lane_));
+            const int li = lane_ & 15, lk = lane_ >> 4;
+            v4d acc;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = S[(i0 + lk + 4 * r) * CH_LD + j0 + li];
+#pragma unroll
+            for (int kk = 0; kk < CH_SB / 4; ++kk)
+                acc = Mfma<double>::run(-S[(i0 + li) * CH_LD + s0 + 4 * kk + lk], S[(j0 + li) * CH_LD + s0 + 4 * kk + lk],
+                                        acc);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (j0 + li <= i0 + lk + 4 * r) S[(i0 + lk + 4 * r) * CH_LD + j0 + li] = acc[r];
         }
-        __syncthreads();  // the next step's Schur values read the four new columns
+        if (nbelow > 0) __syncthreads();
+        PSTAMP()
     }
-    PSTAMP(2)
-    // L_kk out (zeros above the diagonal), reciprocal diagonal for phase B
-    for (int idx = t; idx < CH_NB * CH_NB; idx += CH_THREADS) {
-        const int r = idx >> 7, c = idx & 127;
-        Ab[(size_t)r * lda + c] = (c <= r) ? S[r * CH_LD + c] : 0.0;
-    }
-    if (t < CH_NB) dinv[t] = 1.0 / S[t * CH_LD + t];
-    if (t == 0 && fail != 0 && info[b] == 0) info[b] = fail;
-    if (!need_inverse) return;  // the last block column has no panel below it
-    __syncthreads();
 
-    PSTAMP(3)
-    // ---------------- phase B: X = inv(L), no workgroup barriers ----------------
-    // X[row][j] = -dinv[j] * ( dinv[row] * L[row][j] + sum_{c=j+1}^{row-1} X[row][c] * L[c][j] ),  X[row][c] parked at S[c][row]
-    {
-        const double drow = dinv[row];
-        for (int j = row - 1; j >= 0; --j) {
-            // terms c = j + 1 + part + 8 i < row; groups of four: 8 LDS reads issued back to back, then 4 FMAs
-            const int nit = (row - j - 1 + CH_TPR - 1 - part) / CH_TPR;
-            double acc0 = 0.0, acc1 = 0.0;
-            for (int i0 = 0; i0 < nit; i0 += 4) {
-                double xa[4], xb[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int i = (i0 + u < nit) ? i0 + u : nit - 1;
-                    const int c = j + 1 + part + CH_TPR * i;
-                    xa[u] = S[c * CH_LD + row];
-                    xb[u] = S[c * CH_LD + j];
-                }
-                acc0 += xa[0] * xb[0];
-                acc1 += (i0 + 1 < nit) ? xa[1] * xb[1] : 0.0;
-                acc0 += (i0 + 2 < nit) ? xa[2] * xb[2] : 0.0;
-                acc1 += (i0 + 3 < nit) ? xa[3] * xb[3] : 0.0;
-            }
-            double acc = acc0 + acc1;
-#pragma unroll
-            for (int o = 1; o < CH_TPR; o <<= 1) acc += __shfl_xor(acc, o);
-            if (part == 0) S[j * CH_LD + row] = -dinv[j] * (drow * Sr[j] + acc);
-            __builtin_amdgcn_wave_barrier();  // the 8 threads of a row share one wave: in-order LDS makes it visible
-        }
+    // L_kk out (zeros above the diagonal)
+#pragma unroll 4
+    for (int it = 0; it < CH_NB * CH_NB / 2 / CH_THREADS; ++it) {
+        const int idx = t + it * CH_THREADS, r = idx >> 6, c = (idx & 63) * 2;
+        v2d v;
+        v[0] = (c <= r) ? S[r * CH_LD + c] : 0.0;
+        v[1] = (c + 1 <= r) ? S[r * CH_LD + c + 1] : 0.0;
+        *reinterpret_cast<v2d*>(Ab + (size_t)r * lda + c) = v;
     }
-    __syncthreads();
-    PSTAMP(4)
-    double* Wb = work + (size_t)b * CH_NB * CH_NB;
-    for (int idx = t; idx < CH_NB * CH_NB; idx += CH_THREADS) {
-        const int r = idx >> 7, c = idx & 127;
-        Wb[idx] = (c < r) ? S[c * CH_LD + r] : (c == r ? dinv[r] : 0.0);
+    if (t == 0 && fail != 0 && info[b] == 0) info[b] = fail;
+    PSTAMP()
+    if (need_inverse) {  // the last block column has no panel below it
+        // level 1: the two 64x64 diagonal blocks, X_10 = -X_11 (L_10 X_00) with 32x32 blocks; level 2: the 64x64 block
+        if (w < 4) chol_inv_offdiag<2>(S, dinv, 64 * (w >> 1) + 32, 64 * (w >> 1), w & 1, lane);
+        __syncthreads();
+        if (w < 4) chol_inv_offdiag<4>(S, dinv, 64, 0, w, lane);
+        __syncthreads();
+        PSTAMP()
+        double* Wb = work + (size_t)b * CH_NB * CH_NB;
+        for (int idx = t; idx < CH_NB * CH_NB; idx += CH_THREADS) {
+            const int r = idx >> 7, c = idx & 127;
+            Wb[idx] = chol_xval(S, dinv, r, c);
+        }
     }
 #ifdef TSVGP_DIAG_POTRF
     __syncthreads();
-    PSTAMP(5)
-    if (t == 0 && k == 0)
-        for (int i = 0; i < 6; ++i) reinterpret_cast<unsigned long long*>(Wb)[i] = stamp[i];
+    PSTAMP()
+    if (t == 0 && k == 0 && need_inverse) {
+        unsigned long long* dst = reinterpret_cast<unsigned long long*>(work + (size_t)b * CH_NB * CH_NB);
+        dst[0] = nstamp;
+        for (int i = 0; i < nstamp; ++i) dst[1 + i] = stamp[i];
+    }
 #endif
 #undef PSTAMP
 }
 
-// 128x128x128 tile products for the panel solve and the trailing update; operands with arbitrary leading dimension.
-template <int OP>  // 0: C = A * B^T (panel: B = inv(L_kk) from `work`);  1: C -= A * B^T (trailing update)
-__global__ __launch_bounds__(NTHREADS, 2) void chol_tile_kernel(double* __restrict__ Amat, int lda, int64_t stride,
-                                                                int k, int nt, const double* __restrict__ work) {
-    constexpr int RS = RowStride<double>::value;
-    __shared__ __attribute__((aligned(16))) double lds[2][2][TILE * RS];
-    typedef Mfma<double>::acc_t acc_t;
-    const int t = threadIdx.x, lane = t & 63;
-    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int srow = t >> 1, skh = t & 1;
+// Tile products for the panel solve and the trailing update, one WAVE per 32x32 output tile, K = 128, no LDS and no
+// barriers in the product: the sum over k does not care which lane group supplies which k, so lane (i = l&15, g = l>>4)
+// streams the CONTIGUOUS run k in [64h + 16g, 64h + 16g + 16) of its operand row straight from global memory / L2
+// (8 x 16-byte loads) and MFMA step kk of half h uses element kk of every lane's run, for A and B alike.
+//   OP 0 (panel):  A[i, k] <- A[i, k] * inv(L_kk)^T   one workgroup = the four 32-column tiles of a 32-row block; the
+//                  block is overwritten in place, so all four waves finish reading before any of them stores
+//   OP 1 (update): A[i, j] <- A[i, j] - A[i, k] * A[j, k]^T   over the lower 32x32 tiles of the trailing matrix
+template <int OP>
+__global__ __launch_bounds__(NTHREADS) void chol_tile_kernel(double* __restrict__ Amat, int lda, int64_t stride, int k,
+                                                             int nt, const double* __restrict__ work) {
+    const int lane = threadIdx.x & 63, li = lane & 15, g = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b = blockIdx.y;
     double* Ab = Amat + (size_t)b * stride;
+    const int nb32 = (nt - k - 1) * (CH_NB / CH_SB);
+    const int base = (k + 1) * CH_NB;  // first row / column of the trailing matrix
     int ti, tj;
+    bool active = true;
     if (OP == 0) {
-        ti = k + 1 + blockIdx.x;
-        tj = k;
+        ti = blockIdx.x;
+        tj = w;
     } else {
-        // blockIdx.x enumerates pairs (ti >= tj > k)
-        const int idx = blockIdx.x;
-        int r = 0;
-        while ((r + 1) * (r + 2) / 2 <= idx) ++r;
-        ti = k + 1 + r;
-        tj = k + 1 + (idx - r * (r + 1) / 2);
+        const int wid = blockIdx.x * (NTHREADS / 64) + w;
+        active = wid < nb32 * (nb32 + 1) / 2;
+        int r = (int)((sqrtf(8.0f * (float)wid + 1.0f) - 1.0f) * 0.5f);
+        while (r * (r + 1) / 2 > wid) --r;
+        while ((r + 1) * (r + 2) / 2 <= wid) ++r;
+        ti = r;
+        tj = wid - r * (r + 1) / 2;
     }
-    const double* Asrc = Ab + (size_t)(ti * CH_NB + srow) * lda + (size_t)k * CH_NB + skh * 8;
-    const double* Bsrc = (OP == 0) ? work + (size_t)b * CH_NB * CH_NB + (size_t)srow * CH_NB + skh * 8
-                                   : Ab + (size_t)(tj * CH_NB + srow) * lda + (size_t)k * CH_NB + skh * 8;
-    acc_t acc[2][8];
+    v4d acc[2][2];
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int n = 0; n < 8; ++n) acc[s][n] = acc_t{0, 0, 0, 0};
-    double ra[8], rb[8];
-    load8(ra, Asrc);
-    load8(rb, Bsrc);
-    store_rowk8(&lds[0][0][srow * RS + skh * 8], ra);
-    store_rowk8(&lds[0][1][srow * RS + skh * 8], rb);
-    __syncthreads();
-    int buf = 0;
-    for (int c = 0; c < CH_NB / KC; ++c) {
-        const bool has_next = (c + 1 < CH_NB / KC);
-        if (has_next) {
-            load8(ra, Asrc + (c + 1) * KC);
-            load8(rb, Bsrc + (c + 1) * KC);
+        for (int n = 0; n < 2; ++n) acc[s][n] = v4d{0, 0, 0, 0};
+    if (active) {
+        const double* Arow = Ab + (size_t)(base + CH_SB * ti + li) * lda + (size_t)k * CH_NB + 16 * g;
+        const double* Brow = (OP == 0) ? work + (size_t)b * CH_NB * CH_NB + (size_t)(CH_SB * tj + li) * CH_NB + 16 * g
+                                       : Ab + (size_t)(base + CH_SB * tj + li) * lda + (size_t)k * CH_NB + 16 * g;
+        const size_t bstep = (OP == 0) ? (size_t)16 * CH_NB : (size_t)16 * lda;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            v2d ra[2][8], rb[2][8];
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    ra[s][q] = *reinterpret_cast<const v2d*>(Arow + (size_t)16 * s * lda + 64 * h + 2 * q);
+                    rb[s][q] = *reinterpret_cast<const v2d*>(Brow + s * bstep + 64 * h + 2 * q);
+                }
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk)
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+                        acc[s][n] = Mfma<double>::run(ra[s][kk >> 1][kk & 1], rb[n][kk >> 1][kk & 1], acc[s][n]);
         }
-        mma_chunk_rowk<double, 0xFF>(acc, &lds[buf][0][0], &lds[buf][1][0], w, lane);
-        if (has_next) {
-            store_rowk8(&lds[buf ^ 1][0][srow * RS + skh * 8], ra);
-            store_rowk8(&lds[buf ^ 1][1][srow * RS + skh * 8], rb);
-        }
-        __syncthreads();
-        buf ^= 1;
     }
-    double* Cb = Ab + (size_t)(ti * CH_NB) * lda + (size_t)tj * CH_NB + (lane & 15);
+    if (OP == 0) __syncthreads();  // in place: every wave of the row block has its operands in registers
+    if (!active) return;
+    double* Cb = Ab + (size_t)(base + CH_SB * ti) * lda + (OP == 0 ? (size_t)k * CH_NB : (size_t)base) + CH_SB * tj + li;
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            double* Cr = Cb + (size_t)(row_block(w, s) * 16 + Mfma<double>::row(lane, r)) * lda;
+            double* Cr = Cb + (size_t)(16 * s + g + 4 * r) * lda;
 #pragma unroll
-            for (int n = 0; n < 8; ++n) {
+            for (int n = 0; n < 2; ++n) {
                 if (OP == 0)
-                    Cr[n * 16] = acc[s][n][r];
+                    Cr[16 * n] = acc[s][n][r];
                 else
-                    Cr[n * 16] -= acc[s][n][r];
+                    Cr[16 * n] -= acc[s][n][r];
             }
         }
 }
@@ -1538,9 +1665,10 @@ int potrf(double* A, int M, int lda, int batch, int64_t stride, int* info, doubl
                            (k + 1 < nt) ? 1 : 0);
         const int below = nt - k - 1;
         if (below > 0) {
-            hipLaunchKernelGGL(chol_tile_kernel<0>, dim3(below, batch), dim3(NTHREADS), 0, st, A, lda, stride, k, nt,
+            const int nb32 = below * (CH_NB / CH_SB), ntile = nb32 * (nb32 + 1) / 2, wpb = NTHREADS / 64;
+            hipLaunchKernelGGL(chol_tile_kernel<0>, dim3(nb32, batch), dim3(NTHREADS), 0, st, A, lda, stride, k, nt,
                                work);
-            hipLaunchKernelGGL(chol_tile_kernel<1>, dim3(below * (below + 1) / 2, batch), dim3(NTHREADS), 0, st, A,
+            hipLaunchKernelGGL(chol_tile_kernel<1>, dim3((ntile + wpb - 1) / wpb, batch), dim3(NTHREADS), 0, st, A,
                                lda, stride, k, nt, work);
         }
     }

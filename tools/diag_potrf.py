@@ -7,15 +7,21 @@ so = "/tmp/libtsvgp_diag_potrf.so"
 subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-DTSVGP_DIAG_POTRF",
                        "-I", root + "/include", root + "/t-svgp_amd/csrc/tsvgp_kernels.hip", "-o", so])
 lib = ctypes.CDLL(so)
-M = 128
+M = 256  # two block columns: the first diagonal block also builds its inverse
 A = torch.randn(M, M, dtype=torch.float64, device="cuda:0"); A = A @ A.T / M + torch.eye(M, dtype=torch.float64, device="cuda:0")
 info = torch.zeros(1, dtype=torch.int32, device="cuda:0"); work = torch.zeros(128 * 128, dtype=torch.float64, device="cuda:0")
 vp = ctypes.c_void_p
+# the stamped build overwrites the head of inv(L_00) in `work` with its stamps, so the factor itself is wrong here
 for _ in range(3):
     W = A.clone()
     assert lib.tsvgp_potrf_f64(vp(W.data_ptr()), M, M, 1, ctypes.c_int64(M * M), vp(info.data_ptr()), vp(work.data_ptr()), None) == 0
 torch.cuda.synchronize()
-st = work[:6].view(torch.int64).cpu().numpy()
-names = ["load", "phase A (factor)", "store L + dinv", "phase B (inverse)", "store inverse"]
-for i, n in enumerate(names):
-    print(f"{n:22s} {int(st[i + 1] - st[i]):8d} cycles  {(st[i + 1] - st[i]) / 2.39e3:7.1f} us")
+st = work[:20].view(torch.int64).cpu().numpy()
+n = int(st[0]); st = st[1:1 + n]
+names = ["load"]
+for s_ in range(4):
+    names += [f"s{s_}: factor 32x32", f"s{s_}: row solves + inv32", f"s{s_}: trailing MFMA update"]
+names += ["store L", "assemble inverse (2 levels)", "store inverse"]
+for i in range(n - 1):
+    print(f"{names[i] if i < len(names) else '?':32s} {int(st[i + 1] - st[i]):8d} ticks  {(st[i + 1] - st[i]) / 2.3e3:7.2f} us")
+print(f"{'total':32s} {int(st[-1] - st[0]):8d} ticks  {(st[-1] - st[0]) / 2.3e3:7.2f} us   (s_memtime ticks at ~2.3 GHz)")
