@@ -37,7 +37,6 @@ from ..base import default_device, default_float, default_jitter, to_tensor
 from ..inducing_variables import inducingpoint_wrapper
 from ..sites import DenseSites
 from ..util import (
-    chol_solve_upper,
     cholesky_deferred,
     gradient_transformation_mean_var_to_expectation,
     kl_from_dense_site,
@@ -201,30 +200,34 @@ class t_SVGP(base_SVGP):
         # independent and both latency bound (one workgroup per diagonal block): do them in ONE batched call.
         W = Id + L.transpose(-1, -2) @ (K6 @ L)
         W = 0.5 * (W + W.transpose(-1, -2))
+        # The triangular inverses are formed explicitly (ONE batched triangular solve against I) and applied as GEMMs:
+        # a rocBLAS trsm with an M x M right-hand side costs ~0.25 ms at M = 1024, a GEMM ~0.05 ms.
         if whiten_jitter is not None and warm:
-            U_W, U9 = rev_cholesky(W, infos, potrf), warm[1]["U9"]
+            U_W, U9, Uinv9 = rev_cholesky(W, infos, potrf), warm[1]["U9"], warm[1]["Uinv9"]
+            Uinv_W = torch.linalg.solve_triangular(U_W, Id, upper=True)
         elif whiten_jitter is not None:
             both = rev_cholesky(torch.cat([W, (Kzz + whiten_jitter * Id)[None]], dim=0), infos, potrf)
-            U_W, U9 = both[:-1], both[-1]
+            inv_both = torch.linalg.solve_triangular(both, Id, upper=True)
+            U_W, U9, Uinv_W, Uinv9 = both[:-1], both[-1], inv_both[:-1], inv_both[-1].triu()
         else:
-            U_W, U9 = rev_cholesky(W, infos, potrf), None
-        Dm = torch.linalg.solve_triangular(U_W, L.transpose(-1, -2), upper=True).triu()  # D = U_W^-1 L^T, [P, M, M]
-        DKl = torch.einsum("pmk,kp->pm", Dm @ K6, l1)
+            U_W, U9, Uinv9 = rev_cholesky(W, infos, potrf), None, None
+            Uinv_W = torch.linalg.solve_triangular(U_W, Id, upper=True)
+        Dm = (Uinv_W @ L.transpose(-1, -2)).triu()  # D = U_W^-1 L^T, [P, M, M], upper triangular
+        DKl = torch.einsum("pmk,kp->pm", Dm, K6 @ l1)
         beta = l1 - torch.einsum("pkm,pk->mp", Dm, DKl)  # K6^-1 m = l1 - D^T D K6 l1
-        ops = dict(Z=Z, Kzz=Kzz, K6=K6, D=Dm, U_W=U_W, beta=beta, Id=Id, infos=infos, potrf=potrf,
-                   moment_mode=B.TRI_UPPER, whiten_mode=B.TRI_UPPER)
-        if whiten_jitter is not None and direct:
+        ops = dict(Z=Z, Kzz=Kzz, K6=K6, D=Dm, U_W=U_W, beta=beta, Id=Id, infos=infos, potrf=potrf, direct=False,
+                   moment_mode=B.TRI_UPPER, whiten_mode=B.TRI_UPPER, whiten_T=None)
+        if whiten_jitter is None:
+            return ops
+        ops["U9"], ops["Uinv9"] = U9, Uinv9  # K_uu + jitter I = U9 U9^T, tsvgp.py:268-270
+        if warm_key is not None and not warm:
+            self._warm = (warm_key, dict(Kzz=Kzz, U9=U9, Uinv9=Uinv9))
+        if direct:
             # direct projection: the moments act on K_fu with D itself, the sums are mapped by K9^-1 (.) K9^-1
-            # afterwards; no N-sized whitening, no inverse of U9
-            ops["U9"], ops["Uinv9"], ops["gamma"], ops["moment_Tm"] = U9, None, beta, Dm
-            if warm_key is not None and not warm:
-                self._warm = (warm_key, dict(Kzz=Kzz, U9=U9, Uinv9=None))
-        elif whiten_jitter is not None:
-            ops["U9"] = U9  # K_uu + jitter I = U9 U9^T, tsvgp.py:268-270
-            ops["Uinv9"] = (warm[1]["Uinv9"] if (warm and warm[1]["Uinv9"] is not None)
-                            else torch.linalg.solve_triangular(U9, Id, upper=True).triu())
-            if warm_key is not None and (not warm or warm[1]["Uinv9"] is None):
-                self._warm = (warm_key, dict(Kzz=Kzz, U9=U9, Uinv9=ops["Uinv9"]))
+            # afterwards; no N-sized whitening
+            ops["direct"], ops["gamma"], ops["moment_Tm"] = True, beta, Dm
+        else:
+            ops["whiten_T"] = Uinv9  # B = K_fu U9^-T
             ops["gamma"] = U9.transpose(-1, -2) @ beta  # mean = k^T beta = b^T U9^T beta with b = U9^-1 k
             ops["moment_Tm"] = (Dm @ U9).triu()  # var = knn - |D k|^2 = knn - |T b|^2
         return ops
@@ -276,7 +279,7 @@ class t_SVGP(base_SVGP):
         Xnew = self._as_device(Xnew)
         ops = self._site_operands(whiten_jitter=1e-9)
         st = self._get_engine().run(Xnew, None, ops["Z"], self.kernel, moment_Tm=ops["moment_Tm"],
-                                    moment_mode=ops["moment_mode"], gamma=ops["gamma"], whiten_T=ops["Uinv9"],
+                                    moment_mode=ops["moment_mode"], gamma=ops["gamma"], whiten_T=ops["whiten_T"],
                                     whiten_mode=ops["whiten_mode"], want_moments=True)
         self._check_step(ops, st.nonpos)
         return st.mean, st.var
@@ -333,7 +336,7 @@ class t_SVGP(base_SVGP):
             st = self._get_engine().run(X, Y, ops["Z"], self.kernel, moment_Tm=ops["moment_Tm"],
                                         moment_mode=ops["moment_mode"], gamma=ops["gamma"],
                                         lik_id=self.likelihood.lik_id, lik_param=self.likelihood.lik_param,
-                                        whiten_T=ops["Uinv9"], whiten_mode=ops["whiten_mode"], sites=True,
+                                        whiten_T=ops["whiten_T"], whiten_mode=ops["whiten_mode"], sites=True,
                                         b_tag=warm_key)
             try:
                 verdict = self._apply_site_update(st, ops, lr, jitter, soft_final=use_direct)
@@ -362,16 +365,16 @@ class t_SVGP(base_SVGP):
         acc2, acc1, _, nonpos, rows = D_.unpack_stats(packed, P, M, True)
 
         Uinv9, Kzz, beta = ops["Uinv9"], ops["Kzz"], ops["beta"]
-        if Uinv9 is None:
+        Uinv9t = Uinv9.transpose(-1, -2)
+        if ops["direct"]:
             # direct projection: acc2 = sum g1 k k^T, acc1 = sum g0 k  ->  G1 = K9^-1 acc2 K9^-1, G0 = K9^-1 acc1
-            # (two triangular solves per application: torch.cholesky_solve returned wrong values for small batched
-            # right-hand sides on this ROCm build -- tools/check_cholesky_solve.py, 188 of 300 calls at M=12, P=2)
-            U9 = ops["U9"]
-            G1 = chol_solve_upper(U9, chol_solve_upper(U9, acc2).transpose(-1, -2))
-            G0 = chol_solve_upper(U9, acc1.transpose(-1, -2))  # [M, P]
+            # (K9^-1 = U9^-T U9^-1 applied as GEMMs; torch.cholesky_solve is not an option: it returned wrong values for
+            # small batched right-hand sides on this ROCm build -- tools/check_cholesky_solve.py)
+            K9inv = Uinv9t @ Uinv9
+            G1 = K9inv @ acc2 @ K9inv
+            G0 = K9inv @ acc1.transpose(-1, -2)  # [M, P]
         else:
             # G1 = U9^-T acc2 U9^-1,  G0 = U9^-T acc1   (tsvgp.py:279-280 in whitened coordinates)
-            Uinv9t = Uinv9.transpose(-1, -2)
             G1 = Uinv9t @ acc2 @ Uinv9
             G0 = Uinv9t @ acc1.transpose(-1, -2)  # [M, P]
         G1 = 0.5 * (G1 + G1.transpose(-1, -2))

@@ -20,7 +20,7 @@ def _stats(model, X, Y, ops):
     B = pkg()._backend
     return model._get_engine().run(X, Y, ops["Z"], model.kernel, moment_Tm=ops["moment_Tm"], moment_mode=ops["moment_mode"],
                                    gamma=ops["gamma"], lik_id=model.likelihood.lik_id, lik_param=model.likelihood.lik_param,
-                                   whiten_T=ops["Uinv9"], whiten_mode=ops["whiten_mode"], sites=True)
+                                   whiten_T=ops["whiten_T"], whiten_mode=ops["whiten_mode"], sites=True)
 
 
 @pytest.mark.parametrize("cfg", ["c2_fp64", "c3_fp32"])

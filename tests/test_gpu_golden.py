@@ -27,7 +27,7 @@ def test_hip_matches_fixture(path):
             ops = model._site_operands(whiten_jitter=1e-9)
             st = model._get_engine().run(model._as_device(X), model._as_device(Y), ops["Z"], model.kernel,
                                          moment_Tm=ops["moment_Tm"], moment_mode=ops["moment_mode"], gamma=ops["gamma"],
-                                         lik_id=lik_id, lik_param=model.likelihood.lik_param, whiten_T=ops["Uinv9"], whiten_mode=ops["whiten_mode"],
+                                         lik_id=lik_id, lik_param=model.likelihood.lik_param, whiten_T=ops["whiten_T"], whiten_mode=ops["whiten_mode"],
                                          sites=True, want_moments=True, want_grads=True)
             for key, val in (("mean", st.mean), ("var", st.var), ("g0", st.g0), ("g1", st.g1)):
                 assert relerr(val.cpu().numpy(), fx[f"s{step}_{key}"]) < 1e-8, (step, key)

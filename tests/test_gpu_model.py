@@ -62,7 +62,7 @@ def test_intermediates_match_oracle_fp64():
     B = pkg()._backend
     st = hip._get_engine().run(hip._as_device(X), hip._as_device(Y), ops["Z"], hip.kernel, moment_Tm=ops["moment_Tm"],
                                moment_mode=ops["moment_mode"], gamma=ops["gamma"], lik_id=B.LIK_BERNOULLI,
-                               whiten_T=ops["Uinv9"], whiten_mode=ops["whiten_mode"], sites=True, want_moments=True, want_grads=True)
+                               whiten_T=ops["whiten_T"], whiten_mode=ops["whiten_mode"], sites=True, want_moments=True, want_grads=True)
     ora.natgrad_step((X, Y), lr=0.5)  # fills ora.last with the intermediates of the same state
     last = ora.last
     assert relerr(st.mean.cpu().numpy(), last["mean"]) < 1e-8

@@ -19,7 +19,7 @@ for route in ("whitened", "direct", "auto"):
             ops = m._site_operands(whiten_jitter=1e-9)
             st = m._get_engine().run(m._as_device(X), m._as_device(Y), ops["Z"], m.kernel, moment_Tm=ops["moment_Tm"],
                                      moment_mode=ops["moment_mode"], gamma=ops["gamma"], lik_id=m.likelihood.lik_id,
-                                     lik_param=m.likelihood.lik_param, whiten_T=ops["Uinv9"], whiten_mode=ops["whiten_mode"], sites=True,
+                                     lik_param=m.likelihood.lik_param, whiten_T=ops["whiten_T"], whiten_mode=ops["whiten_mode"], sites=True,
                                      want_moments=True, want_grads=True)
             e_mean = rel(st.mean.cpu().numpy(), fx[f"s{step}_mean"]); e_var = rel(st.var.cpu().numpy(), fx[f"s{step}_var"])
             # sensitivity floor: oracle moments from an oracle state perturbed by 2e-16 relative noise
