@@ -111,6 +111,15 @@ int tsvgp_site_accum_f32(const float *B, const float *g0, const float *g1, doubl
  *     work: batch * 128 * 128 doubles. */
 int tsvgp_potrf_f64(double *A, int M, int lda, int batch, int64_t stride, int32_t *info, double *work, void *stream);
 
+/* (6b) The same factorisation plus the inverse factor: X[b] = inv(L[b]) (lower triangular, exact zeros above) and
+ *     Xt[b] = X[b]^T, both [batch x M x M] row-major (leading dimension M).  The inverted diagonal blocks the panel
+ *     solve needs anyway are combined by the 2x2 block recursion inv([[A,0],[C,B]]) = [[A^-1,0],[-B^-1 C A^-1, B^-1]]
+ *     as MFMA tile products.  Replaces tf.linalg.triangular_solve / cholesky_solve with M x M right-hand sides
+ *     (reference src/util.py:168-175, src/models/tsvgp.py:270-271): the callers apply X by GEMM.
+ *     T: scratch, batch * M * M doubles.  Other arguments as tsvgp_potrf_f64. */
+int tsvgp_potrf_inv_f64(double *A, int M, int lda, int batch, int64_t stride, int32_t *info, double *work, double *X,
+                        double *Xt, double *T, void *stream);
+
 /* Device self-test of the MFMA fragment maps used above (writes a 16x16 product C = A*B, k = 4, for host checking).
  * a [16 x 4], b [4 x 16], c [16 x 16] row-major. */
 int tsvgp_selftest_mfma_f64(const double *a, const double *b, double *c, void *stream);

@@ -64,6 +64,8 @@ _PROTOTYPES = {
     "tsvgp_site_accum_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     "tsvgp_site_accum_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     "tsvgp_potrf_f64": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p]),
+    "tsvgp_potrf_inv_f64": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_void_p]),
     "tsvgp_selftest_mfma_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "tsvgp_selftest_mfma_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
 }

@@ -1275,7 +1275,8 @@ __device__ __forceinline__ void chol_inv_offdiag(double* __restrict__ S, const d
 // recursion (chol_inv_offdiag) and written to `work` for the panel kernel.
 __global__ __launch_bounds__(CH_THREADS) void potrf_diag_kernel(double* __restrict__ A, int lda, int64_t stride, int k,
                                                                 double* __restrict__ work, int* __restrict__ info,
-                                                                int need_inverse) {
+                                                                int need_inverse, double* __restrict__ Xout,
+                                                                double* __restrict__ Xtout, int ldx, int64_t xstride) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     double* S = reinterpret_cast<double*>(smem_raw);  // [CH_NB][CH_LD]; lower: A -> L, strict upper: inv(L)^T
     __shared__ int fail;
@@ -1371,6 +1372,15 @@ __global__ __launch_bounds__(CH_THREADS) void potrf_diag_kernel(double* __restri
             const int r = idx >> 7, c = idx & 127;
             Wb[idx] = chol_xval(S, dinv, r, c);
         }
+        if (Xout) {  // the block of inv(L) and of its transpose, for tsvgp_potrf_inv_f64
+            double* Xb = Xout + (size_t)b * xstride + (size_t)k * CH_NB * ldx + (size_t)k * CH_NB;
+            double* Xtb = Xtout + (size_t)b * xstride + (size_t)k * CH_NB * ldx + (size_t)k * CH_NB;
+            for (int idx = t; idx < CH_NB * CH_NB; idx += CH_THREADS) {
+                const int r = idx >> 7, c = idx & 127;
+                Xb[(size_t)r * ldx + c] = chol_xval(S, dinv, r, c);
+                Xtb[(size_t)r * ldx + c] = chol_xval(S, dinv, c, r);
+            }
+        }
     }
 #ifdef TSVGP_DIAG_POTRF
     __syncthreads();
@@ -1459,6 +1469,90 @@ __global__ __launch_bounds__(NTHREADS) void chol_tile_kernel(double* __restrict_
                     Cr[16 * n] -= acc[s][n][r];
             }
         }
+}
+
+// inv(L) from the inverted diagonal blocks by the 2x2 recursion, one level per launch pair:
+//   [[L00, 0], [L10, L11]]^-1 = [[X00, 0], [-X11 L10 X00, X11]]      (blocks of n rows; the second may be shorter)
+// with X (lower, row-major) and Xt = X^T kept side by side so that every product is of the form A * B^T with both
+// operands read along contiguous k (the wave-tile scheme of chol_tile_kernel):
+//   STAGE 0:  T^T[j, i] =  sum_k Xt00[j, k] L10[i, k]        (stored at block (0, 1) of the scratch matrix T)
+//   STAGE 1:  X10[i, j] = -sum_k X11[i, k] T^T[j, k]         (stored to X and, transposed, to Xt)
+// The k-ranges skip the zero halves of the triangular operands (Xt00 is upper, X11 lower).
+template <int STAGE>
+__global__ __launch_bounds__(NTHREADS) void trtri_level_kernel(const double* __restrict__ Lm, int lda, int64_t strideA,
+                                                               double* __restrict__ X, double* __restrict__ Xt,
+                                                               double* __restrict__ T, int ldx, int64_t strideX, int M,
+                                                               int n) {
+    const int lane = threadIdx.x & 63, li = lane & 15, g = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pair = blockIdx.y, b = blockIdx.z;
+    const int r0 = 2 * pair * n, r1 = r0 + n;
+    const int n1 = min(n, M - r1);
+    if (n1 <= 0) return;
+    const int nrow32 = (STAGE == 0 ? n : n1) / CH_SB, ncol32 = (STAGE == 0 ? n1 : n) / CH_SB;
+    const int wid = blockIdx.x * (NTHREADS / 64) + w;
+    if (wid >= nrow32 * ncol32) return;
+    const int tr = wid / ncol32, tc = wid - tr * ncol32;  // output tile: rows tr, columns tc (units of 32)
+    const double* Lb = Lm + (size_t)b * strideA;
+    double* Xb = X + (size_t)b * strideX;
+    double* Xtb = Xt + (size_t)b * strideX;
+    double* Tb = T + (size_t)b * strideX;
+    // operands: rows of A (output rows) and rows of B (output columns), both read along k
+    const double *Arow, *Brow;
+    size_t astep, bstep;
+    int kbeg, kend;
+    if (STAGE == 0) {
+        Arow = Xtb + (size_t)(r0 + CH_SB * tr + li) * ldx + r0;  // Xt00[j, k]: zero for k < j
+        Brow = Lb + (size_t)(r1 + CH_SB * tc + li) * lda + r0;    // L10[i, k]
+        astep = (size_t)16 * ldx;
+        bstep = (size_t)16 * lda;
+        kbeg = (CH_SB * tr) & ~63;
+        kend = n;
+    } else {
+        Arow = Xb + (size_t)(r1 + CH_SB * tr + li) * ldx + r1;  // X11[i, k]: zero for k > i
+        Brow = Tb + (size_t)(r0 + CH_SB * tc + li) * ldx + r1;  // T^T[j, k]
+        astep = (size_t)16 * ldx;
+        bstep = (size_t)16 * ldx;
+        kbeg = 0;
+        kend = min(n1, (CH_SB * (tr + 1) + 63) & ~63);
+    }
+    v4d acc[2][2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) acc[s][q] = v4d{0, 0, 0, 0};
+    for (int k0 = kbeg; k0 < kend; k0 += 64) {
+        v2d ra[2][8], rb[2][8];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                ra[s][q] = *reinterpret_cast<const v2d*>(Arow + s * astep + k0 + 16 * g + 2 * q);
+                rb[s][q] = *reinterpret_cast<const v2d*>(Brow + s * bstep + k0 + 16 * g + 2 * q);
+            }
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+                    acc[s][q] = Mfma<double>::run(ra[s][kk >> 1][kk & 1], rb[q][kk >> 1][kk & 1], acc[s][q]);
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int orow = CH_SB * tr + 16 * s + g + 4 * r, ocol = CH_SB * tc + 16 * q + li;
+                if (STAGE == 0) {
+                    Tb[(size_t)(r0 + orow) * ldx + r1 + ocol] = acc[s][q][r];
+                } else {
+                    const double v = -acc[s][q][r];
+                    Xb[(size_t)(r1 + orow) * ldx + r0 + ocol] = v;
+                    Xtb[(size_t)(r0 + ocol) * ldx + r1 + orow] = v;
+                }
+            }
 }
 
 // single-wave MFMA map self-test
@@ -1647,8 +1741,11 @@ int site_accum_slots() {
     return cus * nb;
 }
 
-int potrf(double* A, int M, int lda, int batch, int64_t stride, int* info, double* work, void* stream) {
+int potrf(double* A, int M, int lda, int batch, int64_t stride, int* info, double* work, void* stream,
+          double* X = nullptr, double* Xt = nullptr, double* T = nullptr) {
     if (!A || !info || !work || M <= 0 || (M % CH_NB) || lda < M || batch <= 0) return TSVGP_EINVAL;
+    const bool inv = X != nullptr;
+    if (inv && (!Xt || !T)) return TSVGP_EINVAL;
     const int nt = M / CH_NB;
     const size_t smem = (size_t)CH_NB * CH_LD * sizeof(double);
     static bool attr_set = false;
@@ -1659,17 +1756,34 @@ int potrf(double* A, int M, int lda, int batch, int64_t stride, int* info, doubl
         attr_set = true;
     }
     hipStream_t st = (hipStream_t)stream;
+    const int64_t xstride = (int64_t)M * M;
     if (hipMemsetAsync(info, 0, sizeof(int) * batch, st) != hipSuccess) return TSVGP_ELAUNCH;
+    if (inv) {  // the blocks the recursion does not write stay zero
+        if (hipMemsetAsync(X, 0, sizeof(double) * xstride * batch, st) != hipSuccess) return TSVGP_ELAUNCH;
+        if (hipMemsetAsync(Xt, 0, sizeof(double) * xstride * batch, st) != hipSuccess) return TSVGP_ELAUNCH;
+    }
+    const int wpb = NTHREADS / 64;
     for (int k = 0; k < nt; ++k) {
         hipLaunchKernelGGL(potrf_diag_kernel, dim3(batch), dim3(CH_THREADS), smem, st, A, lda, stride, k, work, info,
-                           (k + 1 < nt) ? 1 : 0);
+                           (inv || k + 1 < nt) ? 1 : 0, X, Xt, M, xstride);
         const int below = nt - k - 1;
         if (below > 0) {
-            const int nb32 = below * (CH_NB / CH_SB), ntile = nb32 * (nb32 + 1) / 2, wpb = NTHREADS / 64;
+            const int nb32 = below * (CH_NB / CH_SB), ntile = nb32 * (nb32 + 1) / 2;
             hipLaunchKernelGGL(chol_tile_kernel<0>, dim3(nb32, batch), dim3(NTHREADS), 0, st, A, lda, stride, k, nt,
                                work);
             hipLaunchKernelGGL(chol_tile_kernel<1>, dim3((ntile + wpb - 1) / wpb, batch), dim3(NTHREADS), 0, st, A,
                                lda, stride, k, nt, work);
+        }
+    }
+    if (inv) {
+        for (int n = CH_NB; n < M; n *= 2) {
+            const int npair = (M + 2 * n - 1) / (2 * n);
+            const int ntile = (n / CH_SB) * (n / CH_SB);
+            const dim3 grid((ntile + wpb - 1) / wpb, npair, batch);
+            hipLaunchKernelGGL(trtri_level_kernel<0>, grid, dim3(NTHREADS), 0, st, A, lda, stride, X, Xt, T, M, xstride,
+                               M, n);
+            hipLaunchKernelGGL(trtri_level_kernel<1>, grid, dim3(NTHREADS), 0, st, A, lda, stride, X, Xt, T, M, xstride,
+                               M, n);
         }
     }
     return launch_status();
@@ -1730,6 +1844,11 @@ int tsvgp_site_accum_f32(const float* B, const float* g0, const float* g1, doubl
 
 int tsvgp_potrf_f64(double* A, int M, int lda, int batch, int64_t stride, int* info, double* work, void* stream) {
     return potrf(A, M, lda, batch, stride, info, work, stream);
+}
+int tsvgp_potrf_inv_f64(double* A, int M, int lda, int batch, int64_t stride, int* info, double* work, double* X,
+                        double* Xt, double* T, void* stream) {
+    if (!X || !Xt || !T) return TSVGP_EINVAL;
+    return potrf(A, M, lda, batch, stride, info, work, stream, X, Xt, T);
 }
 
 int tsvgp_selftest_mfma_f64(const double* a, const double* b, double* c, void* stream) {

@@ -158,9 +158,10 @@ class EStepEngine:
         self.se_fill(Z, Z, inv_ls, float(kernel.variance.value), out)
         return out[:M, :M].contiguous()
 
-    def cholesky(self, A: torch.Tensor):
+    def cholesky(self, A: torch.Tensor, inverse: bool = False):
         """Batched lower Cholesky on the GPU through ``tsvgp_potrf_f64`` (no host synchronisation).
-        A [.., M, M] fp64 (lower triangle referenced) -> (L [.., M, M] with zeros above the diagonal, info [batch] int32)."""
+        A [.., M, M] fp64 (lower triangle referenced) -> (L [.., M, M] with zeros above the diagonal, info [batch] int32);
+        with ``inverse`` also inv(L) (``tsvgp_potrf_inv_f64``), lower triangular with exact zeros above."""
         A = A.to(device=self.device, dtype=torch.float64)
         M = A.shape[-1]
         batch_shape = A.shape[:-2]
@@ -175,10 +176,20 @@ class EStepEngine:
             W[:, idx, idx] = 1.0  # chol([[A, 0], [0, I]]) = [[L, 0], [0, I]]
         info = torch.empty(nb, dtype=torch.int32, device=self.device)
         work = self._get("potrf_work", (nb, 128 * 128), torch.float64)
+        out_shape = tuple(batch_shape) + (M, M)
         with torch.cuda.device(self.device):
-            self._launch("tsvgp_potrf", lambda: self.lib.tsvgp_potrf_f64(W.data_ptr(), Mp, Mp, nb, Mp * Mp, info.data_ptr(),
-                                                                        work.data_ptr(), self._stream()))
-        L = torch.tril(W[:, :M, :M]).reshape(tuple(batch_shape) + (M, M))
+            if inverse:
+                X = torch.empty((2, nb, Mp, Mp), dtype=torch.float64, device=self.device)  # inv(L) and its transpose
+                T = self._get("potrf_T", (nb, Mp, Mp), torch.float64)
+                self._launch("tsvgp_potrf", lambda: self.lib.tsvgp_potrf_inv_f64(
+                    W.data_ptr(), Mp, Mp, nb, Mp * Mp, info.data_ptr(), work.data_ptr(), X[0].data_ptr(), X[1].data_ptr(),
+                    T.data_ptr(), self._stream()))
+            else:
+                self._launch("tsvgp_potrf", lambda: self.lib.tsvgp_potrf_f64(
+                    W.data_ptr(), Mp, Mp, nb, Mp * Mp, info.data_ptr(), work.data_ptr(), self._stream()))
+        L = torch.tril(W[:, :M, :M]).reshape(out_shape)
+        if inverse:
+            return L, info, X[0, :, :M, :M].reshape(out_shape)
         return L, info
 
     def trmm(self, A: torch.Tensor, Tm: torch.Tensor, C: torch.Tensor, mode: int):

@@ -200,18 +200,18 @@ class t_SVGP(base_SVGP):
         # independent and both latency bound (one workgroup per diagonal block): do them in ONE batched call.
         W = Id + L.transpose(-1, -2) @ (K6 @ L)
         W = 0.5 * (W + W.transpose(-1, -2))
-        # The triangular inverses are formed explicitly (ONE batched triangular solve against I) and applied as GEMMs:
-        # a rocBLAS trsm with an M x M right-hand side costs ~0.25 ms at M = 1024, a GEMM ~0.05 ms.
+        # The factorisation also returns the inverse factors (tsvgp_potrf_inv_f64) and they are applied as GEMMs: a
+        # rocBLAS trsm with an M x M right-hand side costs ~0.25 ms at M = 1024, a GEMM ~0.05 ms.
         if whiten_jitter is not None and warm:
-            U_W, U9, Uinv9 = rev_cholesky(W, infos, potrf), warm[1]["U9"], warm[1]["Uinv9"]
-            Uinv_W = torch.linalg.solve_triangular(U_W, Id, upper=True)
+            U9, Uinv9 = warm[1]["U9"], warm[1]["Uinv9"]
+            U_W, Uinv_W = rev_cholesky(W, infos, potrf, inverse=True)
         elif whiten_jitter is not None:
-            both = rev_cholesky(torch.cat([W, (Kzz + whiten_jitter * Id)[None]], dim=0), infos, potrf)
-            inv_both = torch.linalg.solve_triangular(both, Id, upper=True)
-            U_W, U9, Uinv_W, Uinv9 = both[:-1], both[-1], inv_both[:-1], inv_both[-1].triu()
+            both, inv_both = rev_cholesky(torch.cat([W, (Kzz + whiten_jitter * Id)[None]], dim=0), infos, potrf,
+                                          inverse=True)
+            U_W, U9, Uinv_W, Uinv9 = both[:-1], both[-1], inv_both[:-1], inv_both[-1]
         else:
-            U_W, U9, Uinv9 = rev_cholesky(W, infos, potrf), None, None
-            Uinv_W = torch.linalg.solve_triangular(U_W, Id, upper=True)
+            U9, Uinv9 = None, None
+            U_W, Uinv_W = rev_cholesky(W, infos, potrf, inverse=True)
         Dm = (Uinv_W @ L.transpose(-1, -2)).triu()  # D = U_W^-1 L^T, [P, M, M], upper triangular
         DKl = torch.einsum("pmk,kp->pm", Dm, K6 @ l1)
         beta = l1 - torch.einsum("pkm,pk->mp", Dm, DKl)  # K6^-1 m = l1 - D^T D K6 l1

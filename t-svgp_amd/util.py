@@ -20,23 +20,32 @@ def cholesky(a: torch.Tensor) -> torch.Tensor:
     return L
 
 
-def cholesky_deferred(a: torch.Tensor, infos: list, potrf=None) -> torch.Tensor:
+def cholesky_deferred(a: torch.Tensor, infos: list, potrf=None, inverse: bool = False):
     """Cholesky without a host synchronisation: the LAPACK-style ``info`` tensor is appended to ``infos`` and
     checked later in one device->host read (see ``t_SVGP._check_step``).  ``potrf`` is the engine's HIP
-    factorisation (``EStepEngine.cholesky``); without it torch's is used."""
+    factorisation (``EStepEngine.cholesky``); without it torch's is used.  With ``inverse`` returns (L, inv(L))."""
+    Linv = None
     if potrf is not None:
-        L, info = potrf(a)
+        res = potrf(a, inverse=True) if inverse else potrf(a)
+        L, info = res[0], res[1]
+        Linv = res[2] if inverse else None
     else:
         L, info = torch.linalg.cholesky_ex(a, upper=False, check_errors=False)
+        if inverse:
+            Id = torch.eye(a.shape[-1], dtype=a.dtype, device=a.device)
+            Linv = torch.linalg.solve_triangular(L, Id, upper=False)
     infos.append(info.reshape(-1).to(torch.float64).abs().sum().reshape(1))
-    return L
+    return (L, Linv) if inverse else L
 
 
-def rev_cholesky(a: torch.Tensor, infos: list, potrf=None) -> torch.Tensor:
+def rev_cholesky(a: torch.Tensor, infos: list, potrf=None, inverse: bool = False):
     """Upper-form Cholesky a = U U^T, U upper triangular: the lower factor of the index-reversed matrix, reversed back
-    (J a J = C C^T  =>  a = (J C J)(J C J)^T).  Status handling as in ``cholesky_deferred``."""
-    C = cholesky_deferred(torch.flip(a, (-2, -1)), infos, potrf)
-    return torch.flip(C, (-2, -1))
+    (J a J = C C^T  =>  a = (J C J)(J C J)^T, and U^-1 = J C^-1 J).  Status handling as in ``cholesky_deferred``.
+    With ``inverse`` returns (U, inv(U))."""
+    res = cholesky_deferred(torch.flip(a, (-2, -1)), infos, potrf, inverse)
+    if inverse:
+        return torch.flip(res[0], (-2, -1)), torch.flip(res[1], (-2, -1))
+    return torch.flip(res, (-2, -1))
 
 
 def chol_solve_upper(U: torch.Tensor, b: torch.Tensor) -> torch.Tensor:

@@ -188,3 +188,22 @@ def test_potrf(engines, M, batch):
     bad[0, M // 2, M // 2] = -1.0
     _, info = eng.cholesky(torch.as_tensor(bad, device="cuda:0"))
     assert int(info[0]) == M // 2 + 1  # 1-based index of the first non-positive pivot
+
+
+@pytest.mark.parametrize("M,batch", [(128, 1), (256, 3), (1024, 1), (640, 2), (1536, 1), (200, 2), (33, 1)])
+def test_potrf_inverse(engines, M, batch):
+    """tsvgp_potrf_inv_f64: the factor and its inverse (2x2 block recursion on the inverted diagonal blocks), also for
+    block counts that are not powers of two."""
+    eng = engines[torch.float64]
+    rng = np.random.RandomState(6)
+    A = rng.randn(batch, M, M)
+    A = A @ np.swapaxes(A, -1, -2) / M + 0.5 * np.eye(M)
+    L, info, Linv = eng.cholesky(torch.as_tensor(A, device="cuda:0"), inverse=True)
+    torch.cuda.synchronize()
+    assert int(info.abs().sum()) == 0
+    ref = np.linalg.cholesky(A)
+    assert relerr(L.cpu().numpy(), ref) < 1e-12
+    X = Linv.cpu().numpy()
+    assert np.array_equal(np.triu(X, 1), np.zeros_like(A))
+    assert relerr(X, np.linalg.inv(ref)) < 1e-11
+    assert np.max(np.abs(X @ ref - np.eye(M))) < 1e-11
