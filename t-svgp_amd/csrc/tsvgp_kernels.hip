@@ -21,6 +21,8 @@
 // 144 elements.
 
 #include <hip/hip_runtime.h>
+
+#include <type_traits>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -306,8 +308,14 @@ struct PanelArgs {
     int Mp, P, mode, lik;
 };
 
-template <typename T, int MODE, int TRI>
+// FUSE (MOMENTS + UPPER only): the mean GEMV rides on the first column tile, whose k-range covers every chunk of the
+// row panel: each thread multiplies the eight A values it stages by gamma (kept in dynamic LDS, Mp elements) before
+// storing them, which removes the separate sweep of the panel from HBM (1.0 of 18.3 ms at N = 1e6, M = 1024).
+template <typename T, int MODE, int TRI, bool FUSE = false>
 __global__ __launch_bounds__(NTHREADS, 2) void panel_kernel(PanelArgs<T> a) {
+    static_assert(!FUSE || (MODE == MODE_MOMENTS && TRI == TSVGP_TRI_UPPER), "FUSE needs a full k sweep on tile 0");
+    extern __shared__ __attribute__((aligned(16))) unsigned char panel_dyn_smem[];
+    T* const gsm = reinterpret_cast<T*>(panel_dyn_smem);  // FUSE: gamma_p, Mp elements
     constexpr int RS = RowStride<T>::value;
     constexpr int CPT = TILE / KC;  // chunks per 128-wide k-tile
     __shared__ __attribute__((aligned(16))) T lds[2][2][TILE * RS];
@@ -335,7 +343,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void panel_kernel(PanelArgs<T> a) {
         // summed over the 16 lanes that share (lane>>4) and lane lr keeps the one with index lr & 7.
         double rs_mine = 0.0;
         T mpart = T(0);
-        if constexpr (MODE == MODE_MOMENTS) {
+        if constexpr (FUSE) {
+            for (int j = t; j < Mp; j += NTHREADS) gsm[j] = a.gamma[(size_t)j * a.P + p];
+            __syncthreads();
+        } else if constexpr (MODE == MODE_MOMENTS) {
             // Mean GEMV phase: mean[n] = sum_j A[n, j] * gamma[j, p].  A memory/VALU-only sweep of this workgroup's row
             // panel with no accumulators live (it runs beside the partner workgroup's MFMAs on the same CU); gamma_p
             // is staged in LDS (reusing the staging buffers) and read as a two-address broadcast.
@@ -343,6 +354,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void panel_kernel(PanelArgs<T> a) {
             for (int j = t; j < Mp; j += NTHREADS) gs[j] = a.gamma[(size_t)j * a.P + p];
             __syncthreads();
             const T* gk = gs + skh * 8;
+#ifndef TSVGP_EXP_NOGEMV  // ablation switch (tools/exp_moments.py)
 #pragma unroll 4
             for (int c = 0; c < nchunk; ++c) {
                 T ra[8];
@@ -350,10 +362,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void panel_kernel(PanelArgs<T> a) {
 #pragma unroll
                 for (int q = 0; q < 8; ++q) mpart += ra[q] * gk[c * KC + q];
             }
+#endif
             __syncthreads();
         }
 
-        for (int it = 0; it < ntile; ++it) {
+        auto tile_body = [&](const int it, auto first_tag) {
+            constexpr bool FIRST = decltype(first_tag)::value;  // FUSE: the tile that also accumulates the mean
             const T* Trow = Tp + (size_t)(it * TILE + srow) * Mp + skh * 8;
 
             acc_t acc[2][8];
@@ -371,10 +385,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void panel_kernel(PanelArgs<T> a) {
         load8(ra, Arow + (cnext) * KC);       \
         load8(rb, Trow + (cnext) * KC);       \
     }
-#define TSVGP_STAGE(cnext, b_)                                   \
-    {                                                            \
-        store_rowk8(lds_wr + (b_) * BUF_STRIDE, ra);             \
-        store_rowk8(lds_wr + (b_) * BUF_STRIDE + OP_STRIDE, rb); \
+#define TSVGP_STAGE(cnext, b_)                                           \
+    {                                                                    \
+        if constexpr (FIRST) {                                           \
+            const T* gq = gsm + (cnext) * KC + skh * 8;                  \
+            _Pragma("unroll") for (int q = 0; q < 8; ++q) mpart += ra[q] * gq[q]; \
+        }                                                                \
+        store_rowk8(lds_wr + (b_) * BUF_STRIDE, ra);                     \
+        store_rowk8(lds_wr + (b_) * BUF_STRIDE + OP_STRIDE, rb);         \
     }
 #ifdef TSVGP_EXP_NOLOAD
 #define TSVGP_EXP_HASNEXT(x) false
@@ -457,7 +475,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void panel_kernel(PanelArgs<T> a) {
                     }
                 rs_mine += keep;
             }
-        }  // it
+        };  // tile_body
+        if constexpr (FUSE) {
+            tile_body(0, std::true_type{});
+            for (int it = 1; it < ntile; ++it) tile_body(it, std::false_type{});
+        } else {
+            for (int it = 0; it < ntile; ++it) tile_body(it, std::false_type{});
+        }
 
         if constexpr (MODE == MODE_MOMENTS) {
             // lane (lr < 8, lane>>4) holds the complete sum of row  row_block(w, lr>>2)*16 + rowmap(lane, lr&3)
@@ -1483,6 +1507,9 @@ __global__ __launch_bounds__(NTHREADS) void trtri_level_kernel(const double* __r
                                                                double* __restrict__ X, double* __restrict__ Xt,
                                                                double* __restrict__ T, int ldx, int64_t strideX, int M,
                                                                int n) {
+    // One workgroup per 32x32 output tile; its four waves split the k range (64-wide chunks, round robin) and the
+    // partial tiles are summed through LDS: a lone wave per tile would sit out one load latency per chunk.
+    __shared__ v4d part[NTHREADS / 64][4][64];
     const int lane = threadIdx.x & 63, li = lane & 15, g = lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int pair = blockIdx.y, b = blockIdx.z;
@@ -1490,7 +1517,7 @@ __global__ __launch_bounds__(NTHREADS) void trtri_level_kernel(const double* __r
     const int n1 = min(n, M - r1);
     if (n1 <= 0) return;
     const int nrow32 = (STAGE == 0 ? n : n1) / CH_SB, ncol32 = (STAGE == 0 ? n1 : n) / CH_SB;
-    const int wid = blockIdx.x * (NTHREADS / 64) + w;
+    const int wid = blockIdx.x;
     if (wid >= nrow32 * ncol32) return;
     const int tr = wid / ncol32, tc = wid - tr * ncol32;  // output tile: rows tr, columns tc (units of 32)
     const double* Lb = Lm + (size_t)b * strideA;
@@ -1521,7 +1548,7 @@ __global__ __launch_bounds__(NTHREADS) void trtri_level_kernel(const double* __r
     for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int q = 0; q < 2; ++q) acc[s][q] = v4d{0, 0, 0, 0};
-    for (int k0 = kbeg; k0 < kend; k0 += 64) {
+    for (int k0 = kbeg + 64 * w; k0 < kend; k0 += 64 * (NTHREADS / 64)) {
         v2d ra[2][8], rb[2][8];
 #pragma unroll
         for (int s = 0; s < 2; ++s)
@@ -1541,18 +1568,24 @@ __global__ __launch_bounds__(NTHREADS) void trtri_level_kernel(const double* __r
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int q = 0; q < 2; ++q) part[w][2 * s + q][lane] = acc[s][q];
+    __syncthreads();
+    // wave w finishes the 16x16 sub-tile (s, q) = (w >> 1, w & 1)
+    const int s = w >> 1, q = w & 1;
+    v4d sum = part[0][w][lane];
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int orow = CH_SB * tr + 16 * s + g + 4 * r, ocol = CH_SB * tc + 16 * q + li;
-                if (STAGE == 0) {
-                    Tb[(size_t)(r0 + orow) * ldx + r1 + ocol] = acc[s][q][r];
-                } else {
-                    const double v = -acc[s][q][r];
-                    Xb[(size_t)(r1 + orow) * ldx + r0 + ocol] = v;
-                    Xtb[(size_t)(r0 + ocol) * ldx + r1 + orow] = v;
-                }
-            }
+    for (int u = 1; u < NTHREADS / 64; ++u) sum += part[u][w][lane];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int orow = CH_SB * tr + 16 * s + g + 4 * r, ocol = CH_SB * tc + 16 * q + li;
+        if (STAGE == 0) {
+            Tb[(size_t)(r0 + orow) * ldx + r1 + ocol] = sum[r];
+        } else {
+            const double v = -sum[r];
+            Xb[(size_t)(r1 + orow) * ldx + r0 + ocol] = v;
+            Xtb[(size_t)(r0 + ocol) * ldx + r1 + orow] = v;
+        }
+    }
 }
 
 // single-wave MFMA map self-test
@@ -1680,6 +1713,10 @@ int moments(const T* A, const T* Tm, const T* gamma, const T* Y, double kdiag, i
     }
     if (mode == TSVGP_TRI_LOWER)
         hipLaunchKernelGGL((panel_kernel<T, MODE_MOMENTS, TSVGP_TRI_LOWER>), grid, block, 0, (hipStream_t)stream, a);
+    else if (mode == TSVGP_TRI_UPPER && (size_t)Mp * sizeof(T) <= 8192)
+        // gamma fits beside the staging buffers without costing the second workgroup per CU: fused mean
+        hipLaunchKernelGGL((panel_kernel<T, MODE_MOMENTS, TSVGP_TRI_UPPER, true>), grid, block, (size_t)Mp * sizeof(T),
+                           (hipStream_t)stream, a);
     else if (mode == TSVGP_TRI_UPPER)
         hipLaunchKernelGGL((panel_kernel<T, MODE_MOMENTS, TSVGP_TRI_UPPER>), grid, block, 0, (hipStream_t)stream, a);
     else
@@ -1779,7 +1816,7 @@ int potrf(double* A, int M, int lda, int batch, int64_t stride, int* info, doubl
         for (int n = CH_NB; n < M; n *= 2) {
             const int npair = (M + 2 * n - 1) / (2 * n);
             const int ntile = (n / CH_SB) * (n / CH_SB);
-            const dim3 grid((ntile + wpb - 1) / wpb, npair, batch);
+            const dim3 grid(ntile, npair, batch);
             hipLaunchKernelGGL(trtri_level_kernel<0>, grid, dim3(NTHREADS), 0, st, A, lda, stride, X, Xt, T, M, xstride,
                                M, n);
             hipLaunchKernelGGL(trtri_level_kernel<1>, grid, dim3(NTHREADS), 0, st, A, lda, stride, X, Xt, T, M, xstride,
