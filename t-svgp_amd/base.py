@@ -37,6 +37,19 @@ def to_tensor(value, dtype=None, device=None) -> torch.Tensor:
     return torch.as_tensor(np.asarray(value), dtype=dtype).to(device)
 
 
+def _host_scalar(value):
+    """Python float of a scalar that already lives on the host; None for arrays and for device tensors."""
+    if isinstance(value, Parameter):
+        return value._host if value._host_version == value.version else None
+    if isinstance(value, torch.Tensor):
+        return float(value) if (value.dim() == 0 and value.device.type == "cpu") else None
+    if isinstance(value, (int, float, np.floating, np.integer)):
+        return float(value)
+    if isinstance(value, np.ndarray) and value.ndim == 0:
+        return float(value)
+    return None
+
+
 class Parameter:
     """Holds one tensor; ``assign`` replaces its value in place (shape-checked)."""
 
@@ -45,6 +58,17 @@ class Parameter:
         self.trainable = trainable
         self.name = name
         self.version = 0  # bumped by assign(): lets cached kernel factorisations notice external parameter changes
+        self._host = _host_scalar(value)  # scalar parameters: the value as a Python float, without a device read
+        self._host_version = 0 if self._host is not None else -1
+
+    def item(self) -> float:
+        """The scalar value as a Python float.  Kernel launches take scalars by value; reading them back from the
+        device on every E-step would put a host synchronisation in the middle of the step, so the host copy is kept
+        from the assignment (or read once per assignment when the value came as a device tensor)."""
+        if self._host_version != self.version:
+            self._host = float(self._value)
+            self._host_version = self.version
+        return self._host
 
     @property
     def value(self) -> torch.Tensor:
@@ -70,6 +94,9 @@ class Parameter:
             raise ValueError(f"assign: shape {tuple(new.shape)} does not match {tuple(self._value.shape)}")
         self._value = new.clone()
         self.version += 1
+        host = _host_scalar(value)
+        if host is not None:
+            self._host, self._host_version = host, self.version
         return self
 
     def numpy(self) -> np.ndarray:

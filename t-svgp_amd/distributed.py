@@ -41,7 +41,7 @@ def pack_stats(stats, with_sites: bool) -> torch.Tensor:
         parts += [stats.acc2.reshape(-1), stats.acc1.reshape(-1)]
     dev = stats.ve_sum.device
     parts += [stats.ve_sum.reshape(1).to(torch.float64), stats.nonpos.reshape(1).to(torch.float64),
-              torch.tensor([float(stats.n_rows)], dtype=torch.float64, device=dev)]
+              torch.full((1,), float(stats.n_rows), dtype=torch.float64, device=dev)]  # a fill kernel, not a host copy
     return torch.cat([p.to(torch.float64) for p in parts])
 
 

@@ -155,7 +155,7 @@ class EStepEngine:
         Mp = B.round_up(M)
         out = torch.empty((Mp, Mp), dtype=torch.float64, device=self.device)
         inv_ls = kernel.inv_lengthscales(D, torch.float64, self.device)
-        self.se_fill(Z, Z, inv_ls, float(kernel.variance.value), out)
+        self.se_fill(Z, Z, inv_ls, kernel.variance.item(), out)
         return out[:M, :M].contiguous()
 
     def cholesky(self, A: torch.Tensor, inverse: bool = False):
@@ -243,7 +243,7 @@ class EStepEngine:
                 raise ValueError(f"Y must be [N, P] = [{N}, {P}], got {tuple(Y.shape)}")
         Np, Mp = B.round_up(N), B.round_up(M)
         inv_ls = kernel.inv_lengthscales(D, T, dev)
-        variance = float(kernel.variance.value)
+        variance = kernel.variance.item()
 
         # The N x M operand of the moments / site kernels: the whitened B = Kfu U^-T, or Kfu itself ("direct" route).
         # A tagged operand left by the previous call is reused when the tag matches (warm E-steps).

@@ -25,7 +25,7 @@ class Gaussian:
 
     @property
     def lik_param(self) -> float:
-        return float(self.variance.value)
+        return self.variance.item()
 
     def predict_mean_and_var(self, Fmu, Fvar):
         return Fmu, Fvar + self.variance.value
