@@ -242,8 +242,8 @@ def main():
             "elbo_after_steps": elbo,
             "warm": {"value": round(args.steps / warm_elapsed, 4), "unit": "E-steps/s",
                      "ms_per_step": round(warm_elapsed / args.steps * 1e3, 4),
-                     "note": "cache_whitened=True: chol(K_uu+jitter I), its inverse and B = K_fu L^-T reused across "
-                             "E-steps with unchanged hyperparameters; not the headline"},
+                     "note": "cache_whitened=True: the factor of K_uu+jitter I, its inverse and the N x M operand (K_fu, or "
+                             "the whitened B) reused across E-steps with unchanged hyperparameters; not the headline"},
             "roofline": roofline,
             "kernels": kernels,
             "kernel_ms_per_step": round(sum(v[0] * v[1] for v in prof.values()) / args.steps, 4),
