@@ -14,7 +14,9 @@ Workloads (BASELINE.json):
   ns  (default) north_star target / the metric's sizes: Gaussian regression N=1e6, M=1024, D=8, P=1, fp64
   c2  configs[1]: Gaussian regression N=1e6, M=512,  D=8,  fp64
   c3  configs[2]: Bernoulli (probit, GH-20) N=1e6, M=1024, D=16, fp32 N-arrays (M x M algebra stays fp64)
-  c5  configs[4]: P=8 latents (shared kernel) N=1e6, M=1024, D=8, fp64
+  c5  configs[4]: P=8 latents, one SE kernel per latent (lengthscales linspace(0.8, 1.5, 8)) on shared inducing points:
+      K_uu [P, M, M], batched factorisations, one K(X, Z) fill per latent; N=1e6, M=1024, D=8, fp64  
+  c5s the shared-kernel special case of c5 (one K(X, Z) fill serves all latents)
   c1  configs[0]: N=1000, M=32, D=1 plumbing case
 """
 import argparse
@@ -36,8 +38,10 @@ WORKLOADS = {
                name="gaussian_regression_N1e6_M512_D8_P1 (BASELINE configs[1])"),
     "c3": dict(N=1_000_000, M=1024, D=16, P=1, lik="bernoulli", dtype="f32",
                name="bernoulli_probit_N1e6_M1024_D16_P1 (BASELINE configs[2])"),
-    "c5": dict(N=1_000_000, M=1024, D=8, P=8, lik="gaussian", dtype="f64",
-               name="gaussian_multioutput_N1e6_M1024_D8_P8_shared_kernel (BASELINE configs[4])"),
+    "c5": dict(N=1_000_000, M=1024, D=8, P=8, lik="gaussian", dtype="f64", separate=True,
+               name="gaussian_multioutput_N1e6_M1024_D8_P8_separate_kernels (BASELINE configs[4])"),
+    "c5s": dict(N=1_000_000, M=1024, D=8, P=8, lik="gaussian", dtype="f64",
+                name="gaussian_multioutput_N1e6_M1024_D8_P8_shared_kernel (special case of BASELINE configs[4])"),
     "c1": dict(N=1000, M=32, D=1, P=1, lik="gaussian", dtype="f64", name="gaussian_1d_N1000_M32 (BASELINE configs[0])",
                lengthscales=0.1, variance=0.3, noise=1.0),
 }
@@ -65,7 +69,7 @@ def make_data(w, seed=0):
 
 def kernel_flops(w, rows):
     """Algorithmic flops per launch of each MFMA kernel for `rows` data rows (triangular/symmetric counts, 2 per FMA)."""
-    M, P = w["M"], w["P"]
+    M, P = w["M"], (1 if w.get("separate") else w["P"])  # separate kernels: one launch per latent
     return {
         "tsvgp_trmm": rows * M * (M + 1),  # B = Kfu L^-T, lower-triangular k-range
         "tsvgp_moments": rows * M * (M + 1) * P + 2 * rows * M * P,  # |F^T b|^2 (upper) + mean GEMV
@@ -76,6 +80,15 @@ def kernel_flops(w, rows):
 def kernel_bytes(w, rows, esize):
     """Algorithmic HBM bytes per launch of the fill kernel (the only HBM-bound kernel): write Kfu once, read X once."""
     return {"tsvgp_se_fill": rows * w["M"] * esize + rows * w["D"] * esize}
+
+
+def make_kernel(mod, w):
+    """The workload's kernel (and inducing variable wrapper) in module `mod` (the package or the oracle)."""
+    var = w.get("variance", 1.0)
+    if w.get("separate"):  # SURVEY 8(d), C5: l_p = linspace(0.8, 1.5, P)
+        return mod.SeparateIndependent([mod.SquaredExponential(variance=var, lengthscales=float(l))
+                                        for l in np.linspace(0.8, 1.5, w["P"])]), mod.SharedIndependentInducingVariables
+    return mod.SquaredExponential(variance=var, lengthscales=w.get("lengthscales", 1.0)), (lambda Z: Z)
 
 
 def cpu_baseline(w, budget_s=20.0):
@@ -91,8 +104,8 @@ def cpu_baseline(w, budget_s=20.0):
     n_s = min(w["N"], max(2000, int(2.0e7 // (w["M"] * w["P"]))))  # bounds the [n, M, P] temporaries to ~160 MB each
     X, Y, Z = make_data(dict(w, N=n_s))
     lik = O.Gaussian(variance=w.get("noise", 0.1)) if w["lik"] == "gaussian" else O.Bernoulli()
-    model = O.t_SVGP(O.SquaredExponential(variance=w.get("variance", 1.0), lengthscales=w.get("lengthscales", 1.0)), lik,
-                     Z, num_latent_gps=w["P"])
+    kernel, wrap = make_kernel(O, w)
+    model = O.t_SVGP(kernel, lik, wrap(Z), num_latent_gps=w["P"])
     model.natgrad_step((X, Y), lr=0.8)  # warm-up (BLAS thread pools, page faults)
     times = []
     t_all = time.perf_counter()
@@ -158,9 +171,8 @@ def main():
     del X, Y
 
     lik = pkg.Gaussian(variance=w.get("noise", 0.1)) if w["lik"] == "gaussian" else pkg.Bernoulli()
-    model = pkg.t_SVGP(pkg.SquaredExponential(variance=w.get("variance", 1.0), lengthscales=w.get("lengthscales", 1.0)),
-                       lik, Z, num_latent_gps=w["P"],
-                       num_data=w["N"], compute_dtype=dtype, device=device)
+    kernel, wrap = make_kernel(pkg, w)
+    model = pkg.t_SVGP(kernel, lik, wrap(Z), num_latent_gps=w["P"], num_data=w["N"], compute_dtype=dtype, device=device)
     eng = model._get_engine()
 
     def barrier():

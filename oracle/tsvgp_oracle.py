@@ -134,19 +134,59 @@ class InducingPoints:
         return self.Z.shape[0]
 
 
+class SeparateIndependent:
+    """gpflow.kernels.SeparateIndependent [ext]: P independent latent GPs, one kernel each, no mixing
+    (docs/notebooks/heteroskedastic.py:62-67)."""
+
+    def __init__(self, kernels):
+        self.kernels = list(kernels)
+
+    @property
+    def num_latent_gps(self):
+        return len(self.kernels)
+
+    def K_diag(self, X):
+        return np.stack([k.K_diag(X) for k in self.kernels], axis=1)  # [N, P]
+
+
+class SharedIndependentInducingVariables:
+    """gpflow.inducing_variables.SharedIndependentInducingVariables [ext]: one set of inducing points shared by
+    all latent GPs (docs/notebooks/heteroskedastic.py:72-74)."""
+
+    def __init__(self, inducing_variable):
+        self.inducing_variable = inducingpoint_wrapper(inducing_variable)
+        self.inducing_variables = [self.inducing_variable]  # the attribute src/models/tsvgp.py:252 reads
+
+    @property
+    def num_inducing(self):
+        return self.inducing_variable.num_inducing
+
+
 def inducingpoint_wrapper(iv):
     """gpflow.models.util.inducingpoint_wrapper [ext]: raw [M,D] arrays are wrapped."""
-    return iv if isinstance(iv, InducingPoints) else InducingPoints(iv)
+    return iv if isinstance(iv, (InducingPoints, SharedIndependentInducingVariables)) else InducingPoints(iv)
+
+
+def _is_multi(iv, kernel):
+    multi_k, multi_iv = isinstance(kernel, SeparateIndependent), isinstance(iv, SharedIndependentInducingVariables)
+    if multi_k != multi_iv:
+        raise NotImplementedError("only (SharedIndependentInducingVariables, SeparateIndependent) is restated")
+    return multi_k
 
 
 def Kuu(iv, kernel, jitter=0.0):
-    """gpflow.covariances.Kuu [ext]: K(Z) + jitter*I."""
+    """gpflow.covariances.Kuu [ext]: K(Z) + jitter*I; [P, M, M] for (shared inducing points, separate kernels)."""
+    if _is_multi(iv, kernel):
+        Z = iv.inducing_variable.Z
+        return np.stack([k.K(Z) for k in kernel.kernels]) + jitter * np.eye(Z.shape[0])
     K = kernel.K(iv.Z)
     return K + jitter * np.eye(K.shape[0])
 
 
 def Kuf(iv, kernel, Xnew):
-    """gpflow.covariances.Kuf [ext]: K(Z, Xnew) -> [M, N]."""
+    """gpflow.covariances.Kuf [ext]: K(Z, Xnew) -> [M, N], or [P, M, N] for separate kernels."""
+    if _is_multi(iv, kernel):
+        return np.stack([k.K(iv.inducing_variable.Z, Xnew) for k in kernel.kernels])
     return kernel.K(iv.Z, Xnew)
 
 
@@ -250,16 +290,31 @@ def base_conditional(Kmn, Kmm, Knn, f, q_sqrt=None, white=False):
 
 
 def conditional(Xnew, iv, kernel, f, q_sqrt=None, white=False):
-    """gpflow.conditionals.conditional (InducingPoints, Kernel) [ext]: jitter = default_jitter()."""
+    """gpflow.conditionals.conditional (InducingPoints, Kernel) [ext]: jitter = default_jitter().
+    For (SharedIndependentInducingVariables, SeparateIndependent) GPflow dispatches to
+    separate_independent_conditional [ext]: base_conditional per latent with its own Kmm / Kmn / Knn."""
     Kmm = Kuu(iv, kernel, jitter=DEFAULT_JITTER)
     Kmn = Kuf(iv, kernel, Xnew)
     Knn = kernel.K_diag(Xnew)
+    if _is_multi(iv, kernel):
+        outs = [base_conditional(Kmn[p], Kmm[p], Knn[:, p], f[:, p:p + 1],
+                                 q_sqrt=None if q_sqrt is None else q_sqrt[p:p + 1], white=white)
+                for p in range(len(kernel.kernels))]
+        return np.concatenate([o[0] for o in outs], axis=1), np.concatenate([o[1] for o in outs], axis=1)
     return base_conditional(Kmn, Kmm, Knn, f, q_sqrt=q_sqrt, white=white)
 
 
 def gauss_kl(q_mu, q_sqrt, K):
-    """gpflow.kullback_leiblers.gauss_kl [ext], dense K [M,M], q_sqrt [P,M,M]."""
+    """gpflow.kullback_leiblers.gauss_kl [ext], dense K [M,M] or one K per latent [P,M,M]; q_sqrt [P,M,M]."""
     M, P = q_mu.shape
+    if K.ndim == 3:  # is_batched: every latent against its own prior
+        Lp = _chol(K)  # [P,M,M]
+        alpha = _trsm(Lp, _T(q_mu)[..., None], lower=True)  # [P,M,1]
+        Lq = np.tril(q_sqrt)
+        LpiLq = _trsm(Lp, Lq, lower=True)
+        twoKL = np.sum(alpha * alpha) - float(M * P) - np.sum(np.log(np.square(np.diagonal(Lq, axis1=-2, axis2=-1))))
+        twoKL += np.sum(LpiLq * LpiLq) + np.sum(np.log(np.square(np.diagonal(Lp, axis1=-2, axis2=-1))))
+        return 0.5 * twoKL
     Lp = _chol(K)
     alpha = _trsm(Lp, q_mu, lower=True)
     Lq = np.tril(q_sqrt)
@@ -494,6 +549,8 @@ class t_SVGP:
         """:215-232."""
         K_uu = Kuu(self.inducing_variable, self.kernel, jitter=DEFAULT_JITTER)
         K_uf = Kuf(self.inducing_variable, self.kernel, Xnew)
+        if K_uu.ndim == 3:  # "todo : make broadcastable" (:214): the reference form is for one shared kernel
+            raise NotImplementedError("new_predict_f is not broadcastable over separate kernels in the reference")
         K_ff = self.kernel.K_diag(Xnew)[..., None]
         mu, var = conditional_from_precision_sites(K_uu, K_ff, K_uf, self.lambda_1, L=self.lambda_2_sqrt)
         if not np.all(var > 0):  # :231
@@ -530,7 +587,10 @@ class t_SVGP:
         X = np.asarray(X, dtype=np.float64)
         Y = np.asarray(Y, dtype=np.float64)
         mean, var = self.predict_f(X)  # :246
-        meanZ, _ = self.predict_f(self.inducing_variable.Z)  # :254
+        if isinstance(self.inducing_variable, SharedIndependentInducingVariables):  # :249-252
+            meanZ, _ = self.predict_f(self.inducing_variable.inducing_variables[0].Z)
+        else:
+            meanZ, _ = self.predict_f(self.inducing_variable.Z)  # :254
 
         g0, g1 = self.likelihood.variational_expectations_grads(mean, var, Y)  # :256-259
         eps = 1e-8
@@ -540,7 +600,7 @@ class t_SVGP:
         K_uu = Kuu(self.inducing_variable, self.kernel)  # :268 (no jitter)
         K_uf = Kuf(self.inducing_variable, self.kernel, X)  # :269
         chol_Kuu = _chol(K_uu + Id * jitter)  # :270
-        A = _chol_solve(chol_Kuu, K_uf).T  # :271  [N,M]
+        A = np.transpose(_chol_solve(chol_Kuu, K_uf))  # :271  [N,M], or [N,M,P] from [P,M,N] (tf.transpose reverses)
 
         if A.ndim == 2:
             A = np.tile(A[..., None], [1, 1, self.num_latent_gps])  # :276-277

@@ -6,14 +6,15 @@ The directory name carries a hyphen (as the project layout prescribes), so impor
 from . import _backend, distributed, util
 from ._backend import HipExtensionError, build_library
 from .base import Parameter, default_float, default_jitter
-from .inducing_variables import InducingPoints, inducingpoint_wrapper
-from .kernels import SquaredExponential
+from .inducing_variables import InducingPoints, SharedIndependentInducingVariables, inducingpoint_wrapper
+from .kernels import SeparateIndependent, SquaredExponential
 from .likelihoods import Bernoulli, Gaussian
 from .models import base_SVGP, t_SVGP
 from .sites import DenseSites, Sites
 
 __all__ = [
     "t_SVGP", "base_SVGP", "DenseSites", "Sites", "SquaredExponential", "Gaussian", "Bernoulli", "InducingPoints",
+    "SeparateIndependent", "SharedIndependentInducingVariables",
     "inducingpoint_wrapper", "Parameter", "default_float", "default_jitter", "HipExtensionError", "build_library",
     "distributed", "util",
 ]

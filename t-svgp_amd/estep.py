@@ -19,6 +19,7 @@ from typing import Optional
 import torch
 
 from . import _backend as B
+from .kernels import SeparateIndependent
 
 
 @dataclass
@@ -149,7 +150,9 @@ class EStepEngine:
         return out
 
     def kuu(self, Z: torch.Tensor, kernel) -> torch.Tensor:
-        """K(Z, Z) in fp64, [M, M] (no jitter)."""
+        """K(Z, Z) in fp64, [M, M] (no jitter); [P, M, M] for separate per-latent kernels."""
+        if isinstance(kernel, SeparateIndependent):
+            return torch.stack([self.kuu(Z, k) for k in kernel.kernels])
         Z = Z.to(device=self.device, dtype=torch.float64).contiguous()
         M, D = Z.shape
         Mp = B.round_up(M)
@@ -211,6 +214,32 @@ class EStepEngine:
                     "tsvgp_selftest_mfma")
         return a, b, c
 
+    def _run_separate(self, X, Y, Z, kernel, *, moment_Tm, gamma, whiten_T, want_grads, **kw) -> EStepStats:
+        """Separate per-latent kernels (K_uu [P, M, M]): one fill + moments + accumulation pass per latent, through the
+        same single-latent kernels and ONE K(X, Z) buffer (P of them would be 8.2 GB each at N = 1e6, M = 1024)."""
+        P = moment_Tm.shape[0]
+        if len(kernel.kernels) != P:
+            raise ValueError(f"{len(kernel.kernels)} kernels for {P} latent GPs")
+        if Y is not None and (Y.dim() != 2 or Y.shape[1] != P):
+            raise ValueError(f"Y must be [N, P] = [{X.shape[0]}, {P}], got {tuple(Y.shape)}")
+        parts = []
+        for p, kp in enumerate(kernel.kernels):
+            wt = None if whiten_T is None else (whiten_T[p] if whiten_T.dim() == 3 else whiten_T)
+            st = self.run(X, None if Y is None else Y[:, p:p + 1], Z, kp, moment_Tm=moment_Tm[p:p + 1],
+                          gamma=gamma[:, p:p + 1], whiten_T=wt, want_grads=want_grads, **kw)
+            if want_grads and st.g0 is not None:
+                st.g0, st.g1 = st.g0.clone(), st.g1.clone()  # views of a buffer the next latent overwrites
+            parts.append(st)
+
+        def cat(name, dim):
+            vals = [getattr(s, name) for s in parts]
+            return None if vals[0] is None else torch.cat(vals, dim=dim)
+
+        out = EStepStats(n_rows=parts[0].n_rows, ve_sum=sum(s.ve_sum for s in parts), nonpos=sum(s.nonpos for s in parts))
+        out.mean, out.var, out.g0, out.g1 = cat("mean", 1), cat("var", 1), cat("g0", 1), cat("g1", 1)
+        out.acc2, out.acc1 = cat("acc2", 0), cat("acc1", 0)
+        return out
+
     # ------------------------------------------------------------------ one N-pass
     def run(self, X, Y, Z, kernel, *, moment_Tm, moment_mode, gamma, lik_id=B.LIK_NONE, lik_param=0.0,
             whiten_T=None, whiten_mode=B.TRI_UPPER, sites=False, want_moments=False, want_grads=False,
@@ -227,6 +256,10 @@ class EStepEngine:
         by the previous call, the fill and the whitening are skipped and B is reused ("warm" E-step: consecutive
         E-steps with unchanged hyperparameters, as in the reference's E/M loop, experiments/uci_regression.py:152-153).
         """
+        if isinstance(kernel, SeparateIndependent):
+            return self._run_separate(X, Y, Z, kernel, moment_Tm=moment_Tm, moment_mode=moment_mode, gamma=gamma,
+                                      lik_id=lik_id, lik_param=lik_param, whiten_T=whiten_T, whiten_mode=whiten_mode,
+                                      sites=sites, want_moments=want_moments, want_grads=want_grads)
         T, dev = self.dtype, self.device
         X = X.to(device=dev, dtype=T).contiguous()
         Z = Z.to(device=dev, dtype=T).contiguous()

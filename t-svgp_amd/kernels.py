@@ -35,3 +35,31 @@ class SquaredExponential:
     def K_diag(self, X) -> torch.Tensor:
         X = to_tensor(X)
         return self.variance.value.expand(X.shape[0]).clone()
+
+
+class SeparateIndependent:
+    """``gpflow.kernels.SeparateIndependent`` [ext]: P independent latent GPs, one kernel each, no mixing matrix
+    (reference docs/notebooks/heteroskedastic.py:62-67).  Used with ``SharedIndependentInducingVariables``; the
+    E-step then carries K_uu as [P, M, M] (batched factorisations) and fills K(X, Z) once per latent."""
+
+    def __init__(self, kernels, name=None):
+        self.kernels = list(kernels)
+        if not self.kernels:
+            raise ValueError("SeparateIndependent needs at least one kernel")
+        self.name = name or "separate_independent"
+
+    @property
+    def num_latent_gps(self) -> int:
+        return len(self.kernels)
+
+    def K_diag(self, X) -> torch.Tensor:
+        return torch.stack([k.K_diag(X) for k in self.kernels], dim=1)  # [N, P]
+
+
+def latent_kernels(kernel, P: int):
+    """The list of per-latent kernels behind ``kernel``: P references to one shared kernel, or the separate ones."""
+    if isinstance(kernel, SeparateIndependent):
+        if len(kernel.kernels) != P:
+            raise ValueError(f"SeparateIndependent has {len(kernel.kernels)} kernels but the model has {P} latent GPs")
+        return kernel.kernels
+    return [kernel] * P

@@ -35,6 +35,7 @@ from .. import _backend as B
 from .. import distributed as D_
 from ..base import default_device, default_float, default_jitter, to_tensor
 from ..inducing_variables import inducingpoint_wrapper
+from ..kernels import SeparateIndependent, latent_kernels
 from ..sites import DenseSites
 from ..util import (
     cholesky_deferred,
@@ -43,6 +44,16 @@ from ..util import (
     posterior_from_dense_site,
     rev_cholesky,
 )
+
+
+def _kmv(K: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
+    """K v per latent: K [M, M] (shared kernel) or [P, M, M] (separate kernels), v [M, P] -> [M, P]."""
+    return K @ v if K.dim() == 2 else torch.einsum("pmk,kp->mp", K, v)
+
+
+def _ktmv(K: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
+    """K^T v per latent (shapes as ``_kmv``)."""
+    return K.transpose(-1, -2) @ v if K.dim() == 2 else torch.einsum("pkm,kp->mp", K, v)
 
 
 class base_SVGP(abc.ABC):
@@ -152,9 +163,14 @@ class t_SVGP(base_SVGP):
         """Cache key of everything B = K(X, Z) U9^-T depends on; None when caching is off or X is not a device tensor."""
         if not self.cache_whitened or not isinstance(X, torch.Tensor) or X.device != self.device:
             return None
-        k = self.kernel
-        return (X.data_ptr(), tuple(X.shape), X._version, X.dtype, k.variance.version, k.lengthscales.version,
+        if isinstance(self.kernel, SeparateIndependent):
+            return None  # one K(X, Z) buffer serves the latents in turn: nothing N-sized survives the call
+        return (X.data_ptr(), tuple(X.shape), X._version, X.dtype, self._kernel_versions(),
                 id(self.inducing_variable.Z), self.inducing_variable.Z.version, float(jitter), self.compute_dtype)
+
+    def _kernel_versions(self):
+        return tuple((id(k), k.variance.version, k.lengthscales.version)
+                     for k in latent_kernels(self.kernel, self.num_latent_gps))
 
     # The direct route's error grows like cond(K_uu)^2 eps (K^-1 (sum g k k^T) K^-1 cancels two factors of K):
     # cond <= 1e3 keeps it <= ~1e-9 relative in fp64, cond <= 30 <= ~1e-4 in fp32 (the stated tolerances).
@@ -165,14 +181,12 @@ class t_SVGP(base_SVGP):
         (symmetric eigenvalues, M x M, one host read) only when the kernel parameters, Z or the jitter changed."""
         if self.projection != "auto":
             return self.projection == "direct"
-        k = self.kernel
-        key = (k.variance.version, k.lengthscales.version, id(self.inducing_variable.Z), self.inducing_variable.Z.version,
-               float(jitter))
+        key = (self._kernel_versions(), id(self.inducing_variable.Z), self.inducing_variable.Z.version, float(jitter))
         if self._cond_cache is None or self._cond_cache[0] != key:
-            Kzz = self._get_engine().kuu(self._Z(), self.kernel)
-            ev = torch.linalg.eigvalsh(Kzz + jitter * torch.eye(Kzz.shape[0], dtype=Kzz.dtype, device=Kzz.device))
-            lo, hi = float(ev[0]), float(ev[-1])
-            cond = hi / lo if lo > 0 else float("inf")
+            Kzz = self._get_engine().kuu(self._Z(), self.kernel)  # [M, M] or [P, M, M]
+            ev = torch.linalg.eigvalsh(Kzz + jitter * torch.eye(Kzz.shape[-1], dtype=Kzz.dtype, device=Kzz.device))
+            lo, hi = ev[..., 0], ev[..., -1]
+            cond = float(torch.where(lo > 0, hi / lo, torch.full_like(lo, float("inf"))).max())  # worst latent
             self._cond_cache = (key, cond)
         return self._cond_cache[1] <= self.DIRECT_MAX_COND[self.compute_dtype]
 
@@ -206,14 +220,17 @@ class t_SVGP(base_SVGP):
             U9, Uinv9 = warm[1]["U9"], warm[1]["Uinv9"]
             U_W, Uinv_W = rev_cholesky(W, infos, potrf, inverse=True)
         elif whiten_jitter is not None:
-            both, inv_both = rev_cholesky(torch.cat([W, (Kzz + whiten_jitter * Id)[None]], dim=0), infos, potrf,
+            K9 = Kzz + whiten_jitter * Id
+            both, inv_both = rev_cholesky(torch.cat([W, K9 if K9.dim() == 3 else K9[None]], dim=0), infos, potrf,
                                           inverse=True)
-            U_W, U9, Uinv_W, Uinv9 = both[:-1], both[-1], inv_both[:-1], inv_both[-1]
+            P_ = W.shape[0]
+            U_W, Uinv_W = both[:P_], inv_both[:P_]
+            U9, Uinv9 = (both[P_:], inv_both[P_:]) if K9.dim() == 3 else (both[-1], inv_both[-1])
         else:
             U9, Uinv9 = None, None
             U_W, Uinv_W = rev_cholesky(W, infos, potrf, inverse=True)
         Dm = (Uinv_W @ L.transpose(-1, -2)).triu()  # D = U_W^-1 L^T, [P, M, M], upper triangular
-        DKl = torch.einsum("pmk,kp->pm", Dm, K6 @ l1)
+        DKl = torch.einsum("pmk,kp->pm", Dm, _kmv(K6, l1))
         beta = l1 - torch.einsum("pkm,pk->mp", Dm, DKl)  # K6^-1 m = l1 - D^T D K6 l1
         ops = dict(Z=Z, Kzz=Kzz, K6=K6, D=Dm, U_W=U_W, beta=beta, Id=Id, infos=infos, potrf=potrf, direct=False,
                    moment_mode=B.TRI_UPPER, whiten_mode=B.TRI_UPPER, whiten_T=None)
@@ -228,7 +245,7 @@ class t_SVGP(base_SVGP):
             ops["direct"], ops["gamma"], ops["moment_Tm"] = True, beta, Dm
         else:
             ops["whiten_T"] = Uinv9  # B = K_fu U9^-T
-            ops["gamma"] = U9.transpose(-1, -2) @ beta  # mean = k^T beta = b^T U9^T beta with b = U9^-1 k
+            ops["gamma"] = _ktmv(U9, beta)  # mean = k^T beta = b^T U9^T beta with b = U9^-1 k
             ops["moment_Tm"] = (Dm @ U9).triu()  # var = knn - |D k|^2 = knn - |T b|^2
         return ops
 
@@ -255,7 +272,7 @@ class t_SVGP(base_SVGP):
         """Mean and Cholesky factor of q(u) = N(u; m, S) (tsvgp.py:202-212)."""
         eng = self._get_engine()
         Kzz = eng.kuu(self._Z(), self.kernel)
-        K_uu = Kzz + default_jitter() * torch.eye(Kzz.shape[0], dtype=Kzz.dtype, device=Kzz.device)
+        K_uu = Kzz + default_jitter() * torch.eye(Kzz.shape[-1], dtype=Kzz.dtype, device=Kzz.device)
         return posterior_from_dense_site(K_uu, self.lambda_1.value, self.lambda_2_sqrt.value)
 
     def prior_kl(self):
@@ -288,6 +305,9 @@ class t_SVGP(base_SVGP):
         """Same moments straight from the sites: var = knn - |D k|^2 (tsvgp.py:215-232, util.py:91-185)."""
         if full_cov or full_output_cov:
             raise NotImplementedError("full covariances are not on the E-step hot path")
+        if isinstance(self.kernel, SeparateIndependent):
+            # "todo : make broadcastable" (tsvgp.py:214): the reference form only covers one shared kernel
+            raise NotImplementedError("new_predict_f is not broadcastable over separate kernels in the reference")
         ops = self._site_operands()
         st = self._get_engine().run(self._as_device(Xnew), None, ops["Z"], self.kernel, moment_Tm=ops["D"],
                                     moment_mode=ops["moment_mode"], gamma=ops["beta"], want_moments=True)
@@ -372,13 +392,13 @@ class t_SVGP(base_SVGP):
             # small batched right-hand sides on this ROCm build -- tools/check_cholesky_solve.py)
             K9inv = Uinv9t @ Uinv9
             G1 = K9inv @ acc2 @ K9inv
-            G0 = K9inv @ acc1.transpose(-1, -2)  # [M, P]
+            G0 = _kmv(K9inv, acc1.transpose(-1, -2))  # [M, P]
         else:
             # G1 = U9^-T acc2 U9^-1,  G0 = U9^-T acc1   (tsvgp.py:279-280 in whitened coordinates)
             G1 = Uinv9t @ acc2 @ Uinv9
-            G0 = Uinv9t @ acc1.transpose(-1, -2)  # [M, P]
+            G0 = _kmv(Uinv9t, acc1.transpose(-1, -2))  # [M, P]
         G1 = 0.5 * (G1 + G1.transpose(-1, -2))
-        meanZ = Kzz @ beta  # predict_f(Z) mean, tsvgp.py:249-254
+        meanZ = _kmv(Kzz, beta)  # predict_f(Z) mean, tsvgp.py:249-254 (per latent kernel for separate kernels)
         grad_mu = gradient_transformation_mean_var_to_expectation(meanZ, [G0, G1])  # tsvgp.py:284
 
         # tsvgp.py:286-291; `rows` = global number of rows, a device scalar (no synchronisation)

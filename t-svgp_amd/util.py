@@ -129,7 +129,7 @@ def kl_from_dense_site(K, lambda_1, D, chol_W, beta):
     which make gpflow.kullback_leiblers.gauss_kl (reference tsvgp.py:65-70) computable without chol(S):
         KL = 1/2 sum_p [ m_p^T beta_p - tr(D_p K D_p^T) + log|W_p| ].
     """
-    m = K @ beta  # [M, P]
+    m = K @ beta if K.dim() == 2 else torch.einsum("pmk,kp->mp", K, beta)  # [M, P]; K [P, M, M]: one prior per latent
     maha = torch.sum(m * beta)
     trace = torch.sum(D * (D @ K))
     logdetW = 2.0 * torch.sum(torch.log(torch.diagonal(chol_W, dim1=-2, dim2=-1)))

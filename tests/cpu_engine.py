@@ -14,11 +14,26 @@ class _Stats:
 
 class NumpyShardEngine:
     def kuu(self, Z, kernel):
+        if hasattr(kernel, "kernels"):  # SeparateIndependent: [P, M, M]
+            return torch.stack([self.kuu(Z, k) for k in kernel.kernels])
         k = O.SquaredExponential(variance=float(kernel.variance.value), lengthscales=kernel.lengthscales.numpy())
         return torch.as_tensor(k.K(Z.cpu().numpy()))
 
     def run(self, X, Y, Z, kernel, *, moment_Tm, moment_mode, gamma, lik_id=0, lik_param=0.0, whiten_T=None,
             whiten_mode=1, sites=False, want_moments=False, want_grads=False, b_tag=None):
+        if hasattr(kernel, "kernels"):  # one pass per latent, as EStepEngine._run_separate
+            parts = [self.run(X, None if Y is None else Y[:, p:p + 1], Z, kp, moment_Tm=moment_Tm[p:p + 1],
+                              moment_mode=moment_mode, gamma=gamma[:, p:p + 1], lik_id=lik_id, lik_param=lik_param,
+                              whiten_T=None if whiten_T is None else (whiten_T[p] if whiten_T.dim() == 3 else whiten_T),
+                              whiten_mode=whiten_mode, sites=sites, want_moments=want_moments, want_grads=want_grads)
+                     for p, kp in enumerate(kernel.kernels)]
+            st = _Stats()
+            st.n_rows = parts[0].n_rows
+            st.nonpos, st.ve_sum = sum(s.nonpos for s in parts), sum(s.ve_sum for s in parts)
+            for name, dim in (("mean", 1), ("var", 1), ("g0", 1), ("g1", 1), ("acc2", 0), ("acc1", 0)):
+                vals = [getattr(s, name) for s in parts]
+                setattr(st, name, None if vals[0] is None else torch.cat(vals, dim=dim))
+            return st
         k = O.SquaredExponential(variance=float(kernel.variance.value), lengthscales=kernel.lengthscales.numpy())
         Xn, Zn = X.cpu().numpy(), Z.cpu().numpy()
         A = k.K(Xn, Zn)

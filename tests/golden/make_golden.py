@@ -24,6 +24,9 @@ CASES = {
     "gaussian_d3_p2": (160, 12, 3, 2, "gaussian", 1.0, 1.0, 0.1, 0.8),
     "bernoulli_d2_p1": (160, 12, 2, 1, "bernoulli", 1.0, 1.5, None, 0.8),
     "bernoulli_d2_p2": (120, 10, 2, 2, "bernoulli", 0.8, 1.0, None, 1.0),
+    # separate per-latent kernels on shared inducing points (SeparateIndependent + SharedIndependentInducingVariables,
+    # reference docs/notebooks/heteroskedastic.py:62-74): the lengthscale entry is one value per latent
+    "gaussian_d3_p3_separate": (160, 12, 3, 3, "gaussian", (0.8, 1.1, 1.5), 1.0, 0.1, 0.8),
 }
 STEPS = (1, 2, 10)
 
@@ -41,10 +44,16 @@ def make_case(name):
         eps = rng.randn(N, P)
         Y = f + np.sqrt(0.1) * eps if lik == "gaussian" else (f + np.sqrt(0.1) * eps > 0).astype(np.float64)
         Z = X[:M].copy()
-    model = O.t_SVGP(O.SquaredExponential(variance=var, lengthscales=ls),
-                     O.Gaussian(variance=noise) if lik == "gaussian" else O.Bernoulli(), Z, num_latent_gps=P)
-    out = dict(X=X, Y=Y, Z=Z, lengthscales=ls, variance=var, noise=-1.0 if noise is None else noise, lr=lr,
-               likelihood=lik, P=P, steps=np.array(STEPS))
+    separate = isinstance(ls, tuple)
+    if separate:
+        kernel = O.SeparateIndependent([O.SquaredExponential(variance=var, lengthscales=l) for l in ls])
+        iv = O.SharedIndependentInducingVariables(Z)
+    else:
+        kernel, iv = O.SquaredExponential(variance=var, lengthscales=ls), Z
+    model = O.t_SVGP(kernel, O.Gaussian(variance=noise) if lik == "gaussian" else O.Bernoulli(), iv, num_latent_gps=P)
+    out = dict(X=X, Y=Y, Z=Z, lengthscales=np.asarray(ls, dtype=np.float64), variance=var,
+               noise=-1.0 if noise is None else noise, lr=lr, likelihood=lik, P=P, steps=np.array(STEPS),
+               separate=int(separate))
     Xs = X[: min(N, 50)] + 0.05
     for step in range(1, max(STEPS) + 1):
         model.natgrad_step((X, Y), lr=lr)

@@ -12,10 +12,13 @@ FIXTURES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*
 
 
 def load_model(fx, module):
-    lik = str(fx["likelihood"])
+    lik = module.Gaussian(variance=float(fx["noise"])) if str(fx["likelihood"]) == "gaussian" else module.Bernoulli()
+    if "separate" in fx.files and int(fx["separate"]):  # one kernel per latent on shared inducing points
+        kernel = module.SeparateIndependent([module.SquaredExponential(variance=float(fx["variance"]), lengthscales=float(l))
+                                             for l in fx["lengthscales"]])
+        return module.t_SVGP(kernel, lik, module.SharedIndependentInducingVariables(fx["Z"]), num_latent_gps=int(fx["P"]))
     return module.t_SVGP(module.SquaredExponential(variance=float(fx["variance"]), lengthscales=float(fx["lengthscales"])),
-                         module.Gaussian(variance=float(fx["noise"])) if lik == "gaussian" else module.Bernoulli(),
-                         fx["Z"], num_latent_gps=int(fx["P"]))
+                         lik, fx["Z"], num_latent_gps=int(fx["P"]))
 
 
 @pytest.mark.parametrize("path", FIXTURES, ids=[os.path.basename(p)[:-4] for p in FIXTURES])
@@ -31,4 +34,4 @@ def test_oracle_reproduces_fixture(path):
             np.testing.assert_allclose(model.lambda_2, fx[f"s{step}_lambda_2_sqrt"] @ np.swapaxes(fx[f"s{step}_lambda_2_sqrt"], -1, -2),
                                        rtol=1e-9, atol=1e-12)
             np.testing.assert_allclose(model.elbo((X, Y)), fx[f"s{step}_elbo"], rtol=1e-10)
-    assert len(FIXTURES) >= 4
+    assert len(FIXTURES) >= 5

@@ -31,9 +31,10 @@ def test_hip_matches_fixture(path):
                                          sites=True, want_moments=True, want_grads=True)
             for key, val in (("mean", st.mean), ("var", st.var), ("g0", st.g0), ("g1", st.g1)):
                 assert relerr(val.cpu().numpy(), fx[f"s{step}_{key}"]) < 1e-8, (step, key)
-            U9 = ops["U9"].cpu().numpy()
-            G1 = np.stack([np.linalg.solve(U9.T, np.linalg.solve(U9.T, a).T).T for a in st.acc2.cpu().numpy()])
-            G0 = np.linalg.solve(U9.T, st.acc1.cpu().numpy().T)
+            acc2, acc1 = st.acc2.cpu().numpy(), st.acc1.cpu().numpy()
+            U9 = np.broadcast_to(ops["U9"].cpu().numpy(), acc2.shape)  # one factor per latent for separate kernels
+            G1 = np.stack([np.linalg.solve(u.T, np.linalg.solve(u.T, a).T).T for u, a in zip(U9, acc2)])
+            G0 = np.stack([np.linalg.solve(u.T, a) for u, a in zip(U9, acc1)], axis=1)
             assert relerr(G1, fx[f"s{step}_G1"]) < 1e-8 and relerr(G0, fx[f"s{step}_G0"]) < 1e-8
         model.natgrad_step((X, Y), lr=lr)
         if step in steps:

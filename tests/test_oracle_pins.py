@@ -283,3 +283,44 @@ def test_gauss_kl_against_closed_form():
         kl += 0.5 * (np.trace(Kinv @ S) + q_mu[:, p] @ Kinv @ q_mu[:, p] - M
                      + np.linalg.slogdet(K)[1] - np.linalg.slogdet(S)[1])
     np.testing.assert_allclose(O.gauss_kl(q_mu, q_sqrt, K), kl, rtol=1e-12)
+
+
+def test_separate_kernels_are_independent_models():
+    """[ext] restatement check for (SharedIndependentInducingVariables, SeparateIndependent), the layout of
+    docs/notebooks/heteroskedastic.py:62-76: with a likelihood that factorises over outputs, P separate kernels on
+    shared inducing points are P independent single-output t-SVGPs (natgrad_step :234-304 is per latent: rank-3 A
+    at :271-277, batched K_uu in util.py:367), and with identical kernels they equal the shared-kernel model."""
+    rng = np.random.RandomState(3)
+    N, M, D, P = 150, 12, 2, 3
+    X = rng.randn(N, D)
+    Z = X[:M].copy()
+    Y = np.sin(X @ rng.randn(D, P)) + 0.3 * rng.randn(N, P)
+    ls = [0.8, 1.0, 1.3]
+
+    def sep(lengths):
+        return O.t_SVGP(O.SeparateIndependent([O.SquaredExponential(1.0, l) for l in lengths]), O.Gaussian(0.1),
+                        O.SharedIndependentInducingVariables(Z), num_latent_gps=P, num_data=N)
+
+    mm = sep(ls)
+    for _ in range(3):
+        mm.natgrad_step((X, Y), lr=0.8)
+    total = 0.0
+    for p in range(P):
+        m1 = O.t_SVGP(O.SquaredExponential(1.0, ls[p]), O.Gaussian(0.1), Z, num_data=N)
+        for _ in range(3):
+            m1.natgrad_step((X, Y[:, p:p + 1]), lr=0.8)
+        np.testing.assert_allclose(mm.lambda_1[:, p], m1.lambda_1[:, 0], rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose(mm.lambda_2[p], m1.lambda_2[0], rtol=1e-7, atol=1e-9)
+        mu, var = m1.predict_f(X[:10])
+        mum, varm = mm.predict_f(X[:10])
+        np.testing.assert_allclose(mum[:, p], mu[:, 0], rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose(varm[:, p], var[:, 0], rtol=1e-7, atol=1e-9)
+        total += m1.elbo((X, Y[:, p:p + 1]))
+    assert abs(total - mm.elbo((X, Y))) < 1e-7 * abs(total)
+    shared = O.t_SVGP(O.SquaredExponential(1.0, 1.0), O.Gaussian(0.1), Z, num_latent_gps=P, num_data=N)
+    same = sep([1.0] * P)
+    for _ in range(3):
+        shared.natgrad_step((X, Y), lr=0.8)
+        same.natgrad_step((X, Y), lr=0.8)
+    np.testing.assert_allclose(same.lambda_1, shared.lambda_1, rtol=1e-7, atol=1e-9)
+    assert abs(same.elbo((X, Y)) - shared.elbo((X, Y))) < 1e-8 * abs(shared.elbo((X, Y)))
