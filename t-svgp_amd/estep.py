@@ -224,7 +224,10 @@ class EStepEngine:
             raise ValueError(f"Y must be [N, P] = [{X.shape[0]}, {P}], got {tuple(Y.shape)}")
         parts = []
         for p, kp in enumerate(kernel.kernels):
-            wt = None if whiten_T is None else (whiten_T[p] if whiten_T.dim() == 3 else whiten_T)
+            if isinstance(whiten_T, (list, tuple)):  # per-latent routes: None = this latent works on K_fu directly
+                wt = whiten_T[p]
+            else:
+                wt = None if whiten_T is None else (whiten_T[p] if whiten_T.dim() == 3 else whiten_T)
             st = self.run(X, None if Y is None else Y[:, p:p + 1], Z, kp, moment_Tm=moment_Tm[p:p + 1],
                           gamma=gamma[:, p:p + 1], whiten_T=wt, want_grads=want_grads, **kw)
             if want_grads and st.g0 is not None:

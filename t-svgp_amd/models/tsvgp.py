@@ -176,19 +176,21 @@ class t_SVGP(base_SVGP):
     # cond <= 1e3 keeps it <= ~1e-9 relative in fp64, cond <= 30 <= ~1e-4 in fp32 (the stated tolerances).
     DIRECT_MAX_COND = {torch.float64: 1.0e3, torch.float32: 30.0}
 
-    def _use_direct(self, jitter) -> bool:
-        """Chooses the projection route.  In "auto" mode the 2-norm condition number of K_uu + jitter I is computed
-        (symmetric eigenvalues, M x M, one host read) only when the kernel parameters, Z or the jitter changed."""
+    def _use_direct(self, jitter) -> list:
+        """Chooses the projection route, per latent GP (one decision for all latents under a shared kernel).  In "auto"
+        mode the 2-norm condition number of K_uu + jitter I is computed (symmetric eigenvalues, M x M, one host read)
+        only when the kernel parameters, Z or the jitter changed."""
+        P = self.num_latent_gps
         if self.projection != "auto":
-            return self.projection == "direct"
+            return [self.projection == "direct"] * P
         key = (self._kernel_versions(), id(self.inducing_variable.Z), self.inducing_variable.Z.version, float(jitter))
         if self._cond_cache is None or self._cond_cache[0] != key:
             Kzz = self._get_engine().kuu(self._Z(), self.kernel)  # [M, M] or [P, M, M]
             ev = torch.linalg.eigvalsh(Kzz + jitter * torch.eye(Kzz.shape[-1], dtype=Kzz.dtype, device=Kzz.device))
             lo, hi = ev[..., 0], ev[..., -1]
-            cond = float(torch.where(lo > 0, hi / lo, torch.full_like(lo, float("inf"))).max())  # worst latent
-            self._cond_cache = (key, cond)
-        return self._cond_cache[1] <= self.DIRECT_MAX_COND[self.compute_dtype]
+            cond = torch.where(lo > 0, hi / lo, torch.full_like(lo, float("inf"))).reshape(-1).tolist()
+            self._cond_cache = (key, cond if len(cond) == P else cond * P)
+        return [c <= self.DIRECT_MAX_COND[self.compute_dtype] for c in self._cond_cache[1]]
 
     def _site_operands(self, whiten_jitter=None, warm_key=None, direct=False):
         """Everything the N-pass needs that depends only on (theta, Z, lambda): O(M^3), fp64, replicated.
@@ -232,21 +234,30 @@ class t_SVGP(base_SVGP):
         Dm = (Uinv_W @ L.transpose(-1, -2)).triu()  # D = U_W^-1 L^T, [P, M, M], upper triangular
         DKl = torch.einsum("pmk,kp->pm", Dm, _kmv(K6, l1))
         beta = l1 - torch.einsum("pkm,pk->mp", Dm, DKl)  # K6^-1 m = l1 - D^T D K6 l1
-        ops = dict(Z=Z, Kzz=Kzz, K6=K6, D=Dm, U_W=U_W, beta=beta, Id=Id, infos=infos, potrf=potrf, direct=False,
-                   moment_mode=B.TRI_UPPER, whiten_mode=B.TRI_UPPER, whiten_T=None)
+        ops = dict(Z=Z, Kzz=Kzz, K6=K6, D=Dm, U_W=U_W, beta=beta, Id=Id, infos=infos, potrf=potrf,
+                   direct=[False] * self.num_latent_gps, moment_mode=B.TRI_UPPER, whiten_mode=B.TRI_UPPER, whiten_T=None)
         if whiten_jitter is None:
             return ops
         ops["U9"], ops["Uinv9"] = U9, Uinv9  # K_uu + jitter I = U9 U9^T, tsvgp.py:268-270
         if warm_key is not None and not warm:
             self._warm = (warm_key, dict(Kzz=Kzz, U9=U9, Uinv9=Uinv9))
-        if direct:
+        direct = [bool(direct)] * self.num_latent_gps if isinstance(direct, bool) else [bool(d) for d in direct]
+        ops["direct"] = direct
+        if all(direct):
             # direct projection: the moments act on K_fu with D itself, the sums are mapped by K9^-1 (.) K9^-1
             # afterwards; no N-sized whitening
-            ops["direct"], ops["gamma"], ops["moment_Tm"] = True, beta, Dm
+            ops["gamma"], ops["moment_Tm"] = beta, Dm
         else:
-            ops["whiten_T"] = Uinv9  # B = K_fu U9^-T
-            ops["gamma"] = _ktmv(U9, beta)  # mean = k^T beta = b^T U9^T beta with b = U9^-1 k
-            ops["moment_Tm"] = (Dm @ U9).triu()  # var = knn - |D k|^2 = knn - |T b|^2
+            gamma_w = _ktmv(U9, beta)  # mean = k^T beta = b^T U9^T beta with b = U9^-1 k
+            T_w = (Dm @ U9).triu()  # var = knn - |D k|^2 = knn - |T b|^2
+            if not any(direct):
+                ops["whiten_T"], ops["gamma"], ops["moment_Tm"] = Uinv9, gamma_w, T_w  # B = K_fu U9^-T
+            else:
+                # separate kernels, some latents well conditioned and some not: each latent takes its own route
+                sel = torch.tensor(direct, device=Dm.device)
+                ops["gamma"] = torch.where(sel[None, :], beta, gamma_w)
+                ops["moment_Tm"] = torch.where(sel[:, None, None], Dm, T_w)
+                ops["whiten_T"] = [None if d else Uinv9[p] for p, d in enumerate(direct)]
         return ops
 
     def _check_step(self, ops, nonpos, extra_infos=(), soft_final=False):
@@ -350,7 +361,8 @@ class t_SVGP(base_SVGP):
         X, Y = self._as_device(data[0]), self._as_device(data[1])
         old_l1, old_L = self.lambda_1.value, self.lambda_2_sqrt.value
         direct = self._use_direct(jitter)
-        for use_direct in ((True, False) if direct else (False,)):  # the whitened route is the fallback of the direct one
+        none = [False] * self.num_latent_gps
+        for use_direct in ((direct, none) if any(direct) else (none,)):  # all-whitened is the fallback of any direct latent
             warm_key = self._warm_key(X, jitter)
             ops = self._site_operands(whiten_jitter=jitter, warm_key=warm_key, direct=use_direct)
             st = self._get_engine().run(X, Y, ops["Z"], self.kernel, moment_Tm=ops["moment_Tm"],
@@ -359,7 +371,7 @@ class t_SVGP(base_SVGP):
                                         whiten_T=ops["whiten_T"], whiten_mode=ops["whiten_mode"], sites=True,
                                         b_tag=warm_key)
             try:
-                verdict = self._apply_site_update(st, ops, lr, jitter, soft_final=use_direct)
+                verdict = self._apply_site_update(st, ops, lr, jitter, soft_final=any(use_direct))
             except FloatingPointError:
                 self.lambda_1.assign(old_l1)  # the reference raises before its assigns: leave the state untouched
                 self.sites.assign_lambda_2_sqrt(old_L)
@@ -372,7 +384,7 @@ class t_SVGP(base_SVGP):
             self.lambda_1.assign(old_l1)
             self.sites.assign_lambda_2_sqrt(old_L)
             if self._cond_cache is not None:
-                self._cond_cache = (self._cond_cache[0], float("inf"))
+                self._cond_cache = (self._cond_cache[0], [float("inf")] * self.num_latent_gps)
         raise FloatingPointError("Cholesky decomposition was not successful (matrix not positive definite)")
 
     def _apply_site_update(self, st, ops, lr, jitter, soft_final=False):
@@ -386,17 +398,24 @@ class t_SVGP(base_SVGP):
 
         Uinv9, Kzz, beta = ops["Uinv9"], ops["Kzz"], ops["beta"]
         Uinv9t = Uinv9.transpose(-1, -2)
-        if ops["direct"]:
+        direct = ops["direct"]
+        G1 = G0 = None
+        if any(direct):
             # direct projection: acc2 = sum g1 k k^T, acc1 = sum g0 k  ->  G1 = K9^-1 acc2 K9^-1, G0 = K9^-1 acc1
             # (K9^-1 = U9^-T U9^-1 applied as GEMMs; torch.cholesky_solve is not an option: it returned wrong values for
             # small batched right-hand sides on this ROCm build -- tools/check_cholesky_solve.py)
             K9inv = Uinv9t @ Uinv9
             G1 = K9inv @ acc2 @ K9inv
             G0 = _kmv(K9inv, acc1.transpose(-1, -2))  # [M, P]
-        else:
+        if not all(direct):
             # G1 = U9^-T acc2 U9^-1,  G0 = U9^-T acc1   (tsvgp.py:279-280 in whitened coordinates)
-            G1 = Uinv9t @ acc2 @ Uinv9
-            G0 = _kmv(Uinv9t, acc1.transpose(-1, -2))  # [M, P]
+            G1w = Uinv9t @ acc2 @ Uinv9
+            G0w = _kmv(Uinv9t, acc1.transpose(-1, -2))  # [M, P]
+            if G1 is None:
+                G1, G0 = G1w, G0w
+            else:  # mixed routes (separate kernels): every latent keeps the form its sums were taken in
+                sel = torch.tensor(direct, device=G1.device)
+                G1, G0 = torch.where(sel[:, None, None], G1, G1w), torch.where(sel[None, :], G0, G0w)
         G1 = 0.5 * (G1 + G1.transpose(-1, -2))
         meanZ = _kmv(Kzz, beta)  # predict_f(Z) mean, tsvgp.py:249-254 (per latent kernel for separate kernels)
         grad_mu = gradient_transformation_mean_var_to_expectation(meanZ, [G0, G1])  # tsvgp.py:284

@@ -24,7 +24,8 @@ class NumpyShardEngine:
         if hasattr(kernel, "kernels"):  # one pass per latent, as EStepEngine._run_separate
             parts = [self.run(X, None if Y is None else Y[:, p:p + 1], Z, kp, moment_Tm=moment_Tm[p:p + 1],
                               moment_mode=moment_mode, gamma=gamma[:, p:p + 1], lik_id=lik_id, lik_param=lik_param,
-                              whiten_T=None if whiten_T is None else (whiten_T[p] if whiten_T.dim() == 3 else whiten_T),
+                              whiten_T=(whiten_T[p] if isinstance(whiten_T, (list, tuple)) else None if whiten_T is None
+                                        else (whiten_T[p] if whiten_T.dim() == 3 else whiten_T)),
                               whiten_mode=whiten_mode, sites=sites, want_moments=want_moments, want_grads=want_grads)
                      for p, kp in enumerate(kernel.kernels)]
             st = _Stats()

@@ -253,10 +253,32 @@ def test_auto_projection_gate():
     rng = np.random.RandomState(12)
     well = p.t_SVGP(p.SquaredExponential(1.0, 1.0), p.Gaussian(0.1), rng.randn(50, 8) * 2.0)
     ill = p.t_SVGP(p.SquaredExponential(1.0, 2.0), p.Gaussian(0.1), rng.rand(50, 1) * 2 - 1)  # test_tsvgp.py geometry
-    assert well._use_direct(1e-9) and not ill._use_direct(1e-9)
-    assert well._cond_cache[1] < 1e3 and ill._cond_cache[1] > 1e6
+    assert well._use_direct(1e-9) == [True] and ill._use_direct(1e-9) == [False]
+    assert well._cond_cache[1][0] < 1e3 and ill._cond_cache[1][0] > 1e6
     well.kernel.lengthscales.assign(50.0)  # nearly constant kernel: the cached decision must be re-evaluated
-    assert not well._use_direct(1e-9)
+    assert well._use_direct(1e-9) == [False]
+
+
+def test_separate_kernels_mixed_routes():
+    """With separate kernels "auto" decides per latent: a short-lengthscale latent takes the direct route, a
+    long-lengthscale one (ill-conditioned K_uu) the whitened route, inside the same step; result against the oracle."""
+    p = pkg()
+    rng = np.random.RandomState(22)
+    P, M, D = 3, 40, 4
+    X, Y, _ = synthetic(N=800, M=M, D=D, P=P, lik="gaussian", seed=9)
+    Z = rng.randn(M, D) * 1.5
+    ls = [0.7, 6.0, 1.0]
+    hip = p.t_SVGP(p.SeparateIndependent([p.SquaredExponential(1.0, l) for l in ls]), p.Gaussian(0.1),
+                   p.SharedIndependentInducingVariables(Z), num_latent_gps=P)
+    ora = O.t_SVGP(O.SeparateIndependent([O.SquaredExponential(1.0, l) for l in ls]), O.Gaussian(0.1),
+                   O.SharedIndependentInducingVariables(Z), num_latent_gps=P)
+    assert hip._use_direct(1e-9) == [True, False, True]
+    for _ in range(4):
+        hip.natgrad_step((X, Y), lr=0.8)
+        ora.natgrad_step((X, Y), lr=0.8)
+        _compare_state(hip, ora, 1e-8)
+    e_h, e_o = float(hip.elbo((X, Y))), float(ora.elbo((X, Y)))
+    assert abs(e_h - e_o) / abs(e_o) < 1e-9
 
 
 @pytest.mark.parametrize("projection", ["whitened", "direct"])
