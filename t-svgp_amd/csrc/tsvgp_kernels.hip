@@ -280,8 +280,13 @@ __global__ __launch_bounds__(NTHREADS) void se_fill_kernel(const T* __restrict__
         }
         pair_t out;
         const bool rowok = (n < N);
+#ifdef TSVGP_EXP_NOEXP  // ablation switch (tools/exp_fill.py): the store-bound floor of the kernel
+        out[0] = (rowok && v0) ? variance * (T(1) - T(0.5) * s0) : T(0);
+        out[1] = (rowok && v1) ? variance * (T(1) - T(0.5) * s1) : T(0);
+#else
         out[0] = (rowok && v0) ? variance * exp(T(-0.5) * s0) : T(0);
         out[1] = (rowok && v1) ? variance * exp(T(-0.5) * s1) : T(0);
+#endif
         *reinterpret_cast<pair_t*>(K + n * ldk + m) = out;
     }
 }
