@@ -61,6 +61,19 @@ int tsvgp_se_fill_f64(const double *X, const double *Z, const double *inv_ls, do
 int tsvgp_se_fill_f32(const float *X, const float *Z, const float *inv_ls, float variance, float *K, int64_t N, int M,
                       int D, int64_t ldk, void *stream);
 
+/* (1b) The same fill for the other stationary kernels of the reference's experiments (experiments/uci_regression.py:42-44
+ *     uses gpflow.kernels.Matern52): K = variance * k(r), r^2 = sum_d ((x_nd - z_md) * inv_ls_d)^2 (r = sqrt(max(r^2, 1e-36))
+ *     as GPflow), kind one of TSVGP_KERNEL_*.  TSVGP_KERNEL_SE is tsvgp_se_fill_*. */
+#define TSVGP_KERNEL_SE 0       /* exp(-r^2 / 2) */
+/* (1 is reserved: Matern-1/2 = exp(-r) is not offered -- it is not differentiable at r = 0, so GPflow's own expanded-form
+ * r^2 leaves 1e-8 relative rounding noise on K(Z, Z) and no 1e-8 parity statement can be made for it) */
+#define TSVGP_KERNEL_MATERN32 2 /* (1 + sqrt(3) r) exp(-sqrt(3) r) */
+#define TSVGP_KERNEL_MATERN52 3 /* (1 + sqrt(5) r + 5 r^2 / 3) exp(-sqrt(5) r) */
+int tsvgp_kernel_fill_f64(int kind, const double *X, const double *Z, const double *inv_ls, double variance, double *K,
+                          int64_t N, int M, int D, int64_t ldk, void *stream);
+int tsvgp_kernel_fill_f32(int kind, const float *X, const float *Z, const float *inv_ls, float variance, float *K,
+                          int64_t N, int M, int D, int64_t ldk, void *stream);
+
 /* (2) Blocked triangular solve with an N-sized right-hand side, in inverted-factor form:
  *        C[n, i] = sum_{j in range(i)} A[n, j] * Tm[i, j],   range = j<=i | j>=i | all j   (mode)
  *     With Tm = inv(chol(Kuu + jitter I)) and mode LOWER this is B = Kfu * L^-T, i.e. the forward substitution

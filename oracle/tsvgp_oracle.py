@@ -123,6 +123,32 @@ class SquaredExponential:
         return np.full((np.asarray(X).shape[0],), self.variance, dtype=np.float64)
 
 
+class _Matern(SquaredExponential):
+    """gpflow.kernels.IsotropicStationary [ext]: K = variance * K_r(r) with r = sqrt(max(r2, 1e-36)), r2 the scaled
+    squared distance in the same expanded form as SquaredExponential."""
+
+    def _profile(self, r):
+        raise NotImplementedError
+
+    def K(self, X, X2=None):
+        Xs = self._scaled(X)
+        X2s = Xs if X2 is None else self._scaled(X2)
+        r2 = -2.0 * Xs @ X2s.T + np.sum(Xs * Xs, -1)[:, None] + np.sum(X2s * X2s, -1)[None, :]
+        return self.variance * self._profile(np.sqrt(np.maximum(r2, 1e-36)))
+
+
+class Matern32(_Matern):
+    def _profile(self, r):
+        return (1.0 + np.sqrt(3.0) * r) * np.exp(-np.sqrt(3.0) * r)
+
+
+class Matern52(_Matern):
+    """gpflow.kernels.Matern52 [ext] (experiments/uci_regression.py:42-44)."""
+
+    def _profile(self, r):
+        return (1.0 + np.sqrt(5.0) * r + 5.0 / 3.0 * np.square(r)) * np.exp(-np.sqrt(5.0) * r)
+
+
 class InducingPoints:
     """gpflow.inducing_variables.InducingPoints [ext]."""
 

@@ -7,14 +7,14 @@ from . import _backend, distributed, util
 from ._backend import HipExtensionError, build_library
 from .base import Parameter, default_float, default_jitter
 from .inducing_variables import InducingPoints, SharedIndependentInducingVariables, inducingpoint_wrapper
-from .kernels import SeparateIndependent, SquaredExponential
+from .kernels import Matern32, Matern52, SeparateIndependent, SquaredExponential
 from .likelihoods import Bernoulli, Gaussian
 from .models import base_SVGP, t_SVGP
 from .sites import DenseSites, Sites
 
 __all__ = [
     "t_SVGP", "base_SVGP", "DenseSites", "Sites", "SquaredExponential", "Gaussian", "Bernoulli", "InducingPoints",
-    "SeparateIndependent", "SharedIndependentInducingVariables",
+    "SeparateIndependent", "SharedIndependentInducingVariables", "Matern32", "Matern52",
     "inducingpoint_wrapper", "Parameter", "default_float", "default_jitter", "HipExtensionError", "build_library",
     "distributed", "util",
 ]

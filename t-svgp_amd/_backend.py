@@ -20,6 +20,7 @@ SOURCES = [os.path.join(CSRC, "tsvgp_kernels.hip")]
 
 TILE = 128
 LIK_NONE, LIK_GAUSSIAN, LIK_BERNOULLI = 0, 1, 2
+KERNEL_SE, KERNEL_MATERN32, KERNEL_MATERN52 = 0, 2, 3
 TRI_LOWER, TRI_UPPER, TRI_DENSE = 0, 1, 2
 
 _lib = None
@@ -53,6 +54,8 @@ _PROTOTYPES = {
     "tsvgp_site_accum_slots_f32": (c_int, []),
     "tsvgp_se_fill_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_double, c_void_p, c_int64, c_int, c_int, c_int64, c_void_p]),
     "tsvgp_se_fill_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int, c_int, c_int64, c_void_p]),
+    "tsvgp_kernel_fill_f64": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_double, c_void_p, c_int64, c_int, c_int, c_int64, c_void_p]),
+    "tsvgp_kernel_fill_f32": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int, c_int, c_int64, c_void_p]),
     "tsvgp_trmm_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "tsvgp_trmm_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "tsvgp_moments_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_int, c_double, c_void_p, c_void_p,

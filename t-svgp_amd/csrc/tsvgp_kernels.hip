@@ -235,7 +235,25 @@ __device__ __forceinline__ void lik_eval(int lik, double s2, double m, double v,
 constexpr int FILL_ROWS = 64;
 constexpr int FILL_COLS = 512;
 
-template <typename T>
+// stationary kernel profile k(s) as a function of the scaled squared distance s = sum_d ((x_d - z_d) / l_d)^2
+// (GPflow [ext]: Matern kernels take r = sqrt(max(s, 1e-36)))
+template <int KIND, typename T>
+__device__ __forceinline__ T kernel_profile(T s) {
+    if constexpr (KIND == TSVGP_KERNEL_SE) {
+        return exp(T(-0.5) * s);
+    } else {
+        const T r = sqrt(s > T(1e-36) ? s : T(1e-36));
+        if constexpr (KIND == TSVGP_KERNEL_MATERN32) {
+            const T a = T(1.7320508075688772935) * r;
+            return (T(1) + a) * exp(-a);
+        } else {
+            const T a = T(2.2360679774997896964) * r;
+            return (T(1) + a + T(5.0 / 3.0) * r * r) * exp(-a);
+        }
+    }
+}
+
+template <typename T, int KIND = TSVGP_KERNEL_SE>
 __global__ __launch_bounds__(NTHREADS) void se_fill_kernel(const T* __restrict__ X, const T* __restrict__ Z,
                                                            const T* __restrict__ inv_ls, T variance,
                                                            T* __restrict__ K, int64_t N, int M, int D, int64_t ldk,
@@ -284,8 +302,8 @@ __global__ __launch_bounds__(NTHREADS) void se_fill_kernel(const T* __restrict__
         out[0] = (rowok && v0) ? variance * (T(1) - T(0.5) * s0) : T(0);
         out[1] = (rowok && v1) ? variance * (T(1) - T(0.5) * s1) : T(0);
 #else
-        out[0] = (rowok && v0) ? variance * exp(T(-0.5) * s0) : T(0);
-        out[1] = (rowok && v1) ? variance * exp(T(-0.5) * s1) : T(0);
+        out[0] = (rowok && v0) ? variance * kernel_profile<KIND>(s0) : T(0);
+        out[1] = (rowok && v1) ? variance * kernel_profile<KIND>(s1) : T(0);
 #endif
         *reinterpret_cast<pair_t*>(K + n * ldk + m) = out;
     }
@@ -1620,22 +1638,31 @@ inline bool use_v2_panels() {
 }
 
 template <typename T>
-int se_fill(const T* X, const T* Z, const T* inv_ls, T variance, T* K, int64_t N, int M, int D, int64_t ldk,
-            void* stream) {
-    if (!X || !Z || !inv_ls || !K || N <= 0 || M <= 0 || D <= 0) return TSVGP_EINVAL;
+int kernel_fill(int kind, const T* X, const T* Z, const T* inv_ls, T variance, T* K, int64_t N, int M, int D,
+                int64_t ldk, void* stream) {
+    if (!X || !Z || !inv_ls || !K || N <= 0 || M <= 0 || D <= 0 || (kind != TSVGP_KERNEL_SE && kind != TSVGP_KERNEL_MATERN32 && kind != TSVGP_KERNEL_MATERN52))
+        return TSVGP_EINVAL;
     const int64_t rows_pad = (N + TILE - 1) / TILE * TILE;
     const int cols_pad = (M + TILE - 1) / TILE * TILE;
     if (ldk < cols_pad || (ldk % 2) != 0) return TSVGP_EINVAL;
     const size_t smem = ((size_t)D * FILL_COLS + (size_t)FILL_ROWS * D) * sizeof(T);
     if (smem > 160 * 1024) return TSVGP_EINVAL;
-    if (smem > 64 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&se_fill_kernel<T>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-            return TSVGP_ELAUNCH;
-    }
     dim3 grid((unsigned)((rows_pad + FILL_ROWS - 1) / FILL_ROWS), (unsigned)((cols_pad + FILL_COLS - 1) / FILL_COLS));
-    hipLaunchKernelGGL(se_fill_kernel<T>, grid, dim3(NTHREADS), smem, (hipStream_t)stream, X, Z, inv_ls, variance, K,
-                       N, M, D, ldk, rows_pad, cols_pad);
+#define TSVGP_FILL_LAUNCH(KIND_)                                                                                      \
+    {                                                                                                                 \
+        if (smem > 64 * 1024 &&                                                                                       \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&se_fill_kernel<T, KIND_>),                             \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)                 \
+            return TSVGP_ELAUNCH;                                                                                     \
+        hipLaunchKernelGGL((se_fill_kernel<T, KIND_>), grid, dim3(NTHREADS), smem, (hipStream_t)stream, X, Z, inv_ls, \
+                           variance, K, N, M, D, ldk, rows_pad, cols_pad);                                            \
+    }
+    switch (kind) {
+        case TSVGP_KERNEL_SE: TSVGP_FILL_LAUNCH(TSVGP_KERNEL_SE) break;
+        case TSVGP_KERNEL_MATERN32: TSVGP_FILL_LAUNCH(TSVGP_KERNEL_MATERN32) break;
+        default: TSVGP_FILL_LAUNCH(TSVGP_KERNEL_MATERN52) break;
+    }
+#undef TSVGP_FILL_LAUNCH
     return launch_status();
 }
 
@@ -1842,11 +1869,19 @@ int tsvgp_site_accum_slots_f32(void) { return site_accum_slots<float>(); }
 
 int tsvgp_se_fill_f64(const double* X, const double* Z, const double* inv_ls, double variance, double* K, int64_t N,
                       int M, int D, int64_t ldk, void* stream) {
-    return se_fill<double>(X, Z, inv_ls, variance, K, N, M, D, ldk, stream);
+    return kernel_fill<double>(TSVGP_KERNEL_SE, X, Z, inv_ls, variance, K, N, M, D, ldk, stream);
 }
 int tsvgp_se_fill_f32(const float* X, const float* Z, const float* inv_ls, float variance, float* K, int64_t N, int M,
                       int D, int64_t ldk, void* stream) {
-    return se_fill<float>(X, Z, inv_ls, variance, K, N, M, D, ldk, stream);
+    return kernel_fill<float>(TSVGP_KERNEL_SE, X, Z, inv_ls, variance, K, N, M, D, ldk, stream);
+}
+int tsvgp_kernel_fill_f64(int kind, const double* X, const double* Z, const double* inv_ls, double variance, double* K,
+                          int64_t N, int M, int D, int64_t ldk, void* stream) {
+    return kernel_fill<double>(kind, X, Z, inv_ls, variance, K, N, M, D, ldk, stream);
+}
+int tsvgp_kernel_fill_f32(int kind, const float* X, const float* Z, const float* inv_ls, float variance, float* K,
+                          int64_t N, int M, int D, int64_t ldk, void* stream) {
+    return kernel_fill<float>(kind, X, Z, inv_ls, variance, K, N, M, D, ldk, stream);
 }
 
 int tsvgp_trmm_f64(const double* A, const double* Tm, double* C, int64_t Np, int Mp, int mode, void* stream) {

@@ -138,15 +138,16 @@ class EStepEngine:
         return out
 
     # ------------------------------------------------------------------ kernels
-    def se_fill(self, X: torch.Tensor, Z: torch.Tensor, inv_ls: torch.Tensor, variance: float, out: torch.Tensor):
-        """out[Np x Mp] <- K(X, Z) (padding zero).  X, Z, inv_ls, out share one dtype."""
+    def se_fill(self, X: torch.Tensor, Z: torch.Tensor, inv_ls: torch.Tensor, variance: float, out: torch.Tensor,
+                kind: int = B.KERNEL_SE):
+        """out[Np x Mp] <- K(X, Z) (padding zero) for the stationary kernel ``kind``.  X, Z, inv_ls, out share one dtype."""
         N, D = X.shape
         M = Z.shape[0]
-        fn = self._fn("tsvgp_se_fill", X.dtype)
+        fn = self._fn("tsvgp_kernel_fill", X.dtype)
         with torch.cuda.device(self.device):
             self._launch("tsvgp_se_fill" if N != M or X.data_ptr() != Z.data_ptr() else "tsvgp_se_fill(Kuu)",
-                         lambda: fn(X.data_ptr(), Z.data_ptr(), inv_ls.data_ptr(), float(variance), out.data_ptr(), N,
-                                    M, D, out.shape[1], self._stream()))
+                         lambda: fn(kind, X.data_ptr(), Z.data_ptr(), inv_ls.data_ptr(), float(variance), out.data_ptr(),
+                                    N, M, D, out.shape[1], self._stream()))
         return out
 
     def kuu(self, Z: torch.Tensor, kernel) -> torch.Tensor:
@@ -158,7 +159,7 @@ class EStepEngine:
         Mp = B.round_up(M)
         out = torch.empty((Mp, Mp), dtype=torch.float64, device=self.device)
         inv_ls = kernel.inv_lengthscales(D, torch.float64, self.device)
-        self.se_fill(Z, Z, inv_ls, kernel.variance.item(), out)
+        self.se_fill(Z, Z, inv_ls, kernel.variance.item(), out, kernel.kind)
         return out[:M, :M].contiguous()
 
     def cholesky(self, A: torch.Tensor, inverse: bool = False):
@@ -291,7 +292,7 @@ class EStepEngine:
         else:
             self._b_tag = None
             Kfu = self._get("Kfu", (Np, Mp), T)
-            self.se_fill(X, Z, inv_ls, variance, Kfu)
+            self.se_fill(X, Z, inv_ls, variance, Kfu, kernel.kind)
             A = Kfu
             if whiten_T is not None:
                 Bw = self._get("B", (Np, Mp), T)

@@ -14,10 +14,12 @@ from .base import Parameter, to_tensor
 class SquaredExponential:
     """k(x, z) = variance * exp(-0.5 * sum_d ((x_d - z_d) / lengthscales_d)^2)."""
 
+    kind = 0  # TSVGP_KERNEL_SE: selects the profile inside the HIP fill kernel (include/tsvgp_hip.h)
+
     def __init__(self, variance=1.0, lengthscales=1.0, name=None):
         self.variance = Parameter(variance)
         self.lengthscales = Parameter(lengthscales)
-        self.name = name or "squared_exponential"
+        self.name = name or type(self).__name__.lower()
 
     @property
     def ard(self) -> bool:
@@ -35,6 +37,19 @@ class SquaredExponential:
     def K_diag(self, X) -> torch.Tensor:
         X = to_tensor(X)
         return self.variance.value.expand(X.shape[0]).clone()
+
+
+class Matern32(SquaredExponential):
+    """``gpflow.kernels.Matern32`` [ext]: variance * (1 + sqrt(3) r) exp(-sqrt(3) r)."""
+
+    kind = 2
+
+
+class Matern52(SquaredExponential):
+    """``gpflow.kernels.Matern52`` [ext] (reference experiments/uci_regression.py:42-44):
+    variance * (1 + sqrt(5) r + 5 r^2 / 3) exp(-sqrt(5) r)."""
+
+    kind = 3
 
 
 class SeparateIndependent:

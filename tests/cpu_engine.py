@@ -16,7 +16,7 @@ class NumpyShardEngine:
     def kuu(self, Z, kernel):
         if hasattr(kernel, "kernels"):  # SeparateIndependent: [P, M, M]
             return torch.stack([self.kuu(Z, k) for k in kernel.kernels])
-        k = O.SquaredExponential(variance=float(kernel.variance.value), lengthscales=kernel.lengthscales.numpy())
+        k = getattr(O, type(kernel).__name__)(variance=float(kernel.variance.value), lengthscales=kernel.lengthscales.numpy())
         return torch.as_tensor(k.K(Z.cpu().numpy()))
 
     def run(self, X, Y, Z, kernel, *, moment_Tm, moment_mode, gamma, lik_id=0, lik_param=0.0, whiten_T=None,
@@ -35,7 +35,7 @@ class NumpyShardEngine:
                 vals = [getattr(s, name) for s in parts]
                 setattr(st, name, None if vals[0] is None else torch.cat(vals, dim=dim))
             return st
-        k = O.SquaredExponential(variance=float(kernel.variance.value), lengthscales=kernel.lengthscales.numpy())
+        k = getattr(O, type(kernel).__name__)(variance=float(kernel.variance.value), lengthscales=kernel.lengthscales.numpy())
         Xn, Zn = X.cpu().numpy(), Z.cpu().numpy()
         A = k.K(Xn, Zn)
         tri = {0: np.tril, 1: np.triu, 2: lambda a: a}  # the kernels only read the triangle the mode names

@@ -207,3 +207,24 @@ def test_potrf_inverse(engines, M, batch):
     assert np.array_equal(np.triu(X, 1), np.zeros_like(A))
     assert relerr(X, np.linalg.inv(ref)) < 1e-11
     assert np.max(np.abs(X @ ref - np.eye(M))) < 1e-11
+
+
+@pytest.mark.parametrize("dtype,tol", DTYPES)
+@pytest.mark.parametrize("name,kind", [("Matern32", 2), ("Matern52", 3)])
+def test_matern_fill(engines, dtype, tol, name, kind):
+    """tsvgp_kernel_fill_*: the Matern profiles (GPflow [ext] definitions, r = sqrt(max(r2, 1e-36))) against the oracle,
+    including K(Z, Z) whose diagonal sits at r = 0."""
+    eng = engines[dtype]
+    rng = np.random.RandomState(3)
+    N, M, D = 300, 70, 4
+    X, Z = rng.randn(N, D), rng.randn(M, D)
+    ls = 0.7 + rng.rand(D)
+    B = pkg()._backend
+    t = lambda a: torch.as_tensor(a, dtype=dtype, device="cuda:0").contiguous()
+    ker = getattr(O, name)(variance=1.3, lengthscales=ls)
+    for A in (X, Z):
+        out = torch.full((B.round_up(A.shape[0]), B.round_up(M)), float("nan"), dtype=dtype, device="cuda:0")
+        eng.se_fill(t(A), t(Z), t(1.0 / ls), 1.3, out, kind)
+        K = out.double().cpu().numpy()
+        assert relerr(K[:A.shape[0], :M], ker.K(A, Z)) < tol * 10
+        assert np.all(K[A.shape[0]:, :] == 0) and np.all(K[:, M:] == 0)

@@ -321,3 +321,22 @@ def test_separate_kernels_match_oracle(lik, projection):
     hip.natgrad_step((X, Y), lr=0.8)
     ora.natgrad_step((X, Y), lr=0.8)
     _compare_state(hip, ora, 1e-8)
+
+
+@pytest.mark.parametrize("name", ["Matern52", "Matern32"])
+def test_matern_kernels_match_oracle(name):
+    """The reference's UCI experiment runs Matern-5/2 (experiments/uci_regression.py:42-44): E-steps, ELBO and
+    predictions with the Matern family against the oracle."""
+    p = pkg()
+    X, Y, Z = synthetic(N=600, M=40, D=3, P=1, lik="gaussian", seed=4)
+    hip = p.t_SVGP(getattr(p, name)(1.2, 0.9), p.Gaussian(0.1), Z)
+    ora = O.t_SVGP(getattr(O, name)(1.2, 0.9), O.Gaussian(0.1), Z)
+    for _ in range(4):
+        hip.natgrad_step((X, Y), lr=0.8)
+        ora.natgrad_step((X, Y), lr=0.8)
+        _compare_state(hip, ora, 1e-8)
+    e_h, e_o = float(hip.elbo((X, Y))), float(ora.elbo((X, Y)))
+    assert abs(e_h - e_o) / abs(e_o) < 1e-9
+    mu_h, var_h = hip.predict_f(X[:100] + 0.05)
+    mu_o, var_o = ora.predict_f(X[:100] + 0.05)
+    assert relerr(mu_h.cpu().numpy(), mu_o) < 1e-8 and relerr(var_h.cpu().numpy(), var_o) < 1e-8
