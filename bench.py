@@ -91,7 +91,7 @@ def make_kernel(mod, w):
     return mod.SquaredExponential(variance=var, lengthscales=w.get("lengthscales", 1.0)), (lambda Z: Z)
 
 
-def cpu_baseline(w, budget_s=20.0):
+def cpu_baseline(w, budget_s=20.0, model_kind="tsvgp", model_kind=args.model):
     """The CPU oracle (op-for-op port of the reference sequence) timed on a bounded row sample of the same workload."""
     from oracle import tsvgp_oracle as O
 
@@ -105,7 +105,8 @@ def cpu_baseline(w, budget_s=20.0):
     X, Y, Z = make_data(dict(w, N=n_s))
     lik = O.Gaussian(variance=w.get("noise", 0.1)) if w["lik"] == "gaussian" else O.Bernoulli()
     kernel, wrap = make_kernel(O, w)
-    model = O.t_SVGP(kernel, lik, wrap(Z), num_latent_gps=w["P"])
+    cls = O.t_SVGP_white if model_kind == "white" else O.t_SVGP
+    model = cls(kernel, lik, wrap(Z), num_latent_gps=w["P"])
     model.natgrad_step((X, Y), lr=0.8)  # warm-up (BLAS thread pools, page faults)
     times = []
     t_all = time.perf_counter()
@@ -131,6 +132,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="ns", choices=sorted(WORKLOADS))
+    ap.add_argument("--model", default="tsvgp", choices=["tsvgp", "white"],
+                    help="white: t_SVGP_white (reference src/models/tsvgp_white.py) on the same workload; not the metric")
     ap.add_argument("--rows", type=int, default=None, help="override N (debugging only; the result is then not the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
@@ -172,7 +175,11 @@ def main():
 
     lik = pkg.Gaussian(variance=w.get("noise", 0.1)) if w["lik"] == "gaussian" else pkg.Bernoulli()
     kernel, wrap = make_kernel(pkg, w)
-    model = pkg.t_SVGP(kernel, lik, wrap(Z), num_latent_gps=w["P"], num_data=w["N"], compute_dtype=dtype, device=device)
+    if args.model == "white":
+        model = pkg.t_SVGP_white(kernel, lik, wrap(Z), num_latent_gps=w["P"], num_data=w["N"], compute_dtype=dtype, device=device)
+        w["name"] += " [t_SVGP_white]"
+    else:
+        model = pkg.t_SVGP(kernel, lik, wrap(Z), num_latent_gps=w["P"], num_data=w["N"], compute_dtype=dtype, device=device)
     eng = model._get_engine()
 
     def barrier():

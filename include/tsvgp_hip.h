@@ -37,6 +37,8 @@ extern "C" {
 #define TSVGP_LIK_NONE 0      /* moments only (predict_f) */
 #define TSVGP_LIK_GAUSSIAN 1  /* gpflow.likelihoods.Gaussian: closed form */
 #define TSVGP_LIK_BERNOULLI 2 /* gpflow.likelihoods.Bernoulli, probit + 1e-3 jitter, 20-pt Gauss-Hermite */
+#define TSVGP_LIK_NOCROP 0x100 /* OR-ed into the selector: leave g1 = d ve/d var uncropped (reference
+                                  src/models/tsvgp_white.py:188-191 has no crop; src/models/tsvgp.py:262-263 has) */
 
 /* k-range selectors of the panel product C[n,i] = sum_j A[n,j] * Tm[i,j] */
 #define TSVGP_TRI_LOWER 0 /* j <= i  (forward substitution with the inverted factor)   */

@@ -408,7 +408,7 @@ def gradient_transformation_mean_var_to_expectation(inputs, grads):
 
 
 def kl_from_precision_sites_white(A, l, L=None, L2=None):
-    """src/util.py:239-291 (used only by the pin tests)."""
+    """src/util.py:239-291."""
     if L2 is None:
         L2 = L @ _T(L)
     m = L2.shape[-2]
@@ -450,7 +450,7 @@ def project_diag_sites(Kuf_, lambda_1, lambda_2, Kuu_=None, cholesky=True):
 
 
 def conditional_from_precision_sites_white(Kuu_, Kff, Kuf_, l, L=None, L2=None, jitter=1e-9):
-    """src/util.py:11-88 (used only by the pin tests)."""
+    """src/util.py:11-88."""
     if L2 is None:
         L2 = L @ _T(L)
     m = Kuu_.shape[-1]
@@ -465,7 +465,7 @@ def conditional_from_precision_sites_white(Kuu_, Kff, Kuf_, l, L=None, L2=None, 
 
 
 def posterior_from_dense_site_white(K, lambda_1, lambda_2, jitter=1e-9):
-    """src/util.py:394-426 (used only by the pin tests)."""
+    """src/util.py:394-426."""
     m = K.shape[-1]
     R = K + lambda_2
     LR = _chol(R + np.eye(m) * jitter)
@@ -648,6 +648,120 @@ class t_SVGP:
         self.sites._lambda_2_sqrt = np.tril(lambda_2_sqrt)  # :303 (triangular() transform)
         self.get_mean_chol_cov_inducing_posterior()  # :304 (result discarded)
         self.last = dict(mean=mean, var=var, meanZ=meanZ, g0=g0, g1=g1, G0=grads[0], G1=grads[1])
+
+
+# --------------------------------------------------------------------------
+# src/models/tsvgp_white.py restated
+# --------------------------------------------------------------------------
+class t_SVGP_white:
+    """src/models/tsvgp_white.py:23-246, NumPy fp64: the t-SVGP with the site in K-whitened coordinates,
+    q(u) with precision K^-1 + K^-1 Lambda_2 K^-1 and S^-1 m = K^-1 lambda_1; the state is the FULL Lambda_2.
+    The util functions it calls take element [0] of a latent-batched product (util.py:87, :425), so the class is
+    only meaningful for num_latent_gps = 1; that is what is restated and pinned."""
+
+    def __init__(self, kernel, likelihood, inducing_variable, *, mean_function=None, num_latent_gps=1,
+                 lambda_1=None, lambda_2=None, num_data=None):
+        if mean_function is not None:
+            raise NotImplementedError("only the Zero mean function is restated")
+        self.kernel = kernel
+        self.likelihood = likelihood
+        self.num_latent_gps = num_latent_gps
+        self.num_data = num_data
+        self.inducing_variable = inducingpoint_wrapper(inducing_variable)  # :56
+        self.num_inducing = self.inducing_variable.num_inducing
+        lambda_1 = np.zeros((self.num_inducing, self.num_latent_gps)) if lambda_1 is None else lambda_1  # :78
+        if lambda_2 is None:
+            lambda_2 = np.array([np.eye(self.num_inducing) * 1e-10 for _ in range(self.num_latent_gps)])  # :80-85
+        else:
+            lambda_2 = np.asarray(lambda_2)
+            assert lambda_2.ndim == 3  # :87
+            self.num_latent_gps = lambda_2.shape[0]
+        self.sites = DenseSites(lambda_1=lambda_1, lambda_2=lambda_2)  # :90
+        self.last = {}
+
+    @property
+    def lambda_1(self):
+        return self.sites.lambda_1
+
+    @property
+    def lambda_2(self):
+        return self.sites.lambda_2
+
+    def get_mean_chol_cov_inducing_posterior(self):
+        """:99-109."""
+        K_uu = Kuu(self.inducing_variable, self.kernel, jitter=DEFAULT_JITTER)
+        return posterior_from_dense_site_white(K_uu, self.lambda_1, self.lambda_2)
+
+    def prior_kl(self):
+        """:116-120."""
+        K_uu = Kuu(self.inducing_variable, self.kernel, jitter=DEFAULT_JITTER)
+        return kl_from_precision_sites_white(K_uu, self.lambda_1, L2=self.lambda_2)
+
+    def predict_f(self, Xnew, full_cov=False, full_output_cov=False):
+        """:122-132."""
+        K_uu = Kuu(self.inducing_variable, self.kernel, jitter=DEFAULT_JITTER)
+        K_uf = Kuf(self.inducing_variable, self.kernel, Xnew)
+        K_ff = self.kernel.K_diag(Xnew)[..., None]
+        mu, var = conditional_from_precision_sites_white(K_uu, K_ff, K_uf, self.lambda_1, L2=self.lambda_2)
+        if not np.all(var > 0):  # :131
+            raise FloatingPointError("predict_f: non-positive predictive variance")
+        return mu, var
+
+    def elbo(self, data):
+        """:162-177."""
+        X, Y = data
+        X = np.asarray(X, dtype=np.float64)
+        Y = np.asarray(Y, dtype=np.float64)
+        kl = self.prior_kl()
+        f_mean, f_var = self.predict_f(X)
+        var_exp = self.likelihood.variational_expectations(f_mean, f_var, Y)
+        scale = (float(self.num_data) / X.shape[0]) if self.num_data is not None else 1.0
+        return np.sum(var_exp) * scale - kl
+
+    def compute_data_natural_params(self, data, jitter=1e-9):
+        """:183-212 (no cropping of the second gradient here, unlike tsvgp.py:262-263)."""
+        X, Y = data
+        mean, var = self.predict_f(X)  # :185
+        meanZ, _ = self.predict_f(self.inducing_variable.Z)  # :186
+        g0, g1 = self.likelihood.variational_expectations_grads(mean, var, Y)  # :188-191
+        Id = np.eye(self.num_inducing)
+        K_uu = Kuu(self.inducing_variable, self.kernel)  # :196
+        K_uf = Kuf(self.inducing_variable, self.kernel, X)
+        chol_Kuu = _chol(K_uu + Id * jitter)  # :198
+        A = np.transpose(_chol_solve(chol_Kuu, K_uf))  # :199
+        A = np.tile(A[..., None], [1, 1, self.num_latent_gps])  # :201
+        grads = [np.einsum("nml,nl->ml", A, g0), np.einsum("nml,nol,nl->lmo", A, A, g1, optimize=True)]  # :203-206
+        self.last = dict(mean=mean, var=var, meanZ=meanZ, g0=g0, g1=g1, G0=grads[0], G1=grads[1])
+        return gradient_transformation_mean_var_to_expectation(meanZ, grads)  # :209
+
+    def natgrad_step(self, dataset, lr=0.1, jitter=1e-9):
+        """:215-246."""
+        X, Y = dataset
+        X = np.asarray(X, dtype=np.float64)
+        Y = np.asarray(Y, dtype=np.float64)
+        grad_mu = self.compute_data_natural_params((X, Y))  # :230
+        K_uu = Kuu(self.inducing_variable, self.kernel)  # :231 (no jitter)
+        scale = (float(self.num_data) / X.shape[0]) if self.num_data is not None else 1.0  # :233-238
+        lambda_1 = self.lambda_1
+        lambda_2 = -0.5 * self.lambda_2  # :241
+        lambda_1 = (1.0 - lr) * lambda_1 + lr * scale * K_uu @ grad_mu[0]  # :244
+        lambda_2 = (1.0 - lr) * lambda_2 + lr * scale * K_uu @ grad_mu[1] @ K_uu  # :245
+        self.sites.lambda_1 = lambda_1  # :247
+        self.sites._lambda_2 = -2.0 * lambda_2  # :248
+
+
+def sgpr_predict_f(kernel, X, Y, Z, noise_variance, Xnew):
+    """Titsias' collapsed sparse GP regression posterior (what gpflow.models.SGPR.predict_f computes [ext]), in the
+    textbook form: Sigma = (Kuu + Kuf Kfu / s2)^-1, mean = Ksu Sigma Kuf y / s2, var = kss - Ksu Kuu^-1 Kus + Ksu Sigma Kus.
+    Independent pin for reference tests/models/test_condit.py:69-83."""
+    Kuu_ = kernel.K(Z) + DEFAULT_JITTER * np.eye(Z.shape[0])
+    Kuf_ = kernel.K(Z, X)
+    Kus = kernel.K(Z, Xnew)
+    Sigma_inv = Kuu_ + Kuf_ @ Kuf_.T / noise_variance
+    mean = Kus.T @ np.linalg.solve(Sigma_inv, Kuf_ @ Y) / noise_variance
+    var = kernel.K_diag(Xnew)[:, None] - np.sum(Kus * np.linalg.solve(Kuu_, Kus), 0)[:, None] \
+        + np.sum(Kus * np.linalg.solve(Sigma_inv, Kus), 0)[:, None]
+    return mean, var
 
 
 # --------------------------------------------------------------------------

@@ -9,11 +9,11 @@ from .base import Parameter, default_float, default_jitter
 from .inducing_variables import InducingPoints, SharedIndependentInducingVariables, inducingpoint_wrapper
 from .kernels import Matern32, Matern52, SeparateIndependent, SquaredExponential
 from .likelihoods import Bernoulli, Gaussian
-from .models import base_SVGP, t_SVGP
+from .models import base_SVGP, t_SVGP, t_SVGP_white
 from .sites import DenseSites, Sites
 
 __all__ = [
-    "t_SVGP", "base_SVGP", "DenseSites", "Sites", "SquaredExponential", "Gaussian", "Bernoulli", "InducingPoints",
+    "t_SVGP", "t_SVGP_white", "base_SVGP", "DenseSites", "Sites", "SquaredExponential", "Gaussian", "Bernoulli", "InducingPoints",
     "SeparateIndependent", "SharedIndependentInducingVariables", "Matern32", "Matern52",
     "inducingpoint_wrapper", "Parameter", "default_float", "default_jitter", "HipExtensionError", "build_library",
     "distributed", "util",

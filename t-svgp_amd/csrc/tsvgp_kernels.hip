@@ -197,8 +197,9 @@ __device__ __forceinline__ void bern_point(double f, bool y1, double& lp, double
     }
 }
 
-__device__ __forceinline__ void lik_eval(int lik, double s2, double m, double v, double y, double& g0, double& g1,
+__device__ __forceinline__ void lik_eval(int lik_flags, double s2, double m, double v, double y, double& g0, double& g1,
                                          double& ve) {
+    const int lik = lik_flags & ~TSVGP_LIK_NOCROP;
     if (lik == TSVGP_LIK_GAUSSIAN) {
         const double r = y - m;
         g0 = r / s2;
@@ -225,7 +226,7 @@ __device__ __forceinline__ void lik_eval(int lik, double s2, double m, double v,
         g1 = a1 / (2.0 * sd);
         ve = av;
     }
-    g1 = fmin(g1, -1e-8);  // reference tsvgp.py:262-263
+    if (!(lik_flags & TSVGP_LIK_NOCROP)) g1 = fmin(g1, -1e-8);  // reference tsvgp.py:262-263 (tsvgp_white.py does not crop)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1708,9 +1709,11 @@ int moments(const T* A, const T* Tm, const T* gamma, const T* Y, double kdiag, i
     if (!A || !Tm || !gamma || N <= 0 || Np < N || (Np % TILE) || Mp <= 0 || (Mp % TILE) || P <= 0 || mode < 0 ||
         mode > 2)
         return TSVGP_EINVAL;
-    if (lik != TSVGP_LIK_NONE && lik != TSVGP_LIK_GAUSSIAN && lik != TSVGP_LIK_BERNOULLI) return TSVGP_EINVAL;
+    const int lik_base = lik & ~TSVGP_LIK_NOCROP;
+    if (lik_base != TSVGP_LIK_NONE && lik_base != TSVGP_LIK_GAUSSIAN && lik_base != TSVGP_LIK_BERNOULLI) return TSVGP_EINVAL;
+    if (lik_base == TSVGP_LIK_NONE) lik = TSVGP_LIK_NONE;
     if (lik != TSVGP_LIK_NONE && (!Y || !g0 || !g1)) return TSVGP_EINVAL;
-    if (lik == TSVGP_LIK_GAUSSIAN && !(lik_param > 0.0)) return TSVGP_EINVAL;
+    if (lik_base == TSVGP_LIK_GAUSSIAN && !(lik_param > 0.0)) return TSVGP_EINVAL;
     PanelArgs<T> a{};
     a.A = A;
     a.Tm = Tm;

@@ -1,0 +1,205 @@
+"""t-SVGP with the site in K-whitened coordinates: mirror of the reference's ``t_SVGP_white``
+(reference src/models/tsvgp_white.py:23-246), SURVEY section 8(f) #1.
+
+q(u) = N(m, S) with  S^-1 = K^-1 + K^-1 Lambda_2 K^-1,  S^-1 m = K^-1 lambda_1;  the state is lambda_1 [M, 1] and the
+FULL Lambda_2 [1, M, M] (no Cholesky factor, no final factorisation in the step).  The N-sized work is the same as
+``t_SVGP``'s -- K(X, Z) fill, a whitening product, fused moments + likelihood gradients, weighted Gram accumulation --
+through the same HIP kernels; only the M x M prelude / epilogue differ:
+
+  reference (tsvgp_white.py / util.py:11-88)              here  (K6 = Kuu + 1e-6 I = U6 U6^T, E = Lambda_2 + 1e-9 I = U_E U_E^T)
+  -----------------------------------------------------   ----------------------------------------------------------------
+  R = Lambda_2 + K6 + 1e-9 I;  LR = chol R, LA = chol K6   b = U6^-1 k  (HIP trmm);  H = U6^-1 U_E (upper);  I + H^T H = C C^T
+  var  = kff - |LA^-1 k|^2 + |LR^-1 k|^2                   var  = kff - |T b|^2,  T = C^-1 H^T  (LOWER triangular)
+  mean = k^T R^-1 lambda_1                                 mean = b^T gamma,  gamma = v - T^T T v,  v = U6^-1 lambda_1
+  A = Kfu K9^-1;  G1 = sum g1 a a^T, G0 = sum g0 a          acc2 = sum g1 b b^T, acc1 = sum g0 b  (HIP syrk);  S2 = U6 acc2 U6^T
+  lambda_1 += .. Kuu (G0 - 2 G1 meanZ)                      Kuu G1 Kuu = Mj S2 Mj^T,  Mj = Kuu K9^-1 = I - jitter K9^-1
+  Lambda_2 += .. -2 Kuu G1 Kuu                              (the product with Mj is benign: no cancellation with K^-1)
+
+since  |LA^-1 k|^2 - |LR^-1 k|^2 = b^T (I - (I + G)^-1) b  with  G = U6^-1 E U6^-T = H H^T  and
+I - (I + H H^T)^-1 = H (I + H^T H)^-1 H^T.  The reference's util functions take element [0] of a latent-batched product
+(util.py:87, :425), so the class is only defined for ONE latent GP; more raise NotImplementedError.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .. import _backend as B
+from .. import distributed as D_
+from ..base import default_jitter, to_tensor
+from ..kernels import SeparateIndependent
+from ..sites import DenseSites
+from ..util import cholesky_deferred, rev_cholesky
+from .tsvgp import base_SVGP
+
+
+class t_SVGP_white(base_SVGP):
+    """Class for the t-SVGP model with whitened parameterization (reference tsvgp_white.py:23-246)."""
+
+    def __init__(self, kernel, likelihood, inducing_variable, *, mean_function=None, num_latent_gps: int = 1,
+                 lambda_1=None, lambda_2=None, num_data=None, compute_dtype=None, device=None):
+        super().__init__(kernel, likelihood, inducing_variable, mean_function=mean_function,
+                         num_latent_gps=num_latent_gps, num_data=num_data, compute_dtype=compute_dtype, device=device)
+        if isinstance(kernel, SeparateIndependent):
+            raise NotImplementedError("t_SVGP_white takes one shared kernel (util.py:52-56 asserts Kuu [M, M])")
+        self.num_inducing = self.inducing_variable.num_inducing
+        self._init_variational_parameters(self.num_inducing, lambda_1, lambda_2)
+        if self.num_latent_gps != 1:
+            raise NotImplementedError("the reference's whitened util functions take element [0] of the latent batch "
+                                      "(util.py:87, :425): only num_latent_gps = 1 is defined")
+        self.name = "t_svgp_white"
+
+    def _init_variational_parameters(self, num_inducing, lambda_1, lambda_2):
+        """lambda_1 = 0, Lambda_2 = 1e-10 I (tsvgp_white.py:62-90)."""
+        lambda_1 = np.zeros((num_inducing, self.num_latent_gps)) if lambda_1 is None else lambda_1
+        if lambda_2 is None:
+            lambda_2 = np.array([np.eye(num_inducing) * 1e-10 for _ in range(self.num_latent_gps)])
+        else:
+            lambda_2 = lambda_2.value if hasattr(lambda_2, "value") else lambda_2
+            assert lambda_2.ndim == 3
+            self.num_latent_gps = lambda_2.shape[0]
+        self.sites = DenseSites(to_tensor(lambda_1, device=self.device), lambda_2=to_tensor(lambda_2, device=self.device))
+
+    @property
+    def lambda_1(self):
+        return self.sites.lambda_1
+
+    @property
+    def lambda_2(self):
+        """The full second natural parameter, a Parameter (tsvgp_white.py:96-97)."""
+        return self.sites._lambda_2
+
+    # -- M x M prelude -----------------------------------------------------------------------------------------
+    def _Z(self):
+        return self.inducing_variable.Z.value.to(self.device)
+
+    def _as_device(self, a):
+        if isinstance(a, torch.Tensor):
+            return a.to(self.device)
+        return torch.as_tensor(np.asarray(a)).to(self.device)
+
+    def _operands(self, jitter=None):
+        """Everything the N-pass needs (see the table in the module docstring); with ``jitter`` also K9^-1 for the
+        site update.  No host synchronisation: factorisation statuses go to ops["infos"]."""
+        eng = self._get_engine()
+        Z = self._Z()
+        M = Z.shape[0]
+        infos = []
+        potrf = getattr(eng, "cholesky", None)
+        Kzz = eng.kuu(Z, self.kernel)
+        Id = torch.eye(M, dtype=torch.float64, device=Kzz.device)
+        K6 = Kzz + default_jitter() * Id
+        l1, L2 = self.lambda_1.value, self.lambda_2.value
+        E = 0.5 * (L2 + L2.transpose(-1, -2)) + 1e-9 * Id  # util.py:76 (jitter argument default)
+        mats = [K6[None], E] + ([(Kzz + jitter * Id)[None]] if jitter is not None else [])
+        U, Uinv = rev_cholesky(torch.cat(mats, dim=0), infos, potrf, inverse=True)
+        U6, Uinv6, U_E = U[0], Uinv[0], U[1]
+        H = (Uinv6 @ U_E).triu()
+        Wm = Id + H.transpose(-1, -2) @ H
+        _, Cinv = cholesky_deferred(0.5 * (Wm + Wm.transpose(-1, -2))[None], infos, potrf, inverse=True)
+        Tm = (Cinv[0] @ H.transpose(-1, -2)).tril()
+        v = Uinv6 @ l1
+        gamma = v - Tm.transpose(-1, -2) @ (Tm @ v)
+        ops = dict(Z=Z, Kzz=Kzz, K6=K6, Id=Id, infos=infos, U6=U6, Uinv6=Uinv6, moment_Tm=Tm[None], gamma=gamma)
+        if jitter is not None:
+            ops["K9inv"] = Uinv[2].transpose(-1, -2) @ Uinv[2]
+        return ops
+
+    def _run(self, X, Y, ops, lik_id, sites=False, want_moments=False):
+        return self._get_engine().run(X, Y, ops["Z"], self.kernel, moment_Tm=ops["moment_Tm"], moment_mode=B.TRI_LOWER,
+                                      gamma=ops["gamma"], lik_id=lik_id, lik_param=self.likelihood.lik_param,
+                                      whiten_T=ops["Uinv6"], whiten_mode=B.TRI_UPPER, sites=sites,
+                                      want_moments=want_moments)
+
+    def _check(self, ops, nonpos):
+        flags = torch.cat([torch.cat(list(ops["infos"])).sum().reshape(1), nonpos.reshape(1).to(torch.float64)]).cpu()
+        if float(flags[0]) != 0:
+            raise FloatingPointError("Cholesky decomposition was not successful (matrix not positive definite)")
+        if not (float(flags[1]) == 0):  # tsvgp_white.py:131
+            raise FloatingPointError(f"non-positive predictive variance at {float(flags[1]):.0f} point(s)")
+
+    # -- reference API -----------------------------------------------------------------------------------------
+    def get_mean_chol_cov_inducing_posterior(self):
+        """posterior_from_dense_site_white (util.py:394-426): m = K (K + Lambda_2 + 1e-9 I)^-1 lambda_1, chol(S),
+        S = K R^-1 K."""
+        ops = self._operands()
+        K6 = ops["K6"]
+        R = K6 + self.lambda_2.value[0] + 1e-9 * ops["Id"]
+        LR = torch.linalg.cholesky(R)
+        iLRK = torch.linalg.solve_triangular(LR, K6, upper=False)
+        S_q = iLRK.transpose(-1, -2) @ iLRK
+        Rl = torch.linalg.solve_triangular(LR.transpose(-1, -2), torch.linalg.solve_triangular(
+            LR, self.lambda_1.value, upper=False), upper=True)  # R^-1 lambda_1 (two explicit triangular solves)
+        m_q = K6 @ Rl
+        return m_q, torch.linalg.cholesky(S_q)[None]
+
+    def prior_kl(self):
+        """kl_from_precision_sites_white(K6, lambda_1, L2=Lambda_2) (util.py:239-291; tsvgp_white.py:116-120)."""
+        eng = self._get_engine()
+        Kzz = eng.kuu(self._Z(), self.kernel)
+        Id = torch.eye(Kzz.shape[0], dtype=torch.float64, device=Kzz.device)
+        A = Kzz + default_jitter() * Id
+        R = self.lambda_2.value[0] + A
+        LR, LA = torch.linalg.cholesky(R), torch.linalg.cholesky(A)
+        log_det = 2.0 * (torch.sum(torch.log(torch.diagonal(LR))) - torch.sum(torch.log(torch.diagonal(LA))))
+        tmp = torch.linalg.solve_triangular(LR, LA, upper=False)
+        Rl = torch.linalg.solve_triangular(LR.transpose(-1, -2), torch.linalg.solve_triangular(
+            LR, self.lambda_1.value, upper=False), upper=True)
+        return 0.5 * (log_det + torch.sum(tmp * tmp) - float(A.shape[0]) + torch.sum(torch.square(LA.transpose(-1, -2) @ Rl)))
+
+    def predict_f(self, Xnew, full_cov=False, full_output_cov=False):
+        """tsvgp_white.py:122-132."""
+        if full_cov or full_output_cov:
+            raise NotImplementedError("full covariances are not on the E-step hot path")
+        ops = self._operands()
+        st = self._run(self._as_device(Xnew), None, ops, B.LIK_NONE, want_moments=True)
+        self._check(ops, st.nonpos)
+        return st.mean, st.var
+
+    def predict_y(self, Xnew):
+        return self.likelihood.predict_mean_and_var(*self.predict_f(Xnew))
+
+    def elbo(self, data):
+        """tsvgp_white.py:162-177; with more than one rank ``data`` is this rank's row shard."""
+        X, Y = data
+        kl = self.prior_kl()
+        ops = self._operands()
+        st = self._run(self._as_device(X), self._as_device(Y), ops, self.likelihood.lik_id | B.LIK_NOCROP)
+        packed = D_.pack_stats(st, with_sites=False)
+        if self._reduce():
+            D_.all_reduce_sum(packed)
+        _, _, ve_sum, nonpos, rows = D_.unpack_stats(packed, self.num_latent_gps, self.num_inducing, False)
+        self._check(ops, nonpos)
+        scale = (float(self.num_data) / rows) if self.num_data is not None else 1.0
+        return ve_sum * scale - kl
+
+    def natgrad_step(self, dataset, lr=0.1, jitter=1e-9):
+        """One natural-gradient step on (lambda_1, Lambda_2) (tsvgp_white.py:183-248); returns None."""
+        X, Y = self._as_device(dataset[0]), self._as_device(dataset[1])
+        ops = self._operands(jitter=jitter)
+        # tsvgp_white.py:188-191: no crop of d ve / d var in this class
+        st = self._run(X, Y, ops, self.likelihood.lik_id | B.LIK_NOCROP, sites=True)
+        packed = D_.pack_stats(st, with_sites=True)
+        if self._reduce():
+            D_.all_reduce_sum(packed)
+        acc2, acc1, _, nonpos, rows = D_.unpack_stats(packed, self.num_latent_gps, self.num_inducing, True)
+        U6, Uinv6, Kzz, K9inv, Id = ops["U6"], ops["Uinv6"], ops["Kzz"], ops["K9inv"], ops["Id"]
+        S2 = U6 @ acc2 @ U6.transpose(-1, -2)  # sum g1 k k^T   [1, M, M]
+        s1 = U6 @ acc1.transpose(-1, -2)  # sum g0 k     [M, 1]
+        Mj = Id - jitter * K9inv  # Kuu K9^-1
+        gamma_k = Uinv6.transpose(-1, -2) @ ops["gamma"]  # R^-1 lambda_1
+        a_meanZ = Mj @ gamma_k  # K9^-1 meanZ, meanZ = Kuu R^-1 lambda_1 (predict_f at Z, :186)
+        KG1K = Mj @ S2 @ Mj.transpose(-1, -2)  # Kuu G1 Kuu
+        Kg0 = Mj @ s1 - 2.0 * (Mj @ (S2[0] @ a_meanZ))  # Kuu (G0 - 2 G1 meanZ), util.py:429-438
+        scale = (float(self.num_data) / rows) if self.num_data is not None else 1.0
+        lambda_1 = (1.0 - lr) * self.lambda_1.value + lr * scale * Kg0  # :244
+        lambda_2 = (1.0 - lr) * self.lambda_2.value - 2.0 * lr * scale * KG1K  # :241-248 (Lambda_2 = -2 lambda_2)
+        old_l1, old_L2 = self.lambda_1.value, self.lambda_2.value
+        self.lambda_1.assign(lambda_1)
+        self.sites.assign_lambda_2(0.5 * (lambda_2 + lambda_2.transpose(-1, -2)))
+        try:
+            self._check(ops, nonpos)
+        except FloatingPointError:
+            self.lambda_1.assign(old_l1)  # the reference raises before its assigns: leave the state untouched
+            self.sites.assign_lambda_2(old_L2)
+            raise

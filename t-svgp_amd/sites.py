@@ -49,6 +49,12 @@ class DenseSites(Sites):
             return self._lambda_2_sqrt
         return Parameter(torch.linalg.cholesky(self._lambda_2.value), trainable=False)
 
+    def assign_lambda_2(self, value):
+        """Full second natural parameter (the whitened model's state, reference src/models/tsvgp_white.py:248)."""
+        if self.factor:
+            raise ValueError("sites are stored as a Cholesky factor")
+        self._lambda_2.assign(value)
+
     def assign_lambda_2_sqrt(self, value):
         """triangular() transform: only the lower triangle is kept (reference src/sites.py:63)."""
         if not self.factor:

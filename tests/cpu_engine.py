@@ -53,11 +53,12 @@ class NumpyShardEngine:
         st.acc2 = st.acc1 = st.mean = st.var = st.g0 = st.g1 = None
         if want_moments:
             st.mean, st.var = torch.as_tensor(mean), torch.as_tensor(var)
+        crop, lik_id = not (lik_id & 0x100), lik_id & 0xFF  # TSVGP_LIK_NOCROP
         if lik_id != 0:
             lik = O.Gaussian(variance=lik_param) if lik_id == 1 else O.Bernoulli()
             Yn = Y.cpu().numpy()
             g0, g1 = lik.variational_expectations_grads(mean, var, Yn)
-            g1 = np.minimum(g1, -1e-8)
+            g1 = np.minimum(g1, -1e-8) if crop else g1
             st.ve_sum = torch.tensor(float(np.sum(lik.variational_expectations(mean, var, Yn))), dtype=torch.float64)
             if sites:
                 st.acc2 = torch.as_tensor(np.einsum("nm,no,nl->lmo", A, A, g1))

@@ -68,7 +68,42 @@ def make_case(name):
     return out
 
 
+WHITE_CASES = {
+    # t_SVGP_white (reference src/models/tsvgp_white.py), one latent: name: (N, M, D, likelihood, lengthscale, variance, noise, lr)
+    "white_gaussian_d3": (160, 12, 3, "gaussian", 1.0, 1.0, 0.1, 0.8),
+    "white_bernoulli_d2": (160, 12, 2, "bernoulli", 1.0, 1.5, None, 0.8),
+}
+
+
+def make_white_case(name):
+    N, M, D, lik, ls, var, noise, lr = WHITE_CASES[name]
+    rng = np.random.RandomState(123)
+    X = rng.randn(N, D)
+    f = np.sin(X @ rng.randn(D, 1))
+    eps = rng.randn(N, 1)
+    Y = f + np.sqrt(0.1) * eps if lik == "gaussian" else (f + np.sqrt(0.1) * eps > 0).astype(np.float64)
+    Z = X[:M].copy()
+    model = O.t_SVGP_white(O.SquaredExponential(variance=var, lengthscales=ls),
+                           O.Gaussian(variance=noise) if lik == "gaussian" else O.Bernoulli(), Z)
+    out = dict(X=X, Y=Y, Z=Z, lengthscales=ls, variance=var, noise=-1.0 if noise is None else noise, lr=lr,
+               likelihood=lik, steps=np.array(STEPS))
+    Xs = X[:50] + 0.05
+    for step in range(1, max(STEPS) + 1):
+        model.natgrad_step((X, Y), lr=lr)
+        if step in STEPS:
+            mean_s, var_s = model.predict_f(Xs)
+            out.update({f"s{step}_lambda_1": model.lambda_1.copy(), f"s{step}_lambda_2": model.lambda_2.copy(),
+                        f"s{step}_mean": model.last["mean"], f"s{step}_var": model.last["var"],
+                        f"s{step}_elbo": model.elbo((X, Y)), f"s{step}_pred_mean": mean_s, f"s{step}_pred_var": var_s})
+    out["Xs"] = Xs
+    return out
+
+
 if __name__ == "__main__":
     for name in CASES:
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **make_case(name))
         print("wrote", name)
+    os.makedirs(os.path.join(HERE, "white"), exist_ok=True)
+    for name in WHITE_CASES:
+        np.savez_compressed(os.path.join(HERE, "white", name + ".npz"), **make_white_case(name))
+        print("wrote white/" + name)

@@ -1,0 +1,104 @@
+"""t_SVGP_white (reference src/models/tsvgp_white.py) on the GPU: the HIP path against the oracle and
+the reference's own relational tests restated on the HIP model.  Tolerances as tests/test_gpu_model.py."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import tsvgp_oracle as O
+from tests.helpers import pkg, relerr, synthetic
+from tests.test_golden_cpu import WHITE_FIXTURES, load_white_model
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("lik", ["gaussian", "bernoulli"])
+def test_white_steps_match_oracle_fp64(lik):
+    p = pkg()
+    rng = np.random.RandomState(31)
+    X, Y, _ = synthetic(N=900, M=48, D=4, P=1, lik=lik, seed=5)
+    Z = rng.randn(48, 4) * 1.3
+    mk = lambda mod: mod.t_SVGP_white(mod.SquaredExponential(1.2, 0.9), mod.Gaussian(0.2) if lik == "gaussian" else mod.Bernoulli(),
+                                      Z, num_data=900)
+    hip, ora = mk(p), mk(O)
+    assert abs(float(hip.elbo((X, Y))) - ora.elbo((X, Y))) < 1e-9 * abs(ora.elbo((X, Y)))
+    for _ in range(6):
+        hip.natgrad_step((X, Y), lr=0.7)
+        ora.natgrad_step((X, Y), lr=0.7)
+        assert relerr(hip.lambda_1.numpy(), ora.lambda_1) < 1e-8
+        assert relerr(hip.lambda_2.numpy(), ora.lambda_2) < 1e-8
+    assert abs(float(hip.elbo((X, Y))) - ora.elbo((X, Y))) < 1e-9 * abs(ora.elbo((X, Y)))
+    assert abs(float(hip.prior_kl()) - ora.prior_kl()) < 1e-8 * abs(ora.prior_kl())
+    mu_h, var_h = hip.predict_f(X[:150] + 0.05)
+    mu_o, var_o = ora.predict_f(X[:150] + 0.05)
+    assert relerr(mu_h.cpu().numpy(), mu_o) < 1e-8 and relerr(var_h.cpu().numpy(), var_o) < 1e-8
+    m_h, cS_h = hip.get_mean_chol_cov_inducing_posterior()
+    m_o, cS_o = ora.get_mean_chol_cov_inducing_posterior()
+    assert relerr(m_h.cpu().numpy(), m_o) < 1e-8 and relerr(cS_h.cpu().numpy(), cS_o) < 1e-7
+
+
+@pytest.mark.parametrize("path", WHITE_FIXTURES, ids=[os.path.basename(p)[:-4] for p in WHITE_FIXTURES])
+def test_white_hip_matches_fixture(path):
+    fx = np.load(path)
+    model = load_white_model(fx, pkg())
+    X, Y, lr = fx["X"], fx["Y"], float(fx["lr"])
+    steps = [int(s) for s in fx["steps"]]
+    for step in range(1, max(steps) + 1):
+        if step in steps:  # moments of THIS step, from the pre-step state like the fixture's
+            mu, var = model.predict_f(X)
+            assert relerr(mu.cpu().numpy(), fx[f"s{step}_mean"]) < 1e-8 and relerr(var.cpu().numpy(), fx[f"s{step}_var"]) < 1e-8
+        model.natgrad_step((X, Y), lr=lr)
+        if step in steps:
+            assert relerr(model.lambda_1.numpy(), fx[f"s{step}_lambda_1"]) < 1e-8
+            assert relerr(model.lambda_2.numpy(), fx[f"s{step}_lambda_2"]) < 1e-8
+            e = float(model.elbo((X, Y)))
+            assert abs(e - float(fx[f"s{step}_elbo"])) < 1e-9 * abs(float(fx[f"s{step}_elbo"]))
+            mu, var = model.predict_f(fx["Xs"])
+            assert relerr(mu.cpu().numpy(), fx[f"s{step}_pred_mean"]) < 1e-8
+            assert relerr(var.cpu().numpy(), fx[f"s{step}_pred_var"]) < 1e-8
+
+
+def test_white_reference_relations_on_hip():
+    """reference tests/models/test_tsvgp_white.py:64-115 and tests/models/test_condit.py:69-83 on the HIP models
+    (decimal=4 as there): white == unwhitened t-SVGP before and after a step; exact-GP optimum; SGPR equality."""
+    p = pkg()
+    rng = np.random.RandomState(123)
+    func = lambda x: np.sin(x * 3 * 3.14) + 0.3 * np.cos(x * 9 * 3.14) + 0.5 * np.sin(x * 7 * 3.14)
+    X = rng.rand(8, 1) * 2 - 1
+    Y = func(X) + 0.2 * rng.randn(8, 1)
+    k = lambda mod: mod.SquaredExponential(variance=2.25, lengthscales=2.0)
+    plain, white = p.t_SVGP(k(p), p.Gaussian(0.3), X.copy()), p.t_SVGP_white(k(p), p.Gaussian(0.3), X.copy())
+    np.testing.assert_almost_equal(float(plain.elbo((X, Y))), float(white.elbo((X, Y))), decimal=4)
+    plain.natgrad_step((X, Y), lr=0.9)
+    white.natgrad_step((X, Y), lr=0.9)
+    for a, b in zip(plain.predict_f(X), white.predict_f(X)):
+        np.testing.assert_array_almost_equal(a.cpu().numpy(), b.cpu().numpy(), decimal=4)
+    opt = p.t_SVGP_white(k(p), p.Gaussian(0.3), X.copy())
+    opt.natgrad_step((X, Y * 0), lr=1.0)
+    np.testing.assert_almost_equal(float(opt.elbo((X, Y * 0))), O.gpr_log_marginal_likelihood(k(O), X, Y * 0, 0.3), decimal=4)
+    rs = np.random.RandomState(0)
+    Xs, Ys, Zs = rs.randn(10, 1), rs.randn(10, 1), rs.randn(3, 1)
+    w = p.t_SVGP_white(p.SquaredExponential(1.0, 1.0), p.Gaussian(0.3), Zs)
+    w.natgrad_step((Xs, Ys), lr=1.0)
+    m1, v1 = w.predict_f(Ys)
+    m2, v2 = O.sgpr_predict_f(O.SquaredExponential(1.0, 1.0), Xs, Ys, Zs, 0.3, Ys)
+    np.testing.assert_array_almost_equal(m1.cpu().numpy(), m2, decimal=4)
+    np.testing.assert_array_almost_equal(v1.cpu().numpy(), v2, decimal=4)
+
+
+def test_white_api_and_errors():
+    p = pkg()
+    X, Y, Z = synthetic(N=300, M=16, D=2, P=1, lik="gaussian", seed=2)
+    m = p.t_SVGP_white(p.SquaredExponential(1.0, 1.0), p.Gaussian(0.1), Z)
+    assert m.lambda_1.shape == (16, 1) and m.lambda_2.shape == (1, 16, 16)
+    assert m.natgrad_step((X, Y), lr=0.5) is None  # mutates in place
+    assert float(m.lambda_2.value.abs().max()) > 1e-3
+    with pytest.raises(NotImplementedError):
+        p.t_SVGP_white(p.SquaredExponential(1.0, 1.0), p.Gaussian(0.1), Z, num_latent_gps=2)
+    l1, L2 = m.lambda_1.numpy().copy(), m.lambda_2.numpy().copy()
+    m.kernel.lengthscales.assign(1e-9)  # K(X, Z) = 0: var = kff > 0 still; make the likelihood parameter invalid instead
+    m.kernel.lengthscales.assign(1.0)
+    with pytest.raises(ValueError):
+        m.natgrad_step((X, Y[:, :0]), lr=0.5)  # Y must be [N, 1]
+    assert np.array_equal(m.lambda_1.numpy(), l1) and np.array_equal(m.lambda_2.numpy(), L2)

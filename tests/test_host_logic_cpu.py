@@ -14,8 +14,23 @@ from tests.cpu_engine import NumpyShardEngine
 from tests.helpers import pkg, relerr, synthetic
 
 
-def _pair(Z, lik, P=1, num_data=None):
+def _pair(Z, lik, P=1, num_data=None, kind="plain"):
     p = pkg()
+    if kind == "white":  # t_SVGP_white (one latent)
+        mk = lambda mod, **kw: mod.t_SVGP_white(mod.SquaredExponential(1.0, 1.0),
+                                                mod.Gaussian(0.1) if lik == "gaussian" else mod.Bernoulli(), Z,
+                                                num_data=num_data, **kw)
+        hip = mk(p, device="cpu")
+        hip._engine = NumpyShardEngine()
+        return hip, mk(O)
+    if kind == "separate":  # one kernel per latent on shared inducing points
+        ls = np.linspace(0.8, 1.4, P)
+        mk = lambda mod, **kw: mod.t_SVGP(mod.SeparateIndependent([mod.SquaredExponential(1.0, float(l)) for l in ls]),
+                                          mod.Gaussian(0.1) if lik == "gaussian" else mod.Bernoulli(),
+                                          mod.SharedIndependentInducingVariables(Z), num_latent_gps=P, num_data=num_data, **kw)
+        hip = mk(p, device="cpu")
+        hip._engine = NumpyShardEngine()
+        return hip, mk(O)
     hip = p.t_SVGP(p.SquaredExponential(1.0, 1.0), p.Gaussian(0.1) if lik == "gaussian" else p.Bernoulli(), Z,
                    num_latent_gps=P, num_data=num_data, device="cpu")
     hip._engine = NumpyShardEngine()  # test double: the HIP engine cannot exist without a GPU
@@ -94,20 +109,21 @@ def test_containers_follow_the_reference():
     assert lo_hi == [(0, 4), (4, 7), (7, 10)]
 
 
-def _worker(rank, world, port, lik, P, out):
+def _worker(rank, world, port, lik, P, out, kind="plain"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         p = pkg()
         X, Y, Z = synthetic(N=401, M=20, D=2, P=P, lik=lik, seed=4)  # 401 rows: uneven shards (201 + 200)
         Xs, Ys = p.distributed.shard_rows(X, Y)
-        hip, _ = _pair(Z, lik, P, num_data=401)
+        hip, _ = _pair(Z, lik, P, num_data=401, kind=kind)
         assert hip._reduce()
         for _ in range(3):
             hip.natgrad_step((Xs, Ys), lr=0.8)
         elbo = float(hip.elbo((Xs, Ys)))
         if rank == 0:
-            np.savez(out, l1=hip.lambda_1.numpy(), L2=hip.lambda_2.numpy(), elbo=elbo)
+            L2 = hip.lambda_2
+            np.savez(out, l1=hip.lambda_1.numpy(), L2=L2.numpy(), elbo=elbo)
     finally:
         dist.destroy_process_group()
 
@@ -120,6 +136,22 @@ def test_sharded_estep_gloo_world2_matches_single_process_oracle(tmp_path, lik, 
     got = np.load(out)
     X, Y, Z = synthetic(N=401, M=20, D=2, P=P, lik=lik, seed=4)
     _, ora = _pair(Z, lik, P, num_data=401)
+    for _ in range(3):
+        ora.natgrad_step((X, Y), lr=0.8)
+    assert relerr(got["l1"], ora.lambda_1) < 1e-9
+    assert relerr(got["L2"], ora.lambda_2) < 1e-9
+    assert abs(float(got["elbo"]) - ora.elbo((X, Y))) < 1e-9 * abs(ora.elbo((X, Y)))
+
+
+@pytest.mark.parametrize("kind,lik,P", [("white", "bernoulli", 1), ("separate", "gaussian", 2)])
+def test_sharded_variants_gloo_world2(tmp_path, kind, lik, P):
+    """The same world_size-2 shard + all-reduce path for t_SVGP_white and for separate per-latent kernels."""
+    out = str(tmp_path / "r0.npz")
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, lik, P, out, kind), nprocs=2, join=True)
+    got = np.load(out)
+    X, Y, Z = synthetic(N=401, M=20, D=2, P=P, lik=lik, seed=4)
+    _, ora = _pair(Z, lik, P, num_data=401, kind=kind)
     for _ in range(3):
         ora.natgrad_step((X, Y), lr=0.8)
     assert relerr(got["l1"], ora.lambda_1) < 1e-9

@@ -324,3 +324,40 @@ def test_separate_kernels_are_independent_models():
         same.natgrad_step((X, Y), lr=0.8)
     np.testing.assert_allclose(same.lambda_1, shared.lambda_1, rtol=1e-7, atol=1e-9)
     assert abs(same.elbo((X, Y)) - shared.elbo((X, Y))) < 1e-8 * abs(shared.elbo((X, Y)))
+
+
+def test_white_model_pins():
+    """t_SVGP_white restated (oracle) against the reference's own relational tests, all computable without GPflow:
+    tests/models/test_tsvgp_white.py:64-91 (white == unwhitened t-SVGP: initial ELBO, initial predictions, predictions
+    after one lr=0.9 step; decimal=4 there), :94-115 (one lr=1 step with Z = X reaches the exact-GP optimum) and
+    tests/models/test_condit.py:69-83 (one lr=1 step == Titsias' collapsed SGPR posterior; closed form restated in
+    oracle.sgpr_predict_f)."""
+    rng = np.random.RandomState(123)
+
+    def func(x):
+        return np.sin(x * 3 * 3.14) + 0.3 * np.cos(x * 9 * 3.14) + 0.5 * np.sin(x * 7 * 3.14)
+
+    X = rng.rand(8, 1) * 2 - 1
+    Y = func(X) + 0.2 * rng.randn(8, 1)
+    k = O.SquaredExponential(variance=2.25, lengthscales=2.0)
+    plain, white = O.t_SVGP(k, O.Gaussian(0.3), X.copy()), O.t_SVGP_white(k, O.Gaussian(0.3), X.copy())
+    np.testing.assert_almost_equal(plain.elbo((X, Y)), white.elbo((X, Y)), decimal=4)
+    for a, b in zip(plain.predict_f(X), white.predict_f(X)):
+        np.testing.assert_array_almost_equal(a, b, decimal=4)
+    plain.natgrad_step((X, Y), lr=0.9)
+    white.natgrad_step((X, Y), lr=0.9)
+    for a, b in zip(plain.predict_f(X), white.predict_f(X)):
+        np.testing.assert_array_almost_equal(a, b, decimal=4)
+    opt = O.t_SVGP_white(k, O.Gaussian(0.3), X.copy())
+    opt.natgrad_step((X, Y * 0), lr=1.0)
+    np.testing.assert_almost_equal(opt.elbo((X, Y * 0)), O.gpr_log_marginal_likelihood(k, X, Y * 0, 0.3), decimal=4)
+    k1 = O.SquaredExponential(1.0, 1.0)
+    for seed in range(4):  # seeds with well separated inducing points (cond K_uu < 100)
+        rs = np.random.RandomState(seed)
+        Xs, Ys, Zs = rs.randn(10, 1), rs.randn(10, 1), rs.randn(3, 1)
+        w = O.t_SVGP_white(k1, O.Gaussian(0.3), Zs)
+        w.natgrad_step((Xs, Ys), lr=1.0)
+        m1, v1 = w.predict_f(Ys)
+        m2, v2 = O.sgpr_predict_f(k1, Xs, Ys, Zs, 0.3, Ys)
+        np.testing.assert_array_almost_equal(m1, m2, decimal=6)
+        np.testing.assert_array_almost_equal(v1, v2, decimal=6)
