@@ -91,7 +91,7 @@ def make_kernel(mod, w):
     return mod.SquaredExponential(variance=var, lengthscales=w.get("lengthscales", 1.0)), (lambda Z: Z)
 
 
-def cpu_baseline(w, budget_s=20.0, model_kind="tsvgp", model_kind=args.model):
+def cpu_baseline(w, budget_s=20.0, model_kind="tsvgp"):
     """The CPU oracle (op-for-op port of the reference sequence) timed on a bounded row sample of the same workload."""
     from oracle import tsvgp_oracle as O
 
@@ -268,7 +268,7 @@ def main():
             "kernel_ms_per_step": round(sum(v[0] * v[1] for v in prof.values()) / args.steps, 4),
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(w, args.cpu_budget)
+            out["cpu_baseline"] = cpu_baseline(w, args.cpu_budget, model_kind=args.model)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
