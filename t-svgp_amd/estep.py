@@ -176,8 +176,7 @@ class EStepEngine:
         W = torch.zeros((nb, Mp, Mp), dtype=torch.float64, device=self.device)
         W[:, :M, :M] = A.reshape(nb, M, M)
         if Mp > M:
-            idx = torch.arange(M, Mp, device=self.device)
-            W[:, idx, idx] = 1.0  # chol([[A, 0], [0, I]]) = [[L, 0], [0, I]]
+            W.diagonal(dim1=-2, dim2=-1)[:, M:] = 1.0  # chol([[A, 0], [0, I]]) = [[L, 0], [0, I]]  (a fill: capturable)
         info = torch.empty(nb, dtype=torch.int32, device=self.device)
         work = self._get("potrf_work", (nb, 128 * 128), torch.float64)
         out_shape = tuple(batch_shape) + (M, M)

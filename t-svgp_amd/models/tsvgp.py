@@ -104,7 +104,7 @@ class t_SVGP(base_SVGP):
 
     def __init__(self, kernel, likelihood, inducing_variable, *, mean_function=None, num_latent_gps: int = 1,
                  lambda_1=None, lambda_2_sqrt=None, num_data=None, force=False, compute_dtype=None, device=None,
-                 cache_whitened=False, projection="auto"):
+                 cache_whitened=False, projection="auto", use_graph=False):
         super().__init__(kernel, likelihood, inducing_variable, mean_function=mean_function,
                          num_latent_gps=num_latent_gps, num_data=num_data, compute_dtype=compute_dtype, device=device)
         self.num_inducing = self.inducing_variable.num_inducing
@@ -126,6 +126,9 @@ class t_SVGP(base_SVGP):
             raise ValueError("projection must be 'auto', 'whitened' or 'direct'")
         self.projection = projection
         self._cond_cache = None
+        # Opt-in: replay natgrad_step from a captured hipGraph (see _graph_step); pays off when the step is launch bound
+        self.use_graph = use_graph
+        self._graphs = {}
         self.name = "t_svgp"  # tf.Module derives this from the class name (experiments/uci_regression.py:150)
 
     def _init_variational_parameters(self, num_inducing, lambda_1, lambda_2_sqrt, **kwargs):
@@ -260,15 +263,17 @@ class t_SVGP(base_SVGP):
                 ops["whiten_T"] = [None if d else Uinv9[p] for p, d in enumerate(direct)]
         return ops
 
-    def _check_step(self, ops, nonpos, extra_infos=(), soft_final=False):
-        """ONE device->host read per call: Cholesky statuses and the count of non-positive variances.
-        Returns True when the step stands; "whiten" when soft_final is set and the final factorisation failed (the
-        direct projection lost definiteness: the caller retries with the whitened route); raises FloatingPointError
-        for what TensorFlow raises on (tsvgp.py:113 assert_positive; failed Cholesky)."""
+    def _status_flags(self, ops, nonpos, extra_infos=()) -> torch.Tensor:
+        """Device tensor [3]: failed prelude factorisations, count of non-positive variances, failed final one."""
         zero = torch.zeros(1, dtype=torch.float64, device=self.device)
         final = torch.cat(list(extra_infos)).sum().reshape(1) if len(extra_infos) else zero
-        flags = torch.cat([torch.cat(list(ops["infos"])).sum().reshape(1), nonpos.reshape(1).to(torch.float64),
-                           final]).cpu()
+        return torch.cat([torch.cat(list(ops["infos"])).sum().reshape(1), nonpos.reshape(1).to(torch.float64), final])
+
+    @staticmethod
+    def _judge(flags, soft_final=False):
+        """Host side of the status check.  Returns True when the step stands; "whiten" when soft_final is set and the
+        final factorisation failed (the direct projection lost definiteness: the caller retries with the whitened
+        route); raises FloatingPointError for what TensorFlow raises on (tsvgp.py:113 assert_positive; failed Cholesky)."""
         if float(flags[0]) != 0:  # factorisation of W or of K_uu + jitter I
             raise FloatingPointError("Cholesky decomposition was not successful (matrix not positive definite)")
         if not (float(flags[1]) == 0):  # a NaN count also lands here
@@ -278,6 +283,10 @@ class t_SVGP(base_SVGP):
                 return "whiten"
             raise FloatingPointError("Cholesky decomposition was not successful (matrix not positive definite)")
         return True
+
+    def _check_step(self, ops, nonpos, extra_infos=(), soft_final=False):
+        """ONE device->host read per call: Cholesky statuses and the count of non-positive variances."""
+        return self._judge(self._status_flags(ops, nonpos, extra_infos).cpu(), soft_final)
 
     def get_mean_chol_cov_inducing_posterior(self):
         """Mean and Cholesky factor of q(u) = N(u; m, S) (tsvgp.py:202-212)."""
@@ -359,19 +368,15 @@ class t_SVGP(base_SVGP):
         Updates the parameters in place and returns None.  The whole step is enqueued without host
         synchronisation; one device->host read of the status flags ends it."""
         X, Y = self._as_device(data[0]), self._as_device(data[1])
-        old_l1, old_L = self.lambda_1.value, self.lambda_2_sqrt.value
         direct = self._use_direct(jitter)
+        if self.use_graph and self._graph_step(X, Y, lr, jitter, direct):
+            return
+        old_l1, old_L = self.lambda_1.value, self.lambda_2_sqrt.value
         none = [False] * self.num_latent_gps
         for use_direct in ((direct, none) if any(direct) else (none,)):  # all-whitened is the fallback of any direct latent
-            warm_key = self._warm_key(X, jitter)
-            ops = self._site_operands(whiten_jitter=jitter, warm_key=warm_key, direct=use_direct)
-            st = self._get_engine().run(X, Y, ops["Z"], self.kernel, moment_Tm=ops["moment_Tm"],
-                                        moment_mode=ops["moment_mode"], gamma=ops["gamma"],
-                                        lik_id=self.likelihood.lik_id, lik_param=self.likelihood.lik_param,
-                                        whiten_T=ops["whiten_T"], whiten_mode=ops["whiten_mode"], sites=True,
-                                        b_tag=warm_key)
             try:
-                verdict = self._apply_site_update(st, ops, lr, jitter, soft_final=any(use_direct))
+                flags = self._step_device(X, Y, lr, jitter, use_direct)
+                verdict = self._judge(flags.cpu(), soft_final=any(use_direct))
             except FloatingPointError:
                 self.lambda_1.assign(old_l1)  # the reference raises before its assigns: leave the state untouched
                 self.sites.assign_lambda_2_sqrt(old_L)
@@ -387,9 +392,89 @@ class t_SVGP(base_SVGP):
                 self._cond_cache = (self._cond_cache[0], [float("inf")] * self.num_latent_gps)
         raise FloatingPointError("Cholesky decomposition was not successful (matrix not positive definite)")
 
-    def _apply_site_update(self, st, ops, lr, jitter, soft_final=False):
+    def _step_device(self, X, Y, lr, jitter, use_direct, inplace=False) -> torch.Tensor:
+        """The whole E-step as device work, no host synchronisation: M x M prelude, N-pass, all-reduce, epilogue, state
+        assignment.  Returns the status flags (device).  With ``inplace`` the state tensors are overwritten in place
+        (what a captured graph needs) instead of being replaced."""
+        warm_key = self._warm_key(X, jitter)
+        ops = self._site_operands(whiten_jitter=jitter, warm_key=warm_key, direct=use_direct)
+        st = self._get_engine().run(X, Y, ops["Z"], self.kernel, moment_Tm=ops["moment_Tm"],
+                                    moment_mode=ops["moment_mode"], gamma=ops["gamma"],
+                                    lik_id=self.likelihood.lik_id, lik_param=self.likelihood.lik_param,
+                                    whiten_T=ops["whiten_T"], whiten_mode=ops["whiten_mode"], sites=True,
+                                    b_tag=warm_key)
+        return self._apply_site_update(st, ops, lr, jitter, inplace=inplace)
+
+    # -- hipGraph replay of the step (launch-bound problem sizes) -------------------------------------------------
+    def _graph_step(self, X, Y, lr, jitter, direct) -> bool:
+        """Runs the step by replaying a captured graph (torch.cuda.CUDAGraph = hipGraph on ROCm).  A step is ~130
+        dispatches; at small N and M (BASELINE configs[0]) launching them costs more than running them.  The graph is
+        keyed on everything that is baked into it at capture: the data buffers, kernel / likelihood / Z parameter
+        versions (scalars travel as kernel arguments), lr, jitter and the projection routes.  The first occurrence of a
+        key runs eagerly (library handles, buffers), the second captures, later ones replay.  Returns False when the
+        caller should run eagerly (not capturable, first occurrence, or the replayed step failed its status check: the
+        state has been restored and the eager path raises or retries exactly as without graphs)."""
+        eng = self._get_engine()
+        if (D_.world_size() > 1 or self.cache_whitened or eng.profile is not None or self.device.type != "cuda"
+                or isinstance(self.kernel, SeparateIndependent)):
+            return False
+        lik_v = tuple(p.version for p in vars(self.likelihood).values() if hasattr(p, "version"))
+        key = (X.data_ptr(), Y.data_ptr(), tuple(X.shape), tuple(Y.shape), X.dtype, Y.dtype, self._kernel_versions(),
+               lik_v, id(self.inducing_variable.Z), self.inducing_variable.Z.version, float(lr), float(jitter),
+               tuple(direct), self.num_data)
+        entry = self._graphs.get(key)
+        if entry is None:
+            self._graphs[key] = "seen"
+            return False
+        l1p, Lp = self.lambda_1, self.sites._lambda_2_sqrt
+        if entry == "seen":
+            if len(self._graphs) > 4:  # each graph owns its buffers (K(X, Z) among them): keep few
+                self._graphs = {key: "seen"}
+            sl1, sL = l1p.value.clone(), Lp.value.clone()  # static state tensors the graph reads and writes
+            bl1, bL = torch.empty_like(sl1), torch.empty_like(sL)
+            l1p._value, Lp._value = sl1, sL
+            graph = torch.cuda.CUDAGraph()
+            saved_buf, saved_tag = eng._buf, eng._b_tag
+            eng._buf, eng._b_tag = {}, None  # the graph's own work buffers (kept alive by the entry)
+            try:
+                with torch.cuda.graph(graph):
+                    bl1.copy_(sl1)
+                    bL.copy_(sL)
+                    flags = self._step_device(X, Y, lr, jitter, direct, inplace=True)
+                entry = dict(graph=graph, flags=flags, state=(sl1, sL), backup=(bl1, bL), buf=eng._buf)
+                self._graphs[key] = entry
+            except Exception:  # not capturable on this stack: never try this key again
+                self._graphs[key] = "seen-uncapturable"
+                entry = None
+            finally:
+                eng._buf, eng._b_tag = saved_buf, saved_tag
+            if entry is None:
+                return False
+        elif not isinstance(entry, dict):
+            return False
+        sl1, sL = entry["state"]
+        if l1p._value is not sl1:  # the state was replaced since (an eager step, a user assign): bring it in
+            sl1.copy_(l1p.value)
+            l1p._value = sl1
+        if Lp._value is not sL:
+            sL.copy_(Lp.value)
+            Lp._value = sL
+        entry["graph"].replay()
+        try:
+            ok = self._judge(entry["flags"].cpu(), soft_final=any(direct)) is True
+        except FloatingPointError:
+            ok = False
+        if not ok:  # put the pre-step state back; the eager path then raises or falls back as it always does
+            sl1.copy_(entry["backup"][0])
+            sL.copy_(entry["backup"][1])
+            return False
+        l1p.version += 1
+        Lp.version += 1
+        return True
+
+    def _apply_site_update(self, st, ops, lr, jitter, inplace=False):
         """All-reduce of the packed accumulators (RCCL) + the replicated M x M epilogue (tsvgp.py:278-303).
-        Returns ``_check_step``'s verdict."""
+        Returns the status flags (device tensor, see ``_status_flags``)."""
         P, M = self.num_latent_gps, self.num_inducing
         packed = D_.pack_stats(st, with_sites=True)
         if self._reduce():
@@ -428,7 +513,11 @@ class t_SVGP(base_SVGP):
         lambda_2 = (1 - lr) * lambda_2 + lr * scale * grad_mu[1]  # tsvgp.py:297
         final_info = []
         lambda_2_sqrt = -cholesky_deferred(-2.0 * lambda_2 + ops["Id"] * jitter, final_info, ops["potrf"])  # tsvgp.py:300
-        self.lambda_1.assign(lambda_1)  # tsvgp.py:302
-        self.sites.assign_lambda_2_sqrt(lambda_2_sqrt)  # tsvgp.py:303
+        if inplace:
+            self.lambda_1.value.copy_(lambda_1)
+            self.lambda_2_sqrt.value.copy_(torch.tril(lambda_2_sqrt))
+        else:
+            self.lambda_1.assign(lambda_1)  # tsvgp.py:302
+            self.sites.assign_lambda_2_sqrt(lambda_2_sqrt)  # tsvgp.py:303
         # tsvgp.py:304 recomputes the posterior and discards it: dead work, not reproduced.
-        return self._check_step(ops, nonpos, final_info, soft_final=soft_final)
+        return self._status_flags(ops, nonpos, final_info)

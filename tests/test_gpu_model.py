@@ -340,3 +340,50 @@ def test_matern_kernels_match_oracle(name):
     mu_h, var_h = hip.predict_f(X[:100] + 0.05)
     mu_o, var_o = ora.predict_f(X[:100] + 0.05)
     assert relerr(mu_h.cpu().numpy(), mu_o) < 1e-8 and relerr(var_h.cpu().numpy(), var_o) < 1e-8
+
+
+@pytest.mark.parametrize("lik", ["gaussian", "bernoulli"])
+def test_graph_replay_matches_eager(lik):
+    """use_graph=True: the step is captured into a hipGraph on the second call with the same (data, parameters, lr) and
+    replayed afterwards; states, ELBO and the invalidation on a parameter change must equal the eager path's."""
+    p = pkg()
+    X, Y, Z = synthetic(N=500, M=32, D=3, P=1, lik=lik, seed=3)
+    Xd, Yd = torch.as_tensor(X, device="cuda:0"), torch.as_tensor(Y, device="cuda:0")
+    mk = lambda **kw: p.t_SVGP(p.SquaredExponential(1.0, 1.0), p.Gaussian(0.1) if lik == "gaussian" else p.Bernoulli(), Z, **kw)
+    eager, graph = mk(), mk(use_graph=True)
+    for step in range(6):
+        eager.natgrad_step((Xd, Yd), lr=0.6)
+        graph.natgrad_step((Xd, Yd), lr=0.6)
+        assert relerr(graph.lambda_1.numpy(), eager.lambda_1.numpy()) < 1e-13, step
+        assert relerr(graph.lambda_2.cpu().numpy(), eager.lambda_2.cpu().numpy()) < 1e-13, step
+    captured = [e for e in graph._graphs.values() if isinstance(e, dict)]
+    assert len(captured) == 1  # steps 3.. were replays of one graph
+    assert abs(float(graph.elbo((Xd, Yd))) - float(eager.elbo((Xd, Yd)))) < 1e-12 * abs(float(eager.elbo((Xd, Yd))))
+    # a hyperparameter change is a new key: eager once, then a new capture; a user assign to the state is picked up
+    for m in (eager, graph):
+        m.kernel.lengthscales.assign(0.8)
+        m.lambda_1.assign(m.lambda_1.value * 0.5)
+    for step in range(3):
+        eager.natgrad_step((Xd, Yd), lr=0.6)
+        graph.natgrad_step((Xd, Yd), lr=0.6)
+        assert relerr(graph.lambda_1.numpy(), eager.lambda_1.numpy()) < 1e-13
+    assert len([e for e in graph._graphs.values() if isinstance(e, dict)]) == 2
+
+
+def test_graph_replay_error_path_restores_state():
+    """A replayed step that fails its status check leaves the state untouched and raises like the eager path."""
+    p = pkg()
+    X, Y, Z = synthetic(N=300, M=16, D=2, P=1, lik="gaussian", seed=2)
+    Xd, Yd = torch.as_tensor(X, device="cuda:0"), torch.as_tensor(Y, device="cuda:0")
+    m = p.t_SVGP(p.SquaredExponential(1.0, 1.0), p.Gaussian(0.1), Z, use_graph=True)
+    for _ in range(3):
+        m.natgrad_step((Xd, Yd), lr=0.5)
+    assert any(isinstance(e, dict) for e in m._graphs.values())
+    bad = m.lambda_2_sqrt.value.clone()
+    bad[0, 3, 3] = float("nan")  # poisons W: the prelude factorisation reports failure
+    m.sites.assign_lambda_2_sqrt(bad)
+    l1 = m.lambda_1.numpy().copy()
+    with pytest.raises(FloatingPointError):
+        m.natgrad_step((Xd, Yd), lr=0.5)
+    assert np.array_equal(m.lambda_1.numpy(), l1)
+    assert np.isnan(m.lambda_2_sqrt.numpy()[0, 3, 3])
