@@ -135,6 +135,24 @@ int tsvgp_potrf_f64(double *A, int M, int lda, int batch, int64_t stride, int32_
 int tsvgp_potrf_inv_f64(double *A, int M, int lda, int batch, int64_t stride, int32_t *info, double *work, double *X,
                         double *Xt, double *T, void *stream);
 
+/* (8) Kernel-parameter gradient contraction for the M-step (d ELBO / d theta with the sites fixed: reference
+ *     experiments/uci_regression.py:159-160, pinned by tests/models/test_tsvgp.py:168-188; TensorFlow autodiff there).
+ *     For one latent GP, with V[n,m] = g0[n] beta[m] - 2 g1[n] U[n,m] (U = K_fu Q from tsvgp_trmm, Q = D^T D):
+ *        sum_{n,m} V[n,m] * dK[n,m]/d variance,   /d lengthscale_d,   and per m  sum_n V[n,m] * dK[n,m]/d Z[m,d].
+ *     X [N x D], Z [M x D], U [N x ldu]; g0, g1 with element stride gstride (so a column of an [N x P] array can be
+ *     passed), beta with stride bstride.  Outputs are per-block partial sums to be added by the caller:
+ *        zpart [nrb x Mp x Dp], lpart [nrb x ncb x Dp], vpart [nrb x ncb],   nrb = ceil(N / tsvgp_kernel_grad_rows()),
+ *        ncb = ceil(Mp / 512), Mp = M rounded up to 128, Dp = tsvgp_kernel_grad_dpad(D)  (D <= 16). */
+int tsvgp_kernel_grad_rows(void);
+int tsvgp_kernel_grad_dpad(int D);
+int tsvgp_kernel_grad_f64(int kind, const double *X, const double *Z, const double *inv_ls, double variance,
+                          const double *U, int64_t ldu, const double *g0, const double *g1, int gstride,
+                          const double *beta, int bstride, int64_t N, int M, int D, double *zpart, double *lpart,
+                          double *vpart, void *stream);
+int tsvgp_kernel_grad_f32(int kind, const float *X, const float *Z, const float *inv_ls, float variance, const float *U,
+                          int64_t ldu, const float *g0, const float *g1, int gstride, const float *beta, int bstride,
+                          int64_t N, int M, int D, double *zpart, double *lpart, double *vpart, void *stream);
+
 /* Device self-test of the MFMA fragment maps used above (writes a 16x16 product C = A*B, k = 4, for host checking).
  * a [16 x 4], b [4 x 16], c [16 x 16] row-major. */
 int tsvgp_selftest_mfma_f64(const double *a, const double *b, double *c, void *stream);

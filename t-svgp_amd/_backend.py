@@ -57,6 +57,12 @@ _PROTOTYPES = {
     "tsvgp_se_fill_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int, c_int, c_int64, c_void_p]),
     "tsvgp_kernel_fill_f64": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_double, c_void_p, c_int64, c_int, c_int, c_int64, c_void_p]),
     "tsvgp_kernel_fill_f32": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int, c_int, c_int64, c_void_p]),
+    "tsvgp_kernel_grad_rows": (c_int, []),
+    "tsvgp_kernel_grad_dpad": (c_int, [c_int]),
+    "tsvgp_kernel_grad_f64": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_double, c_void_p, c_int64, c_void_p, c_void_p, c_int,
+                                      c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "tsvgp_kernel_grad_f32": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_void_p, c_void_p, c_int,
+                                      c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "tsvgp_trmm_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "tsvgp_trmm_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "tsvgp_moments_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_int, c_double, c_void_p, c_void_p,

@@ -311,6 +311,140 @@ __global__ __launch_bounds__(NTHREADS) void se_fill_kernel(const T* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// kgrad_kernel: the N-sized part of d ELBO / d (variance, lengthscales, Z) for one latent GP (M-step, reference
+// experiments/uci_regression.py:159-160).  With s = sum_d s_d^2, s_d = (x_nd - z_md) / l_d and K = variance * f(s):
+//   V[n, m]  = g0[n] * beta[m] - 2 * g1[n] * U[n, m]                       (U = K_fu Q, a tsvgp_trmm product)
+//   dvar    += V * f(s)
+//   dls[d]  += V * variance * f'(s) * (-2 s_d^2 / l_d)
+//   dZ[m,d] += V * variance * f'(s) * (-2 s_d   / l_d)
+// f'(s) in closed form: SE -f/2;  Matern-3/2 -(3/2) e^-a, a = sqrt(3 s);  Matern-5/2 -(5/6)(1 + a) e^-a, a = sqrt(5 s).
+// HBM bound (one read of U).  Grid (row blocks of KG_ROWS, column tiles of FILL_COLS); thread = two columns, its dZ sums
+// stay in registers over the block's rows; per-block partials are written out and summed by the caller in a fixed order
+// (bitwise reproducible, no atomics).  DT = D padded to a compile-time size (padded dimensions contribute zeros).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int KG_ROWS = 1024;
+constexpr int KG_CHUNK = 64;
+
+template <int KIND, typename T>
+__device__ __forceinline__ void kernel_profile_grad(T s, T& f, T& df) {
+    if constexpr (KIND == TSVGP_KERNEL_SE) {
+        f = exp(T(-0.5) * s);
+        df = T(-0.5) * f;
+    } else {
+        const T r = sqrt(s > T(1e-36) ? s : T(1e-36));
+        if constexpr (KIND == TSVGP_KERNEL_MATERN32) {
+            const T a = T(1.7320508075688772935) * r, e = exp(-a);
+            f = (T(1) + a) * e;
+            df = T(-1.5) * e;
+        } else {
+            const T a = T(2.2360679774997896964) * r, e = exp(-a);
+            f = (T(1) + a + T(5.0 / 3.0) * r * r) * e;
+            df = T(-5.0 / 6.0) * (T(1) + a) * e;
+        }
+    }
+}
+
+template <typename T, int KIND, int DT>
+__global__ __launch_bounds__(NTHREADS) void kgrad_kernel(const T* __restrict__ X, const T* __restrict__ Z,
+                                                         const T* __restrict__ inv_ls, T variance,
+                                                         const T* __restrict__ U, int64_t ldu, const T* __restrict__ g0,
+                                                         const T* __restrict__ g1, int gstride,
+                                                         const T* __restrict__ beta, int bstride, int64_t N, int M, int D,
+                                                         double* __restrict__ zpart, double* __restrict__ lpart,
+                                                         double* __restrict__ vpart, int Mp) {
+    __shared__ T Xs[KG_CHUNK][DT];
+    __shared__ T Gs[KG_CHUNK][2];
+    __shared__ double red[NTHREADS / 64][DT + 1];
+    typedef typename Mfma<T>::pair_t pair_t;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int64_t n0 = (int64_t)blockIdx.x * KG_ROWS;
+    const int m0 = blockIdx.y * FILL_COLS + 2 * t;
+    const bool c0 = m0 < M, c1 = m0 + 1 < M;
+    T z[2][DT], il[DT];
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+        il[d] = d < D ? inv_ls[d] : T(0);
+        z[0][d] = (c0 && d < D) ? Z[(int64_t)m0 * D + d] * il[d] : T(0);
+        z[1][d] = (c1 && d < D) ? Z[(int64_t)(m0 + 1) * D + d] * il[d] : T(0);
+    }
+    const T b0 = c0 ? beta[(int64_t)m0 * bstride] : T(0), b1 = c1 ? beta[(int64_t)(m0 + 1) * bstride] : T(0);
+    double za[2][DT], la[DT], va = 0.0;
+#pragma unroll
+    for (int d = 0; d < DT; ++d) za[0][d] = za[1][d] = la[d] = 0.0;
+    const int64_t nend = (n0 + KG_ROWS < N) ? n0 + KG_ROWS : N;
+    for (int64_t nc = n0; nc < nend; nc += KG_CHUNK) {
+        __syncthreads();
+        for (int idx = t; idx < KG_CHUNK * DT; idx += NTHREADS) {
+            const int rr = idx / DT, d = idx - rr * DT;
+            const int64_t n = nc + rr;
+            Xs[rr][d] = (n < nend && d < D) ? X[n * D + d] * inv_ls[d] : T(0);
+        }
+        if (t < KG_CHUNK) {
+            const int64_t n = nc + t;
+            Gs[t][0] = n < nend ? g0[n * gstride] : T(0);
+            Gs[t][1] = n < nend ? g1[n * gstride] : T(0);
+        }
+        __syncthreads();
+        const int nr = (int)((nend - nc < KG_CHUNK) ? nend - nc : KG_CHUNK);
+        if (c0) {
+#pragma unroll 2
+            for (int rr = 0; rr < nr; ++rr) {
+                const pair_t u = *reinterpret_cast<const pair_t*>(U + (nc + rr) * ldu + m0);
+                const T gg0 = Gs[rr][0], gg1 = Gs[rr][1];
+                T sd[2][DT], s0 = T(0), s1 = T(0);
+#pragma unroll
+                for (int d = 0; d < DT; ++d) {
+                    const T x = Xs[rr][d];
+                    sd[0][d] = x - z[0][d];
+                    sd[1][d] = x - z[1][d];
+                    s0 += sd[0][d] * sd[0][d];
+                    s1 += sd[1][d] * sd[1][d];
+                }
+                T f0, df0, f1, df1;
+                kernel_profile_grad<KIND>(s0, f0, df0);
+                kernel_profile_grad<KIND>(s1, f1, df1);
+                const T v0 = gg0 * b0 - T(2) * gg1 * u[0];
+                const T v1 = c1 ? gg0 * b1 - T(2) * gg1 * u[1] : T(0);
+                va += (double)(v0 * f0) + (double)(v1 * f1);
+                const T w0 = T(-2) * variance * v0 * df0, w1 = T(-2) * variance * v1 * df1;
+#pragma unroll
+                for (int d = 0; d < DT; ++d) {
+                    const T p0 = w0 * sd[0][d], p1 = w1 * sd[1][d];
+                    za[0][d] += (double)p0;  // times 1 / l_d below
+                    za[1][d] += (double)p1;
+                    la[d] += (double)(p0 * sd[0][d]) + (double)(p1 * sd[1][d]);
+                }
+            }
+        }
+    }
+    // dZ partials: this thread's two columns
+    const int64_t zb = ((int64_t)blockIdx.x * Mp) * DT;
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+        if (c0) zpart[zb + (int64_t)m0 * DT + d] = za[0][d] * (double)il[d];
+        if (c1) zpart[zb + (int64_t)(m0 + 1) * DT + d] = za[1][d] * (double)il[d];
+    }
+    // lengthscale / variance partials: sum over the workgroup's threads
+#pragma unroll
+    for (int d = 0; d <= DT; ++d) {
+        double v = d < DT ? la[d < DT ? d : 0] * (double)il[d < DT ? d : 0] : va;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) red[w][d] = v;
+    }
+    __syncthreads();
+    if (t <= DT) {
+        double v = 0.0;
+        for (int u = 0; u < NTHREADS / 64; ++u) v += red[u][t];
+        const int64_t blk = (int64_t)blockIdx.x * gridDim.y + blockIdx.y;
+        if (t < DT)
+            lpart[blk * DT + t] = v;
+        else
+            vpart[blk] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // panel_kernel: one workgroup per 128-row panel of A; loops over latents p, output column tiles `it`, k-chunks.
 //   C[n, i] = sum_{j in range(i)} A[n, j] * Tm[p][i, j]
 // ---------------------------------------------------------------------------------------------------------------
@@ -1861,6 +1995,43 @@ int potrf(double* A, int M, int lda, int batch, int64_t stride, int* info, doubl
     return launch_status();
 }
 
+template <typename T>
+int kernel_grad(int kind, const T* X, const T* Z, const T* inv_ls, T variance, const T* U, int64_t ldu, const T* g0,
+                const T* g1, int gstride, const T* beta, int bstride, int64_t N, int M, int D, double* zpart,
+                double* lpart, double* vpart, void* stream) {
+    if (!X || !Z || !inv_ls || !U || !g0 || !g1 || !beta || !zpart || !lpart || !vpart || N <= 0 || M <= 0 || D <= 0 ||
+        D > 16 || gstride <= 0 || bstride <= 0 || (ldu % 2) != 0)
+        return TSVGP_EINVAL;
+    if (kind != TSVGP_KERNEL_SE && kind != TSVGP_KERNEL_MATERN32 && kind != TSVGP_KERNEL_MATERN52) return TSVGP_EINVAL;
+    const int Mp = (M + TILE - 1) / TILE * TILE;
+    if (ldu < Mp) return TSVGP_EINVAL;
+    const dim3 grid((unsigned)((N + KG_ROWS - 1) / KG_ROWS), (unsigned)((Mp + FILL_COLS - 1) / FILL_COLS));
+    hipStream_t st = (hipStream_t)stream;
+    const int DT = D <= 1 ? 1 : D <= 2 ? 2 : D <= 4 ? 4 : D <= 8 ? 8 : 16;
+    if (hipMemsetAsync(zpart, 0, sizeof(double) * (size_t)grid.x * Mp * DT, st) != hipSuccess) return TSVGP_ELAUNCH;
+#define TSVGP_KG_LAUNCH(KIND_, DT_)                                                                                  \
+    hipLaunchKernelGGL((kgrad_kernel<T, KIND_, DT_>), grid, dim3(NTHREADS), 0, st, X, Z, inv_ls, variance, U, ldu, g0, g1, \
+                       gstride, beta, bstride, N, M, D, zpart, lpart, vpart, Mp)
+#define TSVGP_KG_DT(KIND_)                          \
+    switch (DT) {                                   \
+        case 1: TSVGP_KG_LAUNCH(KIND_, 1); break;   \
+        case 2: TSVGP_KG_LAUNCH(KIND_, 2); break;   \
+        case 4: TSVGP_KG_LAUNCH(KIND_, 4); break;   \
+        case 8: TSVGP_KG_LAUNCH(KIND_, 8); break;   \
+        default: TSVGP_KG_LAUNCH(KIND_, 16); break; \
+    }
+    if (kind == TSVGP_KERNEL_SE) {
+        TSVGP_KG_DT(TSVGP_KERNEL_SE)
+    } else if (kind == TSVGP_KERNEL_MATERN32) {
+        TSVGP_KG_DT(TSVGP_KERNEL_MATERN32)
+    } else {
+        TSVGP_KG_DT(TSVGP_KERNEL_MATERN52)
+    }
+#undef TSVGP_KG_DT
+#undef TSVGP_KG_LAUNCH
+    return launch_status();
+}
+
 }  // namespace
 
 extern "C" {
@@ -1931,6 +2102,21 @@ int tsvgp_potrf_inv_f64(double* A, int M, int lda, int batch, int64_t stride, in
     return potrf(A, M, lda, batch, stride, info, work, stream, X, Xt, T);
 }
 
+int tsvgp_kernel_grad_rows(void) { return KG_ROWS; }
+int tsvgp_kernel_grad_dpad(int D) { return D <= 1 ? 1 : D <= 2 ? 2 : D <= 4 ? 4 : D <= 8 ? 8 : 16; }
+int tsvgp_kernel_grad_f64(int kind, const double* X, const double* Z, const double* inv_ls, double variance,
+                          const double* U, int64_t ldu, const double* g0, const double* g1, int gstride,
+                          const double* beta, int bstride, int64_t N, int M, int D, double* zpart, double* lpart,
+                          double* vpart, void* stream) {
+    return kernel_grad<double>(kind, X, Z, inv_ls, variance, U, ldu, g0, g1, gstride, beta, bstride, N, M, D, zpart, lpart,
+                               vpart, stream);
+}
+int tsvgp_kernel_grad_f32(int kind, const float* X, const float* Z, const float* inv_ls, float variance, const float* U,
+                          int64_t ldu, const float* g0, const float* g1, int gstride, const float* beta, int bstride,
+                          int64_t N, int M, int D, double* zpart, double* lpart, double* vpart, void* stream) {
+    return kernel_grad<float>(kind, X, Z, inv_ls, variance, U, ldu, g0, g1, gstride, beta, bstride, N, M, D, zpart, lpart,
+                              vpart, stream);
+}
 int tsvgp_selftest_mfma_f64(const double* a, const double* b, double* c, void* stream) {
     if (!a || !b || !c) return TSVGP_EINVAL;
     hipLaunchKernelGGL(selftest_kernel<double>, dim3(1), dim3(64), 0, (hipStream_t)stream, a, b, c);

@@ -202,6 +202,32 @@ class EStepEngine:
                                                                       mode, self._stream()))
         return C
 
+    def kernel_grad(self, X, Z, kernel, U, g0, g1, beta):
+        """N-sized part of d ELBO / d (variance, lengthscales, Z) for ONE latent GP (``tsvgp_kernel_grad_*``):
+        sum_{n,m} V[n,m] dK[n,m]/d theta with V = g0 beta^T - 2 g1 * U.  X [N, D], Z [M, D], U [Np, Mp] (compute dtype);
+        g0, g1: columns of the [Np, P] gradient buffers (any element stride), beta [M] fp64.
+        Returns (d_variance scalar, d_lengthscales [D], d_Z [M, D]) in fp64."""
+        T, dev = self.dtype, self.device
+        X = X.to(device=dev, dtype=T).contiguous()
+        Z = Z.to(device=dev, dtype=T).contiguous()
+        N, D = X.shape
+        M = Z.shape[0]
+        Mp = B.round_up(M)
+        inv_ls = kernel.inv_lengthscales(D, T, dev)
+        rows, Dp = int(self.lib.tsvgp_kernel_grad_rows()), int(self.lib.tsvgp_kernel_grad_dpad(D))
+        nrb, ncb = (N + rows - 1) // rows, (Mp + 511) // 512
+        zpart = torch.empty((nrb, Mp, Dp), dtype=torch.float64, device=dev)
+        lpart = torch.empty((nrb, ncb, Dp), dtype=torch.float64, device=dev)
+        vpart = torch.empty((nrb, ncb), dtype=torch.float64, device=dev)
+        bt = beta.to(device=dev, dtype=T).contiguous()
+        assert g0.dim() == 1 and g1.dim() == 1 and g0.stride(0) == g1.stride(0)
+        with torch.cuda.device(dev):
+            self._launch("tsvgp_kernel_grad", lambda: self._fn("tsvgp_kernel_grad")(
+                kernel.kind, X.data_ptr(), Z.data_ptr(), inv_ls.data_ptr(), kernel.variance.item(), U.data_ptr(), U.shape[1],
+                g0.data_ptr(), g1.data_ptr(), g0.stride(0), bt.data_ptr(), 1, N, M, D, zpart.data_ptr(), lpart.data_ptr(),
+                vpart.data_ptr(), self._stream()))
+        return vpart.sum(), lpart.sum(dim=(0, 1))[:D], zpart.sum(dim=0)[:M, :D]
+
     def selftest_mfma(self, dtype=None):
         """Runs one MFMA and returns (a, b, c) for a host-side check of the fragment maps."""
         dtype = dtype or self.dtype

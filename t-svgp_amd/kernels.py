@@ -38,11 +38,27 @@ class SquaredExponential:
         X = to_tensor(X)
         return self.variance.value.expand(X.shape[0]).clone()
 
+    @staticmethod
+    def _profile(s: torch.Tensor) -> torch.Tensor:
+        return torch.exp(-0.5 * s)
+
+    def K_torch(self, Z: torch.Tensor, variance: torch.Tensor, lengthscales: torch.Tensor) -> torch.Tensor:
+        """K(Z, Z) as a differentiable torch expression of (variance, lengthscales, Z), difference form like the HIP
+        fill.  Only for the M x M part of the M-step gradient (``t_SVGP.elbo_and_grads``); N-sized work never comes here."""
+        Zs = Z / lengthscales
+        diff = Zs[:, None, :] - Zs[None, :, :]
+        return variance * self._profile(torch.sum(diff * diff, dim=-1))
+
 
 class Matern32(SquaredExponential):
     """``gpflow.kernels.Matern32`` [ext]: variance * (1 + sqrt(3) r) exp(-sqrt(3) r)."""
 
     kind = 2
+
+    @staticmethod
+    def _profile(s):
+        a = torch.sqrt(3.0 * torch.clamp(s, min=1e-36))
+        return (1.0 + a) * torch.exp(-a)
 
 
 class Matern52(SquaredExponential):
@@ -50,6 +66,12 @@ class Matern52(SquaredExponential):
     variance * (1 + sqrt(5) r + 5 r^2 / 3) exp(-sqrt(5) r)."""
 
     kind = 3
+
+    @staticmethod
+    def _profile(s):
+        sc = torch.clamp(s, min=1e-36)
+        a = torch.sqrt(5.0 * sc)
+        return (1.0 + a + 5.0 / 3.0 * sc) * torch.exp(-a)
 
 
 class SeparateIndependent:

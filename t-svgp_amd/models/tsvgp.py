@@ -360,6 +360,86 @@ class t_SVGP(base_SVGP):
         scale = (float(self.num_data) / rows) if self.num_data is not None else 1.0
         return ve_sum * scale - kl
 
+    # -- M-step gradient -----------------------------------------------------------------------
+    def elbo_and_grads(self, data):
+        """ELBO and its gradient with respect to the kernel variance, the lengthscales, the inducing inputs Z and (Gaussian
+        likelihood) the noise variance, with the sites held fixed -- what the reference's M-step differentiates
+        (experiments/uci_regression.py:159-160: Adam on ``training_loss_closure``; TensorFlow autodiff there).
+
+        With g0 = d ve/d mean and g1 = d ve/d var at the current parameters, the chain rule gives
+            d ELBO = scale * sum_np (g0 d mean + g1 d var) - d KL,   mean = k^T beta,  var = kff - k^T Q k,
+        which splits into an N-sized contraction with dK_fu (HIP: fill, moments, the site sums a1 = sum g0 k,
+        A2 = sum g1 k k^T, U = K_fu Q, and ``tsvgp_kernel_grad``) and an M x M part in which a1, A2 are constants
+        (torch autograd over K_uu(theta, Z), its factorisations and the KL).
+        Returns (elbo, {"variance", "lengthscales", "Z", "likelihood_variance" (Gaussian only)}), gradients of the ELBO
+        with respect to the constrained parameter values.  With more than one rank ``data`` is this rank's shard."""
+        if isinstance(self.kernel, SeparateIndependent):
+            raise NotImplementedError("elbo_and_grads covers one shared kernel")
+        X, Y = self._as_device(data[0]), self._as_device(data[1])
+        eng, P, M = self._get_engine(), self.num_latent_gps, self.num_inducing
+        ops = self._site_operands()
+        Dm, beta = ops["D"], ops["beta"]
+        gaussian = self.likelihood.lik_id == B.LIK_GAUSSIAN
+        # the TRUE d ve / d var here: the crop of tsvgp.py:262-263 belongs to the site update, not to the ELBO (with the
+        # 1e-3 jitter of the probit link log p is not log-concave in the far tails, so some g1 are positive)
+        st = eng.run(X, Y, ops["Z"], self.kernel, moment_Tm=Dm, moment_mode=ops["moment_mode"], gamma=beta,
+                     lik_id=self.likelihood.lik_id | B.LIK_NOCROP, lik_param=self.likelihood.lik_param, sites=True,
+                     want_moments=gaussian)
+        Kfu, g0, g1 = eng._buf["Kfu"], eng._buf["g0"], eng._buf["g1"]  # [Np, Mp], [Np, P] (rows >= N are zero)
+        Q = Dm.transpose(-1, -2) @ Dm  # [P, M, M]
+        Ubuf = eng._get("U", tuple(Kfu.shape), Kfu.dtype)
+        dvar = torch.zeros((), dtype=torch.float64, device=self.device)
+        dls = torch.zeros(X.shape[1], dtype=torch.float64, device=self.device)
+        dZ = torch.zeros((M, X.shape[1]), dtype=torch.float64, device=self.device)
+        for p in range(P):
+            eng.trmm(Kfu, eng._pad_square(0.5 * (Q[p] + Q[p].T), Kfu.shape[1], "pad_Q"), Ubuf, B.TRI_DENSE)  # U = K_fu Q_p
+            v, l, z = eng.kernel_grad(X, ops["Z"], self.kernel, Ubuf, g0[:, p], g1[:, p], beta[:, p])
+            dvar, dls, dZ = dvar + v, dls + l, dZ + z
+        extra = [dvar.reshape(1), dls, dZ.reshape(-1), g1.sum(dim=0, dtype=torch.float64).sum().reshape(1)]
+        if gaussian:  # d ve / d s2 = -1/(2 s2) + ((y - m)^2 + v) / (2 s2^2), summed
+            res = torch.sum((Y.to(st.mean.dtype) - st.mean) ** 2 + st.var)
+            extra.append(res.reshape(1))
+        packed = torch.cat([D_.pack_stats(st, with_sites=True)] + extra)
+        if self._reduce():
+            D_.all_reduce_sum(packed)
+        base = P * M * M + P * M + 3
+        acc2, acc1, ve_sum, nonpos, rows = D_.unpack_stats(packed[:base], P, M, True)
+        tail = packed[base:]
+        Dn = X.shape[1]
+        dvar, dls, dZ, sum_g1 = tail[0], tail[1:1 + Dn], tail[1 + Dn:1 + Dn + M * Dn].reshape(M, Dn), tail[1 + Dn + M * Dn]
+        self._check_step(ops, nonpos)
+        scale = (float(self.num_data) / rows) if self.num_data is not None else 1.0
+
+        # M x M part by autograd: a1, A2, sum g1 are constants here
+        k = self.kernel
+        var_t = k.variance.value.detach().to(self.device).clone().requires_grad_(True)
+        ls_t = k.lengthscales.value.detach().to(self.device).clone().requires_grad_(True)
+        Z_t = self._Z().detach().clone().requires_grad_(True)
+        l1, L = self.lambda_1.value.detach(), self.lambda_2_sqrt.value.detach()
+        Id = ops["Id"]
+        with torch.enable_grad():
+            K6 = k.K_torch(Z_t, var_t, ls_t) + default_jitter() * Id
+            W = Id + L.transpose(-1, -2) @ (K6 @ L)
+            cW = torch.linalg.cholesky(0.5 * (W + W.transpose(-1, -2)))
+            Dt = torch.linalg.solve_triangular(cW, L.transpose(-1, -2), upper=False)
+            Qt = Dt.transpose(-1, -2) @ Dt
+            K6l = K6 @ l1
+            beta_t = l1 - torch.einsum("pmk,kp->mp", Qt, K6l)
+            kl = 0.5 * (torch.sum((K6 @ beta_t) * beta_t) - torch.sum(Qt * K6)
+                        + 2.0 * torch.sum(torch.log(torch.diagonal(cW, dim1=-2, dim2=-1))))
+            surrogate = scale * (torch.sum(beta_t * acc1.transpose(-1, -2)) - torch.sum(Qt * acc2) + var_t * sum_g1) - kl
+            g_var, g_ls, g_Z = torch.autograd.grad(surrogate, [var_t, ls_t, Z_t])
+        ls_shape = k.lengthscales.value.shape
+        n_ls = scale * dls
+        grads = {"variance": g_var + scale * dvar,
+                 "lengthscales": g_ls + (n_ls.sum() if len(ls_shape) == 0 else n_ls.reshape(ls_shape)),
+                 "Z": g_Z + scale * dZ}
+        if gaussian:
+            s2 = self.likelihood.lik_param
+            grads["likelihood_variance"] = scale * (-0.5 * rows * P / s2 + 0.5 * tail[-1] / (s2 * s2))
+        elbo = ve_sum * scale - kl.detach()
+        return elbo, grads
+
     # -- the hot path ------------------------------------------------------------------------------------------
     def natgrad_step(self, data, lr=0.1, jitter=1e-9):
         """One natural-gradient step on the site parameters (tsvgp.py:234-304):

@@ -27,8 +27,10 @@ def _worker(rank, world, port, out):
         for _ in range(3):
             m.natgrad_step((Xd, Yd), lr=0.8)
         e = float(m.elbo((Xd, Yd)))
+        e2, grads = m.elbo_and_grads((Xd, Yd))  # M-step gradient: partial sums all-reduced like the accumulators
         if rank == 0:
-            np.savez(out, l1=m.lambda_1.numpy(), L2=m.lambda_2.cpu().numpy(), elbo=e)
+            np.savez(out, l1=m.lambda_1.numpy(), L2=m.lambda_2.cpu().numpy(), elbo=e, elbo2=float(e2),
+                     g_var=grads["variance"].cpu().numpy(), g_ls=grads["lengthscales"].cpu().numpy(), g_Z=grads["Z"].cpu().numpy())
     finally:
         dist.destroy_process_group()
 
@@ -45,3 +47,12 @@ def test_two_ranks_on_one_gpu_match_single_process(tmp_path):
     assert relerr(got["l1"], ora.lambda_1) < 1e-8
     assert relerr(got["L2"], ora.lambda_2) < 1e-8
     assert abs(float(got["elbo"]) - ora.elbo((X, Y))) < 1e-9 * abs(ora.elbo((X, Y)))
+    # sharded gradients == single-process gradients (same state: load the oracle's, identical to 1e-8)
+    p = pkg()
+    single = p.t_SVGP(p.SquaredExponential(1.0, 1.0), p.Bernoulli(), Z, num_data=5001, device="cuda:0",
+                      lambda_1=got["l1"], lambda_2_sqrt=np.linalg.cholesky(got["L2"]) * -1.0)
+    e1, g1 = single.elbo_and_grads((X, Y))
+    assert abs(float(got["elbo2"]) - float(e1)) < 1e-10 * abs(float(e1))
+    assert relerr(got["g_var"], g1["variance"].cpu().numpy()) < 1e-8
+    assert relerr(got["g_ls"], g1["lengthscales"].cpu().numpy()) < 1e-8
+    assert relerr(got["g_Z"], g1["Z"].cpu().numpy()) < 1e-7
