@@ -5,20 +5,23 @@
 // v_mfma_f32_16x16x4_f32 matrix instructions, 160 KiB LDS per CU, 256 CUs in 8 XCDs.
 //
 // Kernel inventory
-//   se_fill_kernel      K(X,Z) tile fill.  HBM-write bound (N*Mp*sizeof(T) bytes).  Z tile and X rows staged in LDS,
-//                       16-byte coalesced stores.
+//   se_fill_kernel      K(X,Z) tile fill (SE, Matern-3/2, Matern-5/2).  Z tile and X rows staged in LDS, 16-byte
+//                       coalesced stores.
 //   panel_kernel<STORE> C = A * Tm^T restricted to a triangular k-range (inverted-factor triangular solve).  MFMA bound.
-//   panel_kernel<MOMENTS>  same product, but the tile is squared and row-summed in registers (never stored), a GEMV from
-//                       the staging registers forms the mean, and the likelihood-gradient map runs in the epilogue.
-//   syrk_kernel         weighted Gram  sum_n g1[n] b_n b_n^T  over an N-slice per workgroup (lower tiles only) + the
+//   panel_kernel<MOMENTS>  same product, but the tile is squared and row-summed in registers (never stored); the mean
+//                       GEMV rides on the first column tile (FUSE) or runs as a pre-pass; the likelihood-gradient map
+//                       runs in the epilogue.
+//   syrk_kernel         weighted Gram  sum_n g1[n] a_n a_n^T  over an N-slice per workgroup (lower tiles only) + the
 //                       first-order sum on diagonal tiles.  MFMA bound.  Partial tiles -> syrk_reduce_kernel (fixed order).
+//   potrf_diag_kernel, chol_tile_kernel, trtri_level_kernel   blocked Cholesky of the M x M site matrices and the
+//                       inverse factor (latency bound; sub-blocked diagonal block, wave-tile products without LDS).
+//   kgrad_kernel        kernel-parameter gradient contraction of the M-step.  HBM bound.
 //
-// Tiling shared by the MFMA kernels: 128x128 output tile per 256-thread workgroup (4 waves as 2x2, 64x64 per wave =
-// 4x4 MFMA tiles of 16x16, 16 accumulator vectors), k-chunks of 16 staged global->registers->LDS with two LDS buffers
-// and one barrier per chunk; 2 workgroups per CU (73.7 KB LDS, <=256 VGPRs each) so one workgroup's barrier and staging
-// hide under the other's MFMAs.  LDS images are padded so that every fragment read (ds_read_b64 / _b32) and every
-// staging write is bank-conflict free:  [row][k] images use a row stride of 18 elements, [k][row] images a k stride of
-// 144 elements.
+// Tiling shared by the N-sized MFMA kernels: 128x128 output tile per 256-thread workgroup; wave w owns row blocks
+// {w, 7 - w} x all eight 16-column blocks (acc[2][8]); k-chunks of 16 staged global->registers->LDS with two LDS
+// buffers and one barrier per chunk; 2 workgroups per CU (<= 80 KB LDS, <= 256 VGPRs each) so one workgroup's barrier
+// and staging hide under the other's MFMAs.  LDS images are padded so that every fragment read and every staging write
+// is bank-conflict free: [row][k] images use a row stride of 17 doubles / 18 floats, [k][row] images a k stride of 144.
 
 #include <hip/hip_runtime.h>
 
@@ -693,320 +696,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void panel_kernel(PanelArgs<T> a) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// fat_panel_kernel (fp64): the same triangular panel product as panel_kernel, restructured for latency tolerance.
-//   * ONE 512-thread workgroup per CU: 8 waves, two per SIMD (waves w and w+4 share a SIMD, so one wave's LDS-DMA
-//     issue, fragment reads and waits hide under the other's MFMAs).  Output tile 128 rows x 256 columns = the two
-//     128-column tiles it = 2q, 2q+1 at once (every A chunk read from HBM feeds twice the MFMAs); wave (r = w & 3,
-//     H = w >> 2) owns row blocks {r, 7 - r} of column tile 2q + H: acc[2][8], <= 256 VGPRs.
-//   * operands go global -> LDS directly (global_load_lds_dwordx4, no staging registers) into a ring of three 48 KB
-//     chunk buffers (A 128x16 + Tm 256x16 doubles): two chunks are in flight while one is computed (8192 MFMA cycles
-//     per SIMD each); one raw s_barrier per chunk behind a counted s_waitcnt vmcnt(6).
-//   * LDS rows are 128 B (8 units of 16 B) with NO padding (an LDS-DMA writes 1 KB lane-linear); bank conflicts are
-//     removed by XOR-swizzling the unit index with (row >> 1) & 7, on the per-lane global source address and on the
-//     fragment reads.
-//   * triangular structure: compile-time column masks per chunk of the two k-tiles on the diagonal, per column half.
-// Requires Mp % 256 == 0 (the launcher falls back to panel_kernel otherwise).
-// ---------------------------------------------------------------------------------------------------------------
-constexpr int FAT_THREADS = 512;
-constexpr int FAT_RING = 3;
-constexpr int FAT_A_D = TILE * KC;            // doubles per A chunk  (2048 = 16 KB)
-constexpr int FAT_T_D = 2 * TILE * KC;        // doubles per Tm chunk (4096 = 32 KB)
-constexpr int FAT_BUF_D = FAT_A_D + FAT_T_D;  // 6144 doubles = 48 KB
-constexpr int FAT_DMA_PER_WAVE = 6;           // (16 + 32) 1-KB blocks per chunk / 8 waves
-
-typedef __attribute__((address_space(3))) void lds_void_t;
-
-// acc[s][n] += A(row block s) * Tm(column block n of this wave's half)^T over one 16-deep chunk.
-// `between(ks)` is called after the MFMAs of k-step ks: the caller spreads its LDS-DMA issue over the chunk so that it
-// hides under MFMAs instead of delaying the first one after the barrier.
-template <int NMASK, typename Between>
-__device__ __forceinline__ void mma_chunk_fat(v4d (&acc)[2][8], const double* __restrict__ abuf,
-                                              const double* __restrict__ tbuf, int r, const int (&off)[4],
-                                              Between between) {
-    const double* a0p = abuf + r * 256;
-    const double* a1p = abuf + (7 - r) * 256;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        if constexpr (NMASK != 0) {
-            const double a0 = a0p[off[ks]];
-            const double a1 = a1p[off[ks]];
-            double b[8];
-#pragma unroll
-            for (int n = 0; n < 8; ++n)
-                if (NMASK & (1 << n)) b[n] = tbuf[n * 256 + off[ks]];
-#pragma unroll
-            for (int n = 0; n < 8; ++n)
-                if (NMASK & (1 << n)) {
-                    acc[0][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b[n], acc[0][n], 0, 0, 0);
-                    acc[1][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b[n], acc[1][n], 0, 0, 0);
-                }
-        }
-        between(ks);
-    }
-}
-
-// The per-wave body; H (column half) is compile time so that every MFMA sequence is straight-line code.
-template <int MODE, int TRI, int H>
-__device__ __forceinline__ void fat_panel_body(const PanelArgs<double>& a, double* lds) {
-    double* const rowq = lds + FAT_RING * FAT_BUF_D;  // [2][TILE]
-    double* const red = rowq + 2 * TILE;              // [16]
-    constexpr int CPT = TILE / KC;                    // 8 chunks per 128-wide k-tile
-
-    const int t = threadIdx.x, lane = t & 63;
-    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int r = w & 3;
-    const int lr = lane & 15, lk = lane >> 4;
-    const int64_t n0 = (int64_t)blockIdx.x * TILE;
-    const int Mp = a.Mp;
-    const int ntile = Mp / TILE, nchunk = Mp / KC, npair = ntile / 2;
-    const int srow = (t & 255) >> 1, skh = t & 1;  // roles of the GEMV pre-pass / epilogue (threads 0..255)
-
-    // fragment read offsets (doubles) inside a 16-row block: row lr, element k = 4 ks + lk, swizzled 16-byte unit
-    int off[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) off[ks] = lr * 16 + (((2 * ks + (lk >> 1)) ^ ((lr >> 1) & 7)) << 1) + (lk & 1);
-
-    // LDS-DMA roles: wave w moves the 1-KB blocks i = w + 8 j (j = 0..5) of each chunk; blocks 0..15 are A rows
-    // 8i.., blocks 16..47 are Tm rows 8(i-16)...  Lane l lands at unit (l & 7) of row (l >> 3) of the block and
-    // fetches global unit (l & 7) ^ ((row >> 1) & 7).
-    const int drow = lane >> 3;
-    int64_t g_off[FAT_DMA_PER_WAVE];  // element offsets (from a.A for A blocks, from the pair's Tm panel otherwise)
-#pragma unroll
-    for (int j = 0; j < FAT_DMA_PER_WAVE; ++j) {
-        const int blk = w + 8 * j;
-        if (blk < 16) {
-            const int row = blk * 8 + drow;
-            g_off[j] = (n0 + row) * (int64_t)Mp + (((lane & 7) ^ ((row >> 1) & 7)) << 1);
-        } else {
-            const int row = (blk - 16) * 8 + drow;
-            g_off[j] = (int64_t)row * Mp + (((lane & 7) ^ ((row >> 1) & 7)) << 1);
-        }
-    }
-
-    double ve_acc = 0.0;
-    int nonpos = 0;
-
-    for (int p = 0; p < a.P; ++p) {
-        const double* Tp = a.Tm + (size_t)p * Mp * Mp;
-        double rs_mine = 0.0;
-        double mpart = 0.0;
-        if constexpr (MODE == MODE_MOMENTS) {
-            // mean GEMV pre-pass (see panel_kernel); threads 0..255
-            __syncthreads();
-            for (int j = t; j < Mp; j += FAT_THREADS) lds[j] = a.gamma[(size_t)j * a.P + p];
-            __syncthreads();
-            if (t < 256) {
-                const double* gk = lds + skh * 8;
-                const double* Arow = a.A + (n0 + srow) * (int64_t)Mp + skh * 8;
-#pragma unroll 4
-                for (int c = 0; c < nchunk; ++c) {
-                    double ra[8];
-                    load8(ra, Arow + c * KC);
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) mpart += ra[q] * gk[c * KC + q];
-                }
-            }
-        }
-
-        for (int q = 0; q < npair; ++q) {
-            const double* Tpair = Tp + (size_t)(2 * q * TILE) * Mp;
-            int c_lo = 0, c_hi = nchunk;
-            if (TRI == TSVGP_TRI_LOWER) c_hi = (2 * q + 2) * CPT;
-            if (TRI == TSVGP_TRI_UPPER) c_lo = 2 * q * CPT;
-
-            v4d acc[2][8];
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int n = 0; n < 8; ++n) acc[s][n] = v4d{0, 0, 0, 0};
-
-            auto issue_part = [&](int c, int j0, int j1) {
-                double* dst = lds + (c % FAT_RING) * FAT_BUF_D;
-                const double* ag = a.A + c * KC;
-                const double* tg = Tpair + c * KC;
-#pragma unroll
-                for (int j = 0; j < FAT_DMA_PER_WAVE; ++j) {
-                    if (j < j0 || j >= j1) continue;
-                    const int blk = w + 8 * j;  // wave-uniform
-                    const double* src = (blk < 16 ? ag : tg) + g_off[j];
-                    __builtin_amdgcn_global_load_lds(src, (lds_void_t*)(dst + blk * 128), 16, 0, 0);
-                }
-            };
-            auto issue = [&](int c) { issue_part(c, 0, FAT_DMA_PER_WAVE); };
-            // one ring step: chunk c has landed for everyone -> refill the buffer freed by chunk c-1 -> MFMAs on chunk c
-#ifdef TSVGP_EXP_NOLOAD
-#define FAT_EXP_REFILL(x) false
-#else
-#define FAT_EXP_REFILL(x) (x)
-#endif
-#define FAT_STEP(M0_, M1_, c_)                                                                         \
-    {                                                                                                  \
-        const int cc_ = (c_);                                                                          \
-        if (cc_ + 1 < c_hi)                                                                            \
-            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                           \
-        else                                                                                           \
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                           \
-        __builtin_amdgcn_s_barrier();                                                                  \
-        asm volatile("" ::: "memory");                                                                 \
-        const bool refill_ = FAT_EXP_REFILL(cc_ + 2 < c_hi);                                           \
-        const double* cb_ = lds + (cc_ % FAT_RING) * FAT_BUF_D;                                        \
-        mma_chunk_fat<(H == 0 ? (M0_) : (M1_))>(acc, cb_, cb_ + FAT_A_D + H * FAT_A_D, r, off,         \
-                                                [&](int ks) {                                          \
-                                                    if (refill_ && ks < 3) issue_part(cc_ + 2, 2 * ks, 2 * ks + 2); \
-                                                });                                                    \
-    }
-            __syncthreads();  // the previous pair's (or the GEMV pass's) LDS reads are done before the ring restarts
-            issue(c_lo);
-            if (c_lo + 1 < c_hi) issue(c_lo + 1);
-
-            if constexpr (TRI == TSVGP_TRI_DENSE) {
-                for (int c = c_lo; c < c_hi; ++c) FAT_STEP(0xFF, 0xFF, c)
-            } else if constexpr (TRI == TSVGP_TRI_LOWER) {
-                // k-tiles 0..2q-1 full for both halves; k-tile 2q: half 0 on its diagonal, half 1 full;
-                // k-tile 2q+1: half 0 nothing, half 1 on its diagonal
-                const int cd = 2 * q * CPT;
-                for (int c = 0; c < cd; ++c) FAT_STEP(0xFF, 0xFF, c)
-                FAT_STEP(0xFF, 0xFF, cd + 0)
-                FAT_STEP(0xFE, 0xFF, cd + 1)
-                FAT_STEP(0xFC, 0xFF, cd + 2)
-                FAT_STEP(0xF8, 0xFF, cd + 3)
-                FAT_STEP(0xF0, 0xFF, cd + 4)
-                FAT_STEP(0xE0, 0xFF, cd + 5)
-                FAT_STEP(0xC0, 0xFF, cd + 6)
-                FAT_STEP(0x80, 0xFF, cd + 7)
-                FAT_STEP(0x00, 0xFF, cd + 8)
-                FAT_STEP(0x00, 0xFE, cd + 9)
-                FAT_STEP(0x00, 0xFC, cd + 10)
-                FAT_STEP(0x00, 0xF8, cd + 11)
-                FAT_STEP(0x00, 0xF0, cd + 12)
-                FAT_STEP(0x00, 0xE0, cd + 13)
-                FAT_STEP(0x00, 0xC0, cd + 14)
-                FAT_STEP(0x00, 0x80, cd + 15)
-            } else {
-                // k-tile 2q: half 0 on its diagonal, half 1 nothing; k-tile 2q+1: half 0 full, half 1 on its diagonal
-                const int cd = 2 * q * CPT;
-                FAT_STEP(0x01, 0x00, cd + 0)
-                FAT_STEP(0x03, 0x00, cd + 1)
-                FAT_STEP(0x07, 0x00, cd + 2)
-                FAT_STEP(0x0F, 0x00, cd + 3)
-                FAT_STEP(0x1F, 0x00, cd + 4)
-                FAT_STEP(0x3F, 0x00, cd + 5)
-                FAT_STEP(0x7F, 0x00, cd + 6)
-                FAT_STEP(0xFF, 0x00, cd + 7)
-                FAT_STEP(0xFF, 0x01, cd + 8)
-                FAT_STEP(0xFF, 0x03, cd + 9)
-                FAT_STEP(0xFF, 0x07, cd + 10)
-                FAT_STEP(0xFF, 0x0F, cd + 11)
-                FAT_STEP(0xFF, 0x1F, cd + 12)
-                FAT_STEP(0xFF, 0x3F, cd + 13)
-                FAT_STEP(0xFF, 0x7F, cd + 14)
-                FAT_STEP(0xFF, 0xFF, cd + 15)
-                for (int c = cd + 2 * CPT; c < c_hi; ++c) FAT_STEP(0xFF, 0xFF, c)
-            }
-#undef FAT_STEP
-
-            if constexpr (MODE == MODE_STORE) {
-                double* Cb = a.C + n0 * (int64_t)Mp + (2 * q + H) * TILE + lr;
-#pragma unroll
-                for (int s = 0; s < 2; ++s)
-#pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) {
-                        double* Cr = Cb + (int64_t)(row_block(r, s) * 16 + Mfma<double>::row(lane, rr)) * Mp;
-#pragma unroll
-                        for (int n = 0; n < 8; ++n) Cr[n * 16] = acc[s][n][rr];
-                    }
-            } else {
-                double keep = 0.0;
-#pragma unroll
-                for (int s = 0; s < 2; ++s)
-#pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) {
-                        double qq = 0.0;
-#pragma unroll
-                        for (int n = 0; n < 8; ++n) qq += acc[s][n][rr] * acc[s][n][rr];
-                        qq += __shfl_xor(qq, 1);
-                        qq += __shfl_xor(qq, 2);
-                        qq += __shfl_xor(qq, 4);
-                        qq += __shfl_xor(qq, 8);
-                        keep = ((lane & 7) == s * 4 + rr) ? qq : keep;
-                    }
-                rs_mine += keep;
-            }
-        }  // pair
-
-        if constexpr (MODE == MODE_MOMENTS) {
-            __syncthreads();  // the last pair's fragment reads are done before rowq (same array) is written
-            if (lr < 8) rowq[H * TILE + row_block(r, lr >> 2) * 16 + Mfma<double>::row(lane, lr & 3)] = rs_mine;
-            mpart += __shfl_xor(mpart, 1);
-            __syncthreads();
-            if (t < 256 && skh == 0) {
-                const int64_t n = n0 + srow;
-                const double qv = rowq[srow] + rowq[TILE + srow];
-                const double mu = mpart;
-                const double v = a.kdiag - qv;
-                double g0 = 0.0, g1 = 0.0, ve = 0.0;
-                if (n < a.N) {
-                    if (!(v > 0.0)) nonpos += 1;
-                    if (a.mean) a.mean[n * a.P + p] = mu;
-                    if (a.var) a.var[n * a.P + p] = v;
-                    if (a.lik != TSVGP_LIK_NONE) {
-                        lik_eval(a.lik, a.lik_param, mu, v, a.Y[n * a.P + p], g0, g1, ve);
-                        ve_acc += ve;
-                    }
-                }
-                if (a.lik != TSVGP_LIK_NONE) {
-                    a.g0[n * a.P + p] = g0;
-                    a.g1[n * a.P + p] = g1;
-                }
-            }
-        }
-    }  // p
-
-    if constexpr (MODE == MODE_MOMENTS) {
-        double sv = ve_acc;
-        int cnt = nonpos;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            sv += __shfl_xor(sv, o);
-            cnt += __shfl_xor(cnt, o);
-        }
-        __syncthreads();
-        if (lane == 0) {
-            red[w] = sv;
-            red[8 + w] = (double)cnt;
-        }
-        __syncthreads();
-        if (t == 0) {
-            double s1 = 0.0, s2 = 0.0;
-            for (int i = 0; i < 8; ++i) {
-                s1 += red[i];
-                s2 += red[8 + i];
-            }
-            if (a.ve_partial) a.ve_partial[blockIdx.x] = s1;
-            if (a.nonpos_partial) a.nonpos_partial[blockIdx.x] = (int)s2;
-        }
-    }
-}
-
-template <int MODE, int TRI>
-__global__ __launch_bounds__(FAT_THREADS, 2) void fat_panel_kernel(PanelArgs<double> a) {
-    // ONE shared array (staging ring + the small epilogue scratch at its end)
-    __shared__ __attribute__((aligned(1024))) double lds[FAT_RING * FAT_BUF_D + 2 * TILE + 16];
-    const int half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);
-    if (half == 0)
-        fat_panel_body<MODE, TRI, 0>(a, lds);
-    else
-        fat_panel_body<MODE, TRI, 1>(a, lds);
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// syrk_kernel: workgroup (p, lower tile (it, jt), split s) accumulates over its N-slice
-//   part2[128 x 128] = sum_n g1[n,p] B[n, it*128 + :] (x) B[n, jt*128 + :],   diagonal tiles also part1 = sum_n g0 B.
-// Diagonal tiles (it == jt) only compute accumulators with column block <= row block: 9 of 16 per wave and k-step
-// (row blocks {w, 7 - w}), so they get longer N-slices: ns_diag = ceil(23/32 ns_off) splits instead of ns_off.
-// Workgroup order: all off-diagonal tiles of split 0, of split 1, ...; then the diagonal tiles the same way; remapped
-// so that workgroups sharing an XCD (blockIdx % 8) get a contiguous range, i.e. mostly one N-slice -> shared L2 lines.
 // ---------------------------------------------------------------------------------------------------------------
 template <typename T>
 struct SyrkArgs {
@@ -1761,17 +1450,6 @@ __global__ void selftest_kernel(const T* a, const T* b, T* c) {
 
 inline int launch_status() { return hipGetLastError() == hipSuccess ? TSVGP_OK : TSVGP_ELAUNCH; }
 
-// A/B switch for measurements only: TSVGP_PANEL_FAT=1 selects the experimental LDS-DMA "fat" fp64 panel kernels
-// (128x256 tile, 8 waves, ring of three chunk buffers).  Round-1 measurement: no faster than the register-staged
-// 128x128 kernels (trmm 17.1 vs 17.4 ms, moments 18.5 vs 18.3 ms at N=1e6, M=1024), see DESIGN.md section 4.
-inline bool use_v2_panels() {
-    static const bool v = [] {
-        const char* e = getenv("TSVGP_PANEL_FAT");
-        return !(e && e[0] == '1');
-    }();
-    return v;
-}
-
 template <typename T>
 int kernel_fill(int kind, const T* X, const T* Z, const T* inv_ls, T variance, T* K, int64_t N, int M, int D,
                 int64_t ldk, void* stream) {
@@ -1815,18 +1493,6 @@ int trmm(const T* A, const T* Tm, T* C, int64_t Np, int Mp, int mode, void* stre
     a.P = 1;
     a.mode = mode;
     const dim3 grid((unsigned)(Np / TILE)), block(NTHREADS);
-    if constexpr (sizeof(T) == 8) {
-        if (!use_v2_panels() && (Mp % (2 * TILE)) == 0) {
-            const dim3 fblock(FAT_THREADS);
-            if (mode == TSVGP_TRI_LOWER)
-                hipLaunchKernelGGL((fat_panel_kernel<MODE_STORE, TSVGP_TRI_LOWER>), grid, fblock, 0, (hipStream_t)stream, a);
-            else if (mode == TSVGP_TRI_UPPER)
-                hipLaunchKernelGGL((fat_panel_kernel<MODE_STORE, TSVGP_TRI_UPPER>), grid, fblock, 0, (hipStream_t)stream, a);
-            else
-                hipLaunchKernelGGL((fat_panel_kernel<MODE_STORE, TSVGP_TRI_DENSE>), grid, fblock, 0, (hipStream_t)stream, a);
-            return launch_status();
-        }
-    }
     if (mode == TSVGP_TRI_LOWER)
         hipLaunchKernelGGL((panel_kernel<T, MODE_STORE, TSVGP_TRI_LOWER>), grid, block, 0, (hipStream_t)stream, a);
     else if (mode == TSVGP_TRI_UPPER)
@@ -1868,18 +1534,6 @@ int moments(const T* A, const T* Tm, const T* gamma, const T* Y, double kdiag, i
     a.mode = mode;
     a.lik = lik;
     const dim3 grid((unsigned)(Np / TILE)), block(NTHREADS);
-    if constexpr (sizeof(T) == 8) {
-        if (!use_v2_panels() && (Mp % (2 * TILE)) == 0) {
-            const dim3 fblock(FAT_THREADS);
-            if (mode == TSVGP_TRI_LOWER)
-                hipLaunchKernelGGL((fat_panel_kernel<MODE_MOMENTS, TSVGP_TRI_LOWER>), grid, fblock, 0, (hipStream_t)stream, a);
-            else if (mode == TSVGP_TRI_UPPER)
-                hipLaunchKernelGGL((fat_panel_kernel<MODE_MOMENTS, TSVGP_TRI_UPPER>), grid, fblock, 0, (hipStream_t)stream, a);
-            else
-                hipLaunchKernelGGL((fat_panel_kernel<MODE_MOMENTS, TSVGP_TRI_DENSE>), grid, fblock, 0, (hipStream_t)stream, a);
-            return launch_status();
-        }
-    }
     if (mode == TSVGP_TRI_LOWER)
         hipLaunchKernelGGL((panel_kernel<T, MODE_MOMENTS, TSVGP_TRI_LOWER>), grid, block, 0, (hipStream_t)stream, a);
     else if (mode == TSVGP_TRI_UPPER && (size_t)Mp * sizeof(T) <= 8192)
