@@ -53,6 +53,21 @@ def test_product_path_fails_loudly_without_gpu():
                  lambda: m.predict_f(np.zeros((5, 2)))):
         with pytest.raises(p.HipExtensionError):
             call()
+    w = p.t_SVGP_white(p.SquaredExponential(), p.Gaussian(0.1), np.zeros((4, 2)) + np.arange(4)[:, None])
+    data = (np.zeros((5, 2)), np.zeros((5, 1)))
+    for call in (lambda: w.natgrad_step(data), lambda: w.elbo(data), lambda: w.predict_f(data[0]), lambda: m.elbo_and_grads(data)):
+        with pytest.raises(p.HipExtensionError):
+            call()
+    assert lib_validation_extra()
+
+
+def lib_validation_extra():
+    lib = pkg()._backend.lib()
+    ok = lib.tsvgp_potrf_inv_f64(None, 128, 128, 1, 0, None, None, None, None, None, None) == 1
+    ok &= lib.tsvgp_kernel_fill_f64(7, None, None, None, 1.0, None, 10, 4, 2, 128, None) == 1
+    ok &= lib.tsvgp_kernel_grad_f64(0, None, None, None, 1.0, None, 128, None, None, 1, None, 1, 10, 4, 2, None, None, None, None) == 1
+    ok &= lib.tsvgp_kernel_grad_rows() == 1024 and lib.tsvgp_kernel_grad_dpad(5) == 8
+    return bool(ok)
 
 
 def test_package_never_imports_the_oracle(repo_root):
