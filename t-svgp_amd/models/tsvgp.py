@@ -98,6 +98,37 @@ class base_SVGP(abc.ABC):
     def training_loss(self, data):
         return -self.elbo(data)
 
+    def training_loss_closure(self, data, *, compile=False):
+        """``gpflow.models.ExternalDataTrainingLossMixin.training_loss_closure`` [ext] (reference
+        experiments/uci_regression.py:114): a zero-argument callable returning the negative ELBO.  ``data`` is a
+        (X, Y) tuple or an iterator of such tuples (one batch per call).  ``compile`` is accepted and ignored: there is
+        no tracing compiler here."""
+        if isinstance(data, (tuple, list)):
+            return lambda: self.training_loss(tuple(data))
+        it = iter(data)
+        return lambda: self.training_loss(next(it))
+
+    @property
+    def trainable_parameters(self):
+        """The parameters the reference's M-step trains (``model.trainable_variables``, experiments/uci_regression.py:160):
+        kernel variance(s) and lengthscales, the likelihood's parameters and the inducing inputs; the sites are not
+        trainable (src/sites.py:56-63)."""
+        from ..kernels import latent_kernels
+
+        out, seen = [], set()
+        kernels = self.kernel.kernels if hasattr(self.kernel, "kernels") else [self.kernel]
+        for k in kernels:
+            for par in (k.variance, k.lengthscales):
+                if par.trainable and id(par) not in seen:
+                    seen.add(id(par))
+                    out.append(par)
+        out += [par for par in vars(self.likelihood).values() if hasattr(par, "trainable") and par.trainable]
+        if self.inducing_variable.Z.trainable:
+            out.append(self.inducing_variable.Z)
+        return tuple(out)
+
+    trainable_variables = trainable_parameters  # GPflow's name for the unconstrained counterparts
+
 
 class t_SVGP(base_SVGP):
     """Class for the t-SVGP model (reference tsvgp.py:117-304)."""

@@ -187,6 +187,15 @@ def test_api_surface_and_mutation():
     mu, var = m.predict_y(X[:5])
     assert mu.shape == (5, 1) and bool((var > 0).all())
     assert m.predict_log_density((X[:5], Y[:5])).shape == (5,)
+    # GPflow mixin surface the reference's driver uses (experiments/uci_regression.py:114,160)
+    loss = m.training_loss_closure((X, Y), compile=True)
+    assert abs(float(loss()) + float(m.elbo((X, Y)))) < 1e-12 * abs(float(m.elbo((X, Y))))
+    batches = iter([(X[:100], Y[:100]), (X[100:], Y[100:])])
+    it_loss = m.training_loss_closure(batches)
+    assert float(it_loss()) != float(it_loss())
+    names = {id(v) for v in m.trainable_variables}
+    assert names == {id(m.kernel.variance), id(m.kernel.lengthscales), id(m.likelihood.variance), id(m.inducing_variable.Z)}
+    assert id(m.lambda_1) not in names  # the sites are not trainable (src/sites.py:56-63)
 
 
 def test_error_behaviour():
