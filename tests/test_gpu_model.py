@@ -396,3 +396,29 @@ def test_graph_replay_error_path_restores_state():
         m.natgrad_step((Xd, Yd), lr=0.5)
     assert np.array_equal(m.lambda_1.numpy(), l1)
     assert np.isnan(m.lambda_2_sqrt.numpy()[0, 3, 3])
+
+
+@pytest.mark.parametrize("lik", ["gaussian", "bernoulli"])
+@pytest.mark.parametrize("projection", ["auto", "whitened"])
+def test_fp32_direct_route_against_fp64_oracle(lik, projection):
+    """The configuration of BASELINE configs[2] in small: fp32 N-sized arrays with a well-conditioned K_uu (D = 16,
+    cond ~ 3), where "auto" takes the direct route (gate cond <= 30 in fp32).  Both routes meet the fp32 tolerances."""
+    p = pkg()
+    rng = np.random.RandomState(51)
+    N, M, D = 4000, 128, 16
+    X, Y, _ = synthetic(N=N, M=M, D=D, P=1, lik=lik, seed=11)
+    Z = X[:M].copy()
+    mk = lambda mod, **kw: mod.t_SVGP(mod.SquaredExponential(1.0, 1.0), mod.Gaussian(0.1) if lik == "gaussian" else mod.Bernoulli(),
+                                      Z, num_data=N, **kw)
+    hip, ora = mk(p, compute_dtype=torch.float32, projection=projection), mk(O)
+    assert hip._use_direct(1e-9) == [projection == "auto"]
+    for _ in range(4):
+        hip.natgrad_step((X, Y), lr=0.8)
+        ora.natgrad_step((X, Y), lr=0.8)
+    e_h, e_o = float(hip.elbo((X, Y))), float(ora.elbo((X, Y)))
+    assert abs(e_h - e_o) / abs(e_o) < 1e-4
+    mu_h, var_h = hip.predict_f(X[:300] + 0.05)
+    mu_o, var_o = ora.predict_f(X[:300] + 0.05)
+    np.testing.assert_allclose(mu_h.cpu().numpy(), mu_o, rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(var_h.cpu().numpy(), var_o, rtol=1e-3, atol=1e-4)
+    assert relerr(hip.lambda_1.numpy(), ora.lambda_1) < 1e-3
