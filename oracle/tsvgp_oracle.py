@@ -42,6 +42,19 @@ an independent autodiff natural-gradient SVGP for the Bernoulli case
 comparison model is our own restatement of GPflow's SVGP + NaturalGradient and
 not GPflow itself, parity of the non-conjugate site update against the real
 reference is **unpinned beyond those checks**.
+
+Also restated here, with the same status: ``t_SVGP_white``
+(``src/models/tsvgp_white.py``; pinned by ``tests/models/test_tsvgp_white.py:64-115``
+and the SGPR equality of ``tests/models/test_condit.py:69-83``, closed forms),
+the multi-output layout ``SeparateIndependent`` +
+``SharedIndependentInducingVariables`` (GPflow's
+``separate_independent_conditional`` and batched ``gauss_kl`` [ext]; pinned by
+equality with independent single-output models) and the Matern-3/2 / 5/2
+kernels [ext].  The oracle holds NO gradient code: the M-step gradients of the
+product are checked against central finite differences of this module's ELBO
+(the reference's own gradient pin, ``tests/models/test_tsvgp.py:168-188``, needs
+GPflow's SVGP and cannot be run: **gradient parity is unpinned beyond those
+differences**).
 """
 
 from __future__ import annotations
