@@ -951,8 +951,12 @@ __global__ __launch_bounds__(NTHREADS) void syrk_reduce_kernel(const T* __restri
 //   chol_tile_kernel<UPDATE>  A[i,j] <- A[i,j] - A[i,k] * A[j,k]^T      (one wave per trailing lower 32x32 tile)  Latency bound by design (M^3/3 flops is
 // microseconds of MFMA time): the critical path is 8 diagonal blocks, each ~M/8 dependent column steps.
 // ---------------------------------------------------------------------------------------------------------------
+#ifndef TSVGP_CHOL_SB
+#define TSVGP_CHOL_SB 16
+#endif
 constexpr int CH_NB = 128;
-constexpr int CH_SB = 32;          // sub-block factored in one wave's registers
+constexpr int CH_SB = TSVGP_CHOL_SB;  // sub-block of the diagonal block factored in one wave's registers
+constexpr int CH_WT = 32;          // wave tile of the panel / update / inverse-assembly products
 constexpr int CH_LD = CH_NB + 1;   // odd LDS row stride: one-lane-per-row column sweeps touch 32 different banks
 constexpr int CH_THREADS = 512;    // 8 waves
 
@@ -977,9 +981,9 @@ __device__ __forceinline__ double readlane_d(double v, int src) {
 // (reciprocal square roots by v_rsq_f64 + two Newton steps: no f64 divide / sqrt sequences on the critical path),
 // each lane solves its own row against it, and the rank-4 update of the remaining columns takes its second factor
 // from a small LDS scratch (wave-uniform reads).  No workgroup barriers inside.
-__device__ __forceinline__ void chol_factor32(double* __restrict__ S, double* __restrict__ dinv, double* __restrict__ xs,
+__device__ __forceinline__ void chol_factor_sb(double* __restrict__ S, double* __restrict__ dinv, double* __restrict__ xs,
                                               int s0, int lane, int* fail, int col_base) {
-    const int r = lane & 31;
+    const int r = lane & (CH_SB - 1);
     double* const row = S + (s0 + r) * CH_LD + s0;
     double a[CH_SB];
 #pragma unroll
@@ -1051,7 +1055,7 @@ __device__ __forceinline__ void chol_factor32(double* __restrict__ S, double* __
 
 // Row `gr` (below the sub-block) against the finished L_ss: x = a L_ss^-T by forward substitution, one lane per row;
 // the entries of L_ss are wave-uniform LDS reads (broadcast).
-__device__ __forceinline__ void chol_subst32(double* __restrict__ S, const double* __restrict__ dinv, int s0, int gr) {
+__device__ __forceinline__ void chol_subst_sb(double* __restrict__ S, const double* __restrict__ dinv, int s0, int gr) {
     asm volatile("" : "+v"(gr));  // nothing derived from the lane id is hoisted out of the caller's sub-block loop
     double* const row = S + gr * CH_LD + s0;
     const double* const Ls = S + s0 * CH_LD + s0;
@@ -1066,7 +1070,7 @@ __device__ __forceinline__ void chol_subst32(double* __restrict__ S, const doubl
 #pragma unroll
         for (int kk = 0; kk < c; ++kk) v[kk & 3] = fma(-a[kk], Ls[c * CH_LD + kk], v[kk & 3]);
         double x = ((v[0] + v[1]) + (v[2] + v[3])) * dinv[s0 + c];
-        asm volatile("" : "+v"(x));  // pins the row here (see chol_factor32): bounds the L_ss entries in flight
+        asm volatile("" : "+v"(x));  // pins the row here (see chol_factor_sb): bounds the L_ss entries in flight
         a[c] = x;
     }
 #pragma unroll
@@ -1075,9 +1079,9 @@ __device__ __forceinline__ void chol_subst32(double* __restrict__ S, const doubl
 
 // inv(L_ss) by columns: lane j (mod 32) solves L_ss x = e_j with wave-uniform reads of L_ss; X[r][j] is parked
 // transposed in the unused strict upper triangle of the sub-block (S[s0 + j][s0 + r], r > j); the diagonal is dinv.
-__device__ __forceinline__ void chol_inv32(double* __restrict__ S, const double* __restrict__ dinv, int s0, int lane) {
-    asm volatile("" : "+v"(lane));  // as in chol_subst32
-    const int j = lane & 31;
+__device__ __forceinline__ void chol_inv_sb(double* __restrict__ S, const double* __restrict__ dinv, int s0, int lane) {
+    asm volatile("" : "+v"(lane));  // as in chol_subst_sb
+    const int j = lane & (CH_SB - 1);
     const double* const Ls = S + s0 * CH_LD + s0;
     double x[CH_SB];
 #pragma unroll
@@ -1141,8 +1145,8 @@ __device__ __forceinline__ void chol_inv_offdiag(double* __restrict__ S, const d
 }
 
 // Diagonal block: right-looking over four 32-wide sub-blocks, everything in LDS / registers:
-//   (1) wave 0 factors the 32x32 diagonal sub-block in registers (chol_factor32);
-//   (2) the rows below solve against it, one lane per row (chol_subst32); wave 7 meanwhile inverts L_ss (chol_inv32);
+//   (1) wave 0 factors the 32x32 diagonal sub-block in registers (chol_factor_sb);
+//   (2) the rows below solve against it, one lane per row (chol_subst_sb); wave 7 meanwhile inverts L_ss (chol_inv_sb);
 //   (3) the trailing part of the block is updated with 16x16 MFMA tiles, A_ij -= L_is L_js^T, by all waves.
 // Then L_kk is written out and inv(L_kk) is assembled from the four sub-block inverses by two levels of the 2x2
 // recursion (chol_inv_offdiag) and written to `work` for the panel kernel.
@@ -1159,7 +1163,7 @@ __global__ __launch_bounds__(CH_THREADS) void potrf_diag_kernel(double* __restri
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     double* Ab = A + (size_t)b * stride + (size_t)k * CH_NB * lda + (size_t)k * CH_NB;
 #ifdef TSVGP_DIAG_POTRF
-    unsigned long long stamp[16];
+    unsigned long long stamp[40];
     int nstamp = 0;
 #define PSTAMP() stamp[nstamp++] = __builtin_amdgcn_s_memtime();
 #else
@@ -1187,14 +1191,14 @@ __global__ __launch_bounds__(CH_THREADS) void potrf_diag_kernel(double* __restri
     PSTAMP()
 
     for (int s0 = 0; s0 < CH_NB; s0 += CH_SB) {
-        if (w == 0) chol_factor32(S, dinv, xs, s0, lane, &fail, k * CH_NB);
+        if (w == 0) chol_factor_sb(S, dinv, xs, s0, lane, &fail, k * CH_NB);
         __syncthreads();
         PSTAMP()
         const int nbelow = CH_NB - s0 - CH_SB;
         if (t < nbelow)
-            chol_subst32(S, dinv, s0, s0 + CH_SB + t);
+            chol_subst_sb(S, dinv, s0, s0 + CH_SB + t);
         else if (w == 7 && need_inverse)
-            chol_inv32(S, dinv, s0, lane);
+            chol_inv_sb(S, dinv, s0, lane);
         __syncthreads();
         PSTAMP()
         // trailing update on the lower 16x16 tiles of rows/columns [s0 + 32, 128)
@@ -1235,6 +1239,11 @@ __global__ __launch_bounds__(CH_THREADS) void potrf_diag_kernel(double* __restri
     PSTAMP()
     if (need_inverse) {  // the last block column has no panel below it
         // level 1: the two 64x64 diagonal blocks, X_10 = -X_11 (L_10 X_00) with 32x32 blocks; level 2: the 64x64 block
+        // levels n = CH_SB .. 64 of the 2x2 recursion; a level has 64 / n block pairs of n / 16 column tiles: four waves
+        if constexpr (CH_SB == 16) {
+            if (w < 4) chol_inv_offdiag<1>(S, dinv, 32 * w + 16, 32 * w, 0, lane);
+            __syncthreads();
+        }
         if (w < 4) chol_inv_offdiag<2>(S, dinv, 64 * (w >> 1) + 32, 64 * (w >> 1), w & 1, lane);
         __syncthreads();
         if (w < 4) chol_inv_offdiag<4>(S, dinv, 64, 0, w, lane);
@@ -1281,7 +1290,7 @@ __global__ __launch_bounds__(NTHREADS) void chol_tile_kernel(double* __restrict_
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b = blockIdx.y;
     double* Ab = Amat + (size_t)b * stride;
-    const int nb32 = (nt - k - 1) * (CH_NB / CH_SB);
+    const int nb32 = (nt - k - 1) * (CH_NB / CH_WT);
     const int base = (k + 1) * CH_NB;  // first row / column of the trailing matrix
     int ti, tj;
     bool active = true;
@@ -1303,9 +1312,9 @@ __global__ __launch_bounds__(NTHREADS) void chol_tile_kernel(double* __restrict_
 #pragma unroll
         for (int n = 0; n < 2; ++n) acc[s][n] = v4d{0, 0, 0, 0};
     if (active) {
-        const double* Arow = Ab + (size_t)(base + CH_SB * ti + li) * lda + (size_t)k * CH_NB + 16 * g;
-        const double* Brow = (OP == 0) ? work + (size_t)b * CH_NB * CH_NB + (size_t)(CH_SB * tj + li) * CH_NB + 16 * g
-                                       : Ab + (size_t)(base + CH_SB * tj + li) * lda + (size_t)k * CH_NB + 16 * g;
+        const double* Arow = Ab + (size_t)(base + CH_WT * ti + li) * lda + (size_t)k * CH_NB + 16 * g;
+        const double* Brow = (OP == 0) ? work + (size_t)b * CH_NB * CH_NB + (size_t)(CH_WT * tj + li) * CH_NB + 16 * g
+                                       : Ab + (size_t)(base + CH_WT * tj + li) * lda + (size_t)k * CH_NB + 16 * g;
         const size_t bstep = (OP == 0) ? (size_t)16 * CH_NB : (size_t)16 * lda;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -1328,7 +1337,7 @@ __global__ __launch_bounds__(NTHREADS) void chol_tile_kernel(double* __restrict_
     }
     if (OP == 0) __syncthreads();  // in place: every wave of the row block has its operands in registers
     if (!active) return;
-    double* Cb = Ab + (size_t)(base + CH_SB * ti) * lda + (OP == 0 ? (size_t)k * CH_NB : (size_t)base) + CH_SB * tj + li;
+    double* Cb = Ab + (size_t)(base + CH_WT * ti) * lda + (OP == 0 ? (size_t)k * CH_NB : (size_t)base) + CH_WT * tj + li;
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -1365,7 +1374,7 @@ __global__ __launch_bounds__(NTHREADS) void trtri_level_kernel(const double* __r
     const int r0 = 2 * pair * n, r1 = r0 + n;
     const int n1 = min(n, M - r1);
     if (n1 <= 0) return;
-    const int nrow32 = (STAGE == 0 ? n : n1) / CH_SB, ncol32 = (STAGE == 0 ? n1 : n) / CH_SB;
+    const int nrow32 = (STAGE == 0 ? n : n1) / CH_WT, ncol32 = (STAGE == 0 ? n1 : n) / CH_WT;
     const int wid = blockIdx.x;
     if (wid >= nrow32 * ncol32) return;
     const int tr = wid / ncol32, tc = wid - tr * ncol32;  // output tile: rows tr, columns tc (units of 32)
@@ -1378,19 +1387,19 @@ __global__ __launch_bounds__(NTHREADS) void trtri_level_kernel(const double* __r
     size_t astep, bstep;
     int kbeg, kend;
     if (STAGE == 0) {
-        Arow = Xtb + (size_t)(r0 + CH_SB * tr + li) * ldx + r0;  // Xt00[j, k]: zero for k < j
-        Brow = Lb + (size_t)(r1 + CH_SB * tc + li) * lda + r0;    // L10[i, k]
+        Arow = Xtb + (size_t)(r0 + CH_WT * tr + li) * ldx + r0;  // Xt00[j, k]: zero for k < j
+        Brow = Lb + (size_t)(r1 + CH_WT * tc + li) * lda + r0;    // L10[i, k]
         astep = (size_t)16 * ldx;
         bstep = (size_t)16 * lda;
-        kbeg = (CH_SB * tr) & ~63;
+        kbeg = (CH_WT * tr) & ~63;
         kend = n;
     } else {
-        Arow = Xb + (size_t)(r1 + CH_SB * tr + li) * ldx + r1;  // X11[i, k]: zero for k > i
-        Brow = Tb + (size_t)(r0 + CH_SB * tc + li) * ldx + r1;  // T^T[j, k]
+        Arow = Xb + (size_t)(r1 + CH_WT * tr + li) * ldx + r1;  // X11[i, k]: zero for k > i
+        Brow = Tb + (size_t)(r0 + CH_WT * tc + li) * ldx + r1;  // T^T[j, k]
         astep = (size_t)16 * ldx;
         bstep = (size_t)16 * ldx;
         kbeg = 0;
-        kend = min(n1, (CH_SB * (tr + 1) + 63) & ~63);
+        kend = min(n1, (CH_WT * (tr + 1) + 63) & ~63);
     }
     v4d acc[2][2];
 #pragma unroll
@@ -1426,7 +1435,7 @@ __global__ __launch_bounds__(NTHREADS) void trtri_level_kernel(const double* __r
     for (int u = 1; u < NTHREADS / 64; ++u) sum += part[u][w][lane];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int orow = CH_SB * tr + 16 * s + g + 4 * r, ocol = CH_SB * tc + 16 * q + li;
+        const int orow = CH_WT * tr + 16 * s + g + 4 * r, ocol = CH_WT * tc + 16 * q + li;
         if (STAGE == 0) {
             Tb[(size_t)(r0 + orow) * ldx + r1 + ocol] = sum[r];
         } else {
@@ -1634,7 +1643,7 @@ int potrf(double* A, int M, int lda, int batch, int64_t stride, int* info, doubl
                            (inv || k + 1 < nt) ? 1 : 0, X, Xt, M, xstride);
         const int below = nt - k - 1;
         if (below > 0) {
-            const int nb32 = below * (CH_NB / CH_SB), ntile = nb32 * (nb32 + 1) / 2;
+            const int nb32 = below * (CH_NB / CH_WT), ntile = nb32 * (nb32 + 1) / 2;
             hipLaunchKernelGGL(chol_tile_kernel<0>, dim3(nb32, batch), dim3(NTHREADS), 0, st, A, lda, stride, k, nt,
                                work);
             hipLaunchKernelGGL(chol_tile_kernel<1>, dim3((ntile + wpb - 1) / wpb, batch), dim3(NTHREADS), 0, st, A,
@@ -1644,7 +1653,7 @@ int potrf(double* A, int M, int lda, int batch, int64_t stride, int* info, doubl
     if (inv) {
         for (int n = CH_NB; n < M; n *= 2) {
             const int npair = (M + 2 * n - 1) / (2 * n);
-            const int ntile = (n / CH_SB) * (n / CH_SB);
+            const int ntile = (n / CH_WT) * (n / CH_WT);
             const dim3 grid(ntile, npair, batch);
             hipLaunchKernelGGL(trtri_level_kernel<0>, grid, dim3(NTHREADS), 0, st, A, lda, stride, X, Xt, T, M, xstride,
                                M, n);

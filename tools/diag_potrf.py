@@ -16,11 +16,12 @@ for _ in range(3):
     W = A.clone()
     assert lib.tsvgp_potrf_f64(vp(W.data_ptr()), M, M, 1, ctypes.c_int64(M * M), vp(info.data_ptr()), vp(work.data_ptr()), None) == 0
 torch.cuda.synchronize()
-st = work[:20].view(torch.int64).cpu().numpy()
+st = work[:40].view(torch.int64).cpu().numpy()
 n = int(st[0]); st = st[1:1 + n]
 names = ["load"]
-for s_ in range(4):
-    names += [f"s{s_}: factor 32x32", f"s{s_}: row solves + inv32", f"s{s_}: trailing MFMA update"]
+nsb = (n - 5) // 3  # sub-blocks per 128-block (TSVGP_CHOL_SB = 16 -> 8)
+for s_ in range(nsb):
+    names += [f"s{s_}: factor sub-block", f"s{s_}: row solves + sub-block inverse", f"s{s_}: trailing MFMA update"]
 names += ["store L", "assemble inverse (2 levels)", "store inverse"]
 for i in range(n - 1):
     print(f"{names[i] if i < len(names) else '?':32s} {int(st[i + 1] - st[i]):8d} ticks  {(st[i + 1] - st[i]) / 2.3e3:7.2f} us")
