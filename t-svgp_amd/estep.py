@@ -240,7 +240,7 @@ class EStepEngine:
                     "tsvgp_selftest_mfma")
         return a, b, c
 
-    def _run_separate(self, X, Y, Z, kernel, *, moment_Tm, gamma, whiten_T, want_grads, **kw) -> EStepStats:
+    def _run_separate(self, X, Y, Z, kernel, *, moment_Tm, gamma, whiten_T, project_T, want_grads, **kw) -> EStepStats:
         """Separate per-latent kernels (K_uu [P, M, M]): one fill + moments + accumulation pass per latent, through the
         same single-latent kernels and ONE K(X, Z) buffer (P of them would be 8.2 GB each at N = 1e6, M = 1024)."""
         P = moment_Tm.shape[0]
@@ -254,8 +254,10 @@ class EStepEngine:
                 wt = whiten_T[p]
             else:
                 wt = None if whiten_T is None else (whiten_T[p] if whiten_T.dim() == 3 else whiten_T)
+            pt = project_T[p] if isinstance(project_T, (list, tuple)) else (
+                None if project_T is None else (project_T[p] if project_T.dim() == 3 else project_T))
             st = self.run(X, None if Y is None else Y[:, p:p + 1], Z, kp, moment_Tm=moment_Tm[p:p + 1],
-                          gamma=gamma[:, p:p + 1], whiten_T=wt, want_grads=want_grads, **kw)
+                          gamma=gamma[:, p:p + 1], whiten_T=wt, project_T=pt, want_grads=want_grads, **kw)
             if want_grads and st.g0 is not None:
                 st.g0, st.g1 = st.g0.clone(), st.g1.clone()  # views of a buffer the next latent overwrites
             parts.append(st)
@@ -271,13 +273,16 @@ class EStepEngine:
 
     # ------------------------------------------------------------------ one N-pass
     def run(self, X, Y, Z, kernel, *, moment_Tm, moment_mode, gamma, lik_id=B.LIK_NONE, lik_param=0.0,
-            whiten_T=None, whiten_mode=B.TRI_UPPER, sites=False, want_moments=False, want_grads=False,
+            whiten_T=None, whiten_mode=B.TRI_UPPER, project_T=None, sites=False, want_moments=False, want_grads=False,
             b_tag=None) -> EStepStats:
         """One pass over the shard's rows.
 
         X [N, D], Y [N, P] (or None when lik_id == NONE), Z [M, D];
         whiten_T [M, M] fp64: the inverted triangular factor of Kuu + jitter I (B[n, i] = sum_j Kfu[n, j] whiten_T[i, j]
         over the triangle ``whiten_mode`` names), or None (moments then act on Kfu directly);
+        project_T [M, M] fp64 (needs whiten_T): the "projected" route -- after the moments the site sums are taken over
+        a = project_T-product of B (a[n, i] = sum_{j <= i} B[n, j] project_T[i, j], i.e. a = U9^-T b = K9^-1 k with
+        project_T = U9^-T), written over the K(X, Z) buffer;
         moment_Tm [P, M, M] fp64 and gamma [M, P] fp64: operands of the fused moments kernel;
         sites=True also accumulates (acc2, acc1) = (sum g1 a a^T, sum g0 a) over the rows a of the same operand the
         moments used: the whitened B when whiten_T is given, Kfu itself otherwise (the "direct" projection).
@@ -288,7 +293,7 @@ class EStepEngine:
         if isinstance(kernel, SeparateIndependent):
             return self._run_separate(X, Y, Z, kernel, moment_Tm=moment_Tm, moment_mode=moment_mode, gamma=gamma,
                                       lik_id=lik_id, lik_param=lik_param, whiten_T=whiten_T, whiten_mode=whiten_mode,
-                                      sites=sites, want_moments=want_moments, want_grads=want_grads)
+                                      project_T=project_T, sites=sites, want_moments=want_moments, want_grads=want_grads)
         T, dev = self.dtype, self.device
         X = X.to(device=dev, dtype=T).contiguous()
         Z = Z.to(device=dev, dtype=T).contiguous()
@@ -348,6 +353,12 @@ class EStepEngine:
         if want_grads and need_g:
             stats.g0, stats.g1 = g0[:N].to(torch.float64), g1[:N].to(torch.float64)
 
+        if sites and project_T is not None:
+            if whiten_T is None:
+                raise ValueError("project_T needs whiten_T")
+            Aproj = self._get("Kfu", (Np, Mp), T)  # K(X, Z) itself is no longer needed once B exists
+            self.trmm(A, self._pad_square(project_T, Mp, "pad_proj"), Aproj, B.TRI_LOWER)
+            A = Aproj
         if sites:
             nsplit = self.nsplit_override or self.choose_nsplit(Mp, P)
             nsplit = max(1, min(nsplit, Np // 16))

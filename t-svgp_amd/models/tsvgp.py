@@ -152,9 +152,12 @@ class t_SVGP(base_SVGP):
         #               (error ~ sqrt(cond K_uu) eps: safe for any K_uu the reference can factorise);
         #   "direct":   sums over k k^T on K_fu itself, then K_uu^-1 (.) K_uu^-1 by M x M Cholesky solves
         #               (error ~ cond(K_uu) eps; one N M^2 product fewer);
-        #   "auto":     direct when cond(K_uu + jitter I) is small enough for the dtype, else whitened.
-        if projection not in ("auto", "whitened", "direct"):
-            raise ValueError("projection must be 'auto', 'whitened' or 'direct'")
+        #   "projected": a = K_uu^-1 k by a second N-sized triangular product, sums over a a^T as the reference does
+        #               (G1 is a sum of outer products: stays definite at any cond(K_uu); one N M^2 product more);
+        #   "auto":     by cond(K_uu + jitter I): direct, whitened or projected (see _routes); a failed final
+        #               factorisation moves a latent one route down.
+        if projection not in ("auto", "whitened", "direct", "projected"):
+            raise ValueError("projection must be 'auto', 'whitened', 'direct' or 'projected'")
         self.projection = projection
         self._cond_cache = None
         # Opt-in: replay natgrad_step from a captured hipGraph (see _graph_step); pays off when the step is launch bound
@@ -206,27 +209,39 @@ class t_SVGP(base_SVGP):
         return tuple((id(k), k.variance.version, k.lengthscales.version)
                      for k in latent_kernels(self.kernel, self.num_latent_gps))
 
-    # The direct route's error grows like cond(K_uu)^2 eps (K^-1 (sum g k k^T) K^-1 cancels two factors of K):
-    # cond <= 1e3 keeps it <= ~1e-9 relative in fp64, cond <= 30 <= ~1e-4 in fp32 (the stated tolerances).
+    # Route gates on cond(K_uu + jitter I), per latent GP.  direct: its error grows like cond^2 eps (K^-1 (sum g k k^T) K^-1
+    # cancels two factors of K): cond <= 1e3 keeps it <= ~1e-9 relative in fp64, cond <= 30 <= ~1e-4 in fp32.  whitened: the
+    # sums over b b^T carry an ABSOLUTE error ~eps |acc2| that U9^-T (.) U9^-1 amplifies by |K9^-1| (measured 4e-10 at
+    # cond 1e7, 2e-8 at 1e9, and the final factorisation loses definiteness beyond): cond <= 1e7.  projected: any cond.
     DIRECT_MAX_COND = {torch.float64: 1.0e3, torch.float32: 30.0}
+    WHITENED_MAX_COND = {torch.float64: 1.0e7, torch.float32: float("inf")}
+    _DEMOTE = {"direct": "whitened", "whitened": "projected"}
 
-    def _use_direct(self, jitter) -> list:
-        """Chooses the projection route, per latent GP (one decision for all latents under a shared kernel).  In "auto"
-        mode the 2-norm condition number of K_uu + jitter I is computed (symmetric eigenvalues, M x M, one host read)
-        only when the kernel parameters, Z or the jitter changed."""
+    def _routes(self, jitter) -> list:
+        """The projection route of every latent GP (one decision for all latents under a shared kernel): "direct",
+        "whitened" or "projected".  In "auto" mode the 2-norm condition number of K_uu + jitter I is computed (symmetric
+        eigenvalues, M x M, one host read) only when the kernel parameters, Z or the jitter changed."""
         P = self.num_latent_gps
         if self.projection != "auto":
-            return [self.projection == "direct"] * P
+            return [self.projection] * P
         key = (self._kernel_versions(), id(self.inducing_variable.Z), self.inducing_variable.Z.version, float(jitter))
         if self._cond_cache is None or self._cond_cache[0] != key:
             Kzz = self._get_engine().kuu(self._Z(), self.kernel)  # [M, M] or [P, M, M]
             ev = torch.linalg.eigvalsh(Kzz + jitter * torch.eye(Kzz.shape[-1], dtype=Kzz.dtype, device=Kzz.device))
             lo, hi = ev[..., 0], ev[..., -1]
             cond = torch.where(lo > 0, hi / lo, torch.full_like(lo, float("inf"))).reshape(-1).tolist()
-            self._cond_cache = (key, cond if len(cond) == P else cond * P)
-        return [c <= self.DIRECT_MAX_COND[self.compute_dtype] for c in self._cond_cache[1]]
+            self._cond_cache = (key, cond if len(cond) == P else cond * P, {})
+        dmax, wmax = self.DIRECT_MAX_COND[self.compute_dtype], self.WHITENED_MAX_COND[self.compute_dtype]
+        routes = ["direct" if c <= dmax else "whitened" if c <= wmax else "projected" for c in self._cond_cache[1]]
+        for p, r in self._cond_cache[2].items():  # latents demoted after a failed step keep their route
+            order = ("direct", "whitened", "projected")
+            routes[p] = order[max(order.index(routes[p]), order.index(r))]
+        return routes
 
-    def _site_operands(self, whiten_jitter=None, warm_key=None, direct=False):
+    def _use_direct(self, jitter) -> list:
+        return [r == "direct" for r in self._routes(jitter)]
+
+    def _site_operands(self, whiten_jitter=None, warm_key=None, routes=None):
         """Everything the N-pass needs that depends only on (theta, Z, lambda): O(M^3), fp64, replicated.
         No host synchronisation happens here: Cholesky statuses are collected in ops["infos"] and checked once per
         call by ``_check_step`` (TF raises immediately; here the raise comes at the end of the same call).
@@ -269,29 +284,34 @@ class t_SVGP(base_SVGP):
         DKl = torch.einsum("pmk,kp->pm", Dm, _kmv(K6, l1))
         beta = l1 - torch.einsum("pkm,pk->mp", Dm, DKl)  # K6^-1 m = l1 - D^T D K6 l1
         ops = dict(Z=Z, Kzz=Kzz, K6=K6, D=Dm, U_W=U_W, beta=beta, Id=Id, infos=infos, potrf=potrf,
-                   direct=[False] * self.num_latent_gps, moment_mode=B.TRI_UPPER, whiten_mode=B.TRI_UPPER, whiten_T=None)
+                   routes=["whitened"] * self.num_latent_gps, moment_mode=B.TRI_UPPER, whiten_mode=B.TRI_UPPER,
+                   whiten_T=None, project_T=None)
         if whiten_jitter is None:
             return ops
         ops["U9"], ops["Uinv9"] = U9, Uinv9  # K_uu + jitter I = U9 U9^T, tsvgp.py:268-270
         if warm_key is not None and not warm:
             self._warm = (warm_key, dict(Kzz=Kzz, U9=U9, Uinv9=Uinv9))
-        direct = [bool(direct)] * self.num_latent_gps if isinstance(direct, bool) else [bool(d) for d in direct]
-        ops["direct"] = direct
-        if all(direct):
+        routes = list(routes) if routes is not None else ["whitened"] * self.num_latent_gps
+        ops["routes"] = routes
+        if all(r == "direct" for r in routes):
             # direct projection: the moments act on K_fu with D itself, the sums are mapped by K9^-1 (.) K9^-1
             # afterwards; no N-sized whitening
             ops["gamma"], ops["moment_Tm"] = beta, Dm
         else:
             gamma_w = _ktmv(U9, beta)  # mean = k^T beta = b^T U9^T beta with b = U9^-1 k
             T_w = (Dm @ U9).triu()  # var = knn - |D k|^2 = knn - |T b|^2
-            if not any(direct):
+            Uinv9t = Uinv9.transpose(-1, -2).contiguous()  # projected route: a = U9^-T b  (lower triangular product)
+            if len(set(routes)) == 1:
                 ops["whiten_T"], ops["gamma"], ops["moment_Tm"] = Uinv9, gamma_w, T_w  # B = K_fu U9^-T
+                ops["project_T"] = Uinv9t if routes[0] == "projected" else None
             else:
-                # separate kernels, some latents well conditioned and some not: each latent takes its own route
-                sel = torch.tensor(direct, device=Dm.device)
+                # separate kernels, latents of different conditioning: each latent takes its own route
+                per = lambda m, p: m[p] if m.dim() == 3 else m
+                sel = torch.tensor([r == "direct" for r in routes], device=Dm.device)
                 ops["gamma"] = torch.where(sel[None, :], beta, gamma_w)
                 ops["moment_Tm"] = torch.where(sel[:, None, None], Dm, T_w)
-                ops["whiten_T"] = [None if d else Uinv9[p] for p, d in enumerate(direct)]
+                ops["whiten_T"] = [None if r == "direct" else per(Uinv9, p) for p, r in enumerate(routes)]
+                ops["project_T"] = [per(Uinv9t, p) if r == "projected" else None for p, r in enumerate(routes)]
         return ops
 
     def _status_flags(self, ops, nonpos, extra_infos=()) -> torch.Tensor:
@@ -479,45 +499,46 @@ class t_SVGP(base_SVGP):
         Updates the parameters in place and returns None.  The whole step is enqueued without host
         synchronisation; one device->host read of the status flags ends it."""
         X, Y = self._as_device(data[0]), self._as_device(data[1])
-        direct = self._use_direct(jitter)
-        if self.use_graph and self._graph_step(X, Y, lr, jitter, direct):
+        routes = self._routes(jitter)
+        if self.use_graph and self._graph_step(X, Y, lr, jitter, routes):
             return
         old_l1, old_L = self.lambda_1.value, self.lambda_2_sqrt.value
-        none = [False] * self.num_latent_gps
-        for use_direct in ((direct, none) if any(direct) else (none,)):  # all-whitened is the fallback of any direct latent
+        while True:
+            soft = any(r != "projected" for r in routes)
             try:
-                flags = self._step_device(X, Y, lr, jitter, use_direct)
-                verdict = self._judge(flags.cpu(), soft_final=any(use_direct))
+                flags = self._step_device(X, Y, lr, jitter, routes)
+                verdict = self._judge(flags.cpu(), soft_final=soft)
             except FloatingPointError:
                 self.lambda_1.assign(old_l1)  # the reference raises before its assigns: leave the state untouched
                 self.sites.assign_lambda_2_sqrt(old_L)
                 raise
             if verdict is True:
                 return
-            # "whiten": the direct projection lost the definiteness of -2 lambda_2 + jitter I (its error is
-            # ~cond(K_uu)^2 eps of |G1|, the jitter is absolute): redo with the whitened route and stay there until
-            # the parameters change
+            # The final factorisation failed on a cheaper route (its error exceeded the absolute jitter): put the state
+            # back, move every latent one route down (direct -> whitened -> projected) and remember it until the
+            # parameters change.  The projected route forms G1 as a sum of outer products like the reference, so a
+            # failure there is a failure of the reference's own algorithm and raises.
             self.lambda_1.assign(old_l1)
             self.sites.assign_lambda_2_sqrt(old_L)
-            if self._cond_cache is not None:
-                self._cond_cache = (self._cond_cache[0], [float("inf")] * self.num_latent_gps)
-        raise FloatingPointError("Cholesky decomposition was not successful (matrix not positive definite)")
+            routes = [self._DEMOTE.get(r, r) for r in routes]
+            if self.projection == "auto" and self._cond_cache is not None:
+                self._cond_cache[2].update({p: r for p, r in enumerate(routes)})
 
-    def _step_device(self, X, Y, lr, jitter, use_direct, inplace=False) -> torch.Tensor:
+    def _step_device(self, X, Y, lr, jitter, routes, inplace=False) -> torch.Tensor:
         """The whole E-step as device work, no host synchronisation: M x M prelude, N-pass, all-reduce, epilogue, state
         assignment.  Returns the status flags (device).  With ``inplace`` the state tensors are overwritten in place
         (what a captured graph needs) instead of being replaced."""
         warm_key = self._warm_key(X, jitter)
-        ops = self._site_operands(whiten_jitter=jitter, warm_key=warm_key, direct=use_direct)
+        ops = self._site_operands(whiten_jitter=jitter, warm_key=warm_key, routes=routes)
         st = self._get_engine().run(X, Y, ops["Z"], self.kernel, moment_Tm=ops["moment_Tm"],
                                     moment_mode=ops["moment_mode"], gamma=ops["gamma"],
                                     lik_id=self.likelihood.lik_id, lik_param=self.likelihood.lik_param,
-                                    whiten_T=ops["whiten_T"], whiten_mode=ops["whiten_mode"], sites=True,
-                                    b_tag=warm_key)
+                                    whiten_T=ops["whiten_T"], whiten_mode=ops["whiten_mode"], project_T=ops["project_T"],
+                                    sites=True, b_tag=warm_key)
         return self._apply_site_update(st, ops, lr, jitter, inplace=inplace)
 
     # -- hipGraph replay of the step (launch-bound problem sizes) -------------------------------------------------
-    def _graph_step(self, X, Y, lr, jitter, direct) -> bool:
+    def _graph_step(self, X, Y, lr, jitter, routes) -> bool:
         """Runs the step by replaying a captured graph (torch.cuda.CUDAGraph = hipGraph on ROCm).  A step is ~130
         dispatches; at small N and M (BASELINE configs[0]) launching them costs more than running them.  The graph is
         keyed on everything that is baked into it at capture: the data buffers, kernel / likelihood / Z parameter
@@ -532,7 +553,7 @@ class t_SVGP(base_SVGP):
         lik_v = tuple(p.version for p in vars(self.likelihood).values() if hasattr(p, "version"))
         key = (X.data_ptr(), Y.data_ptr(), tuple(X.shape), tuple(Y.shape), X.dtype, Y.dtype, self._kernel_versions(),
                lik_v, id(self.inducing_variable.Z), self.inducing_variable.Z.version, float(lr), float(jitter),
-               tuple(direct), self.num_data)
+               tuple(routes), self.num_data)
         entry = self._graphs.get(key)
         if entry is None:
             self._graphs[key] = "seen"
@@ -551,7 +572,7 @@ class t_SVGP(base_SVGP):
                 with torch.cuda.graph(graph):
                     bl1.copy_(sl1)
                     bL.copy_(sL)
-                    flags = self._step_device(X, Y, lr, jitter, direct, inplace=True)
+                    flags = self._step_device(X, Y, lr, jitter, routes, inplace=True)
                 entry = dict(graph=graph, flags=flags, state=(sl1, sL), backup=(bl1, bL), buf=eng._buf)
                 self._graphs[key] = entry
             except Exception:  # not capturable on this stack: never try this key again
@@ -572,7 +593,7 @@ class t_SVGP(base_SVGP):
             Lp._value = sL
         entry["graph"].replay()
         try:
-            ok = self._judge(entry["flags"].cpu(), soft_final=any(direct)) is True
+            ok = self._judge(entry["flags"].cpu(), soft_final=any(r != "projected" for r in routes)) is True
         except FloatingPointError:
             ok = False
         if not ok:  # put the pre-step state back; the eager path then raises or falls back as it always does
@@ -594,24 +615,25 @@ class t_SVGP(base_SVGP):
 
         Uinv9, Kzz, beta = ops["Uinv9"], ops["Kzz"], ops["beta"]
         Uinv9t = Uinv9.transpose(-1, -2)
-        direct = ops["direct"]
-        G1 = G0 = None
-        if any(direct):
+        routes = ops["routes"]
+        forms = {}
+        if "direct" in routes:
             # direct projection: acc2 = sum g1 k k^T, acc1 = sum g0 k  ->  G1 = K9^-1 acc2 K9^-1, G0 = K9^-1 acc1
             # (K9^-1 = U9^-T U9^-1 applied as GEMMs; torch.cholesky_solve is not an option: it returned wrong values for
             # small batched right-hand sides on this ROCm build -- tools/check_cholesky_solve.py)
             K9inv = Uinv9t @ Uinv9
-            G1 = K9inv @ acc2 @ K9inv
-            G0 = _kmv(K9inv, acc1.transpose(-1, -2))  # [M, P]
-        if not all(direct):
+            forms["direct"] = (K9inv @ acc2 @ K9inv, _kmv(K9inv, acc1.transpose(-1, -2)))
+        if "whitened" in routes:
             # G1 = U9^-T acc2 U9^-1,  G0 = U9^-T acc1   (tsvgp.py:279-280 in whitened coordinates)
-            G1w = Uinv9t @ acc2 @ Uinv9
-            G0w = _kmv(Uinv9t, acc1.transpose(-1, -2))  # [M, P]
-            if G1 is None:
-                G1, G0 = G1w, G0w
-            else:  # mixed routes (separate kernels): every latent keeps the form its sums were taken in
-                sel = torch.tensor(direct, device=G1.device)
-                G1, G0 = torch.where(sel[:, None, None], G1, G1w), torch.where(sel[None, :], G0, G0w)
+            forms["whitened"] = (Uinv9t @ acc2 @ Uinv9, _kmv(Uinv9t, acc1.transpose(-1, -2)))
+        if "projected" in routes:
+            # the sums were taken over a = K9^-1 k itself: they ARE G1 and G0 (tsvgp.py:279-280), a sum of outer products
+            forms["projected"] = (acc2, acc1.transpose(-1, -2))
+        if len(forms) == 1:
+            G1, G0 = next(iter(forms.values()))
+        else:  # mixed routes (separate kernels): every latent keeps the form its sums were taken in
+            G1 = torch.stack([forms[r][0][p] for p, r in enumerate(routes)])
+            G0 = torch.stack([forms[r][1][:, p] for p, r in enumerate(routes)], dim=1)
         G1 = 0.5 * (G1 + G1.transpose(-1, -2))
         meanZ = _kmv(Kzz, beta)  # predict_f(Z) mean, tsvgp.py:249-254 (per latent kernel for separate kernels)
         grad_mu = gradient_transformation_mean_var_to_expectation(meanZ, [G0, G1])  # tsvgp.py:284

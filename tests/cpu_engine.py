@@ -20,13 +20,15 @@ class NumpyShardEngine:
         return torch.as_tensor(k.K(Z.cpu().numpy()))
 
     def run(self, X, Y, Z, kernel, *, moment_Tm, moment_mode, gamma, lik_id=0, lik_param=0.0, whiten_T=None,
-            whiten_mode=1, sites=False, want_moments=False, want_grads=False, b_tag=None):
+            whiten_mode=1, project_T=None, sites=False, want_moments=False, want_grads=False, b_tag=None):
         if hasattr(kernel, "kernels"):  # one pass per latent, as EStepEngine._run_separate
             parts = [self.run(X, None if Y is None else Y[:, p:p + 1], Z, kp, moment_Tm=moment_Tm[p:p + 1],
                               moment_mode=moment_mode, gamma=gamma[:, p:p + 1], lik_id=lik_id, lik_param=lik_param,
                               whiten_T=(whiten_T[p] if isinstance(whiten_T, (list, tuple)) else None if whiten_T is None
                                         else (whiten_T[p] if whiten_T.dim() == 3 else whiten_T)),
-                              whiten_mode=whiten_mode, sites=sites, want_moments=want_moments, want_grads=want_grads)
+                              whiten_mode=whiten_mode, sites=sites, want_moments=want_moments, want_grads=want_grads,
+                              project_T=(project_T[p] if isinstance(project_T, (list, tuple)) else None if project_T is None
+                                         else (project_T[p] if project_T.dim() == 3 else project_T)))
                      for p, kp in enumerate(kernel.kernels)]
             st = _Stats()
             st.n_rows = parts[0].n_rows
@@ -61,6 +63,7 @@ class NumpyShardEngine:
             g1 = np.minimum(g1, -1e-8) if crop else g1
             st.ve_sum = torch.tensor(float(np.sum(lik.variational_expectations(mean, var, Yn))), dtype=torch.float64)
             if sites:
-                st.acc2 = torch.as_tensor(np.einsum("nm,no,nl->lmo", A, A, g1))
-                st.acc1 = torch.as_tensor(np.einsum("nm,nl->lm", A, g0))
+                As = A if project_T is None else A @ np.tril(project_T.cpu().numpy()).T  # projected route: a = U9^-T b
+                st.acc2 = torch.as_tensor(np.einsum("nm,no,nl->lmo", As, As, g1))
+                st.acc1 = torch.as_tensor(np.einsum("nm,nl->lm", As, g0))
         return st

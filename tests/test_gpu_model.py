@@ -236,10 +236,11 @@ def test_warm_cache_matches_cold_and_invalidates():
 
 
 @pytest.mark.parametrize("lik,P", [("gaussian", 2), ("bernoulli", 1)])
-@pytest.mark.parametrize("projection", ["whitened", "direct"])
+@pytest.mark.parametrize("projection", ["whitened", "direct", "projected"])
 def test_both_projection_routes_match_oracle(lik, P, projection):
-    """The whitened route (N-sized triangular product) and the direct route (sums on K_fu, K_uu^-1 applied afterwards)
-    are the same algebra; on a well-conditioned K_uu both meet the fp64 tolerance against the oracle."""
+    """The whitened route (N-sized triangular product), the direct route (sums on K_fu, K_uu^-1 applied afterwards) and
+    the projected route (a = K_uu^-1 k by two triangular products, sums over a a^T as the reference) are the same
+    algebra; on a well-conditioned K_uu all meet the fp64 tolerance against the oracle."""
     p = pkg()
     rng = np.random.RandomState(11)
     X, Y, _ = synthetic(N=1200, M=64, D=6, P=P, lik=lik, seed=6)
@@ -422,3 +423,37 @@ def test_fp32_direct_route_against_fp64_oracle(lik, projection):
     np.testing.assert_allclose(mu_h.cpu().numpy(), mu_o, rtol=1e-3, atol=1e-4)
     np.testing.assert_allclose(var_h.cpu().numpy(), var_o, rtol=1e-3, atol=1e-4)
     assert relerr(hip.lambda_1.numpy(), ora.lambda_1) < 1e-3
+
+
+def test_ill_conditioned_kuu_takes_the_projected_route():
+    """cond(K_uu + 1e-9 I) ~ 7e10 (1-D inputs, 219 redundant inducing points: a typical 1-D demo geometry).  The cheaper
+    routes lose the definiteness of -2 lambda_2 + jitter I there (their M x M back-mapping amplifies rounding by
+    |K_uu^-1|); "auto" takes the projected route, which like the reference forms G1 as a sum of outer products.  The
+    natural parameters themselves are only determined to ~cond * eps in this regime (for ANY arithmetic order), so the
+    comparison is on what is well posed: ELBO and predictions."""
+    p = pkg()
+    rng = np.random.RandomState(3)
+    N, M = 1500, 219
+    X = rng.randn(N, 1)
+    Y = (np.sin(3 * X) + 0.3 * rng.randn(N, 1) > 0).astype(float)
+    Z = rng.randn(M, 1) * 1.5
+    mk = lambda mod, **kw: mod.t_SVGP(mod.SquaredExponential(0.58, 1.17), mod.Bernoulli(), Z, num_data=N, **kw)
+    hip, ora = mk(p), mk(O)
+    assert hip._routes(1e-9) == ["projected"] and hip._cond_cache[1][0] > 1e10
+    for _ in range(3):
+        hip.natgrad_step((X, Y), lr=0.7)
+        ora.natgrad_step((X, Y), lr=0.7)
+    e_h, e_o = float(hip.elbo((X, Y))), float(ora.elbo((X, Y)))
+    assert abs(e_h - e_o) / abs(e_o) < 1e-8
+    mu_h, var_h = hip.predict_f(X[:200])
+    mu_o, var_o = ora.predict_f(X[:200])
+    assert relerr(mu_h.cpu().numpy(), mu_o) < 1e-6 and relerr(var_h.cpu().numpy(), var_o) < 1e-6
+    # the ladder: forced onto the whitened route the final factorisation fails and the step is redone projected
+    forced = mk(p)
+    forced.WHITENED_MAX_COND = {torch.float64: float("inf"), torch.float32: float("inf")}
+    assert forced._routes(1e-9) == ["whitened"]
+    forced.natgrad_step((X, Y), lr=0.7)
+    assert forced._routes(1e-9) == ["projected"]  # remembered until the parameters change
+    one = mk(O)
+    one.natgrad_step((X, Y), lr=0.7)
+    assert abs(float(forced.elbo((X, Y))) - one.elbo((X, Y))) < 1e-8 * abs(one.elbo((X, Y)))
