@@ -50,7 +50,7 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
             e = float("inf")
         except FloatingPointError:
             e = 0.0
-    worst = max(worst, e)
+    worst = max(worst, e / max(1.0, cond * 2.2e-16 * 1e8 * 10))  # tolerance 1e-8, or 10 cond eps where that is larger
     print(f"trial {trial:2d} N={N} M={M} D={D} P={P} {lik} {kname} {'white' if white else route} cond {cond:.1e} max err {e:.1e}", flush=True)
-print("worst", worst)
+print("worst error relative to the tolerance max(1e-8, 10 cond eps), in units of 1e-8:", worst / 1e-8)
 sys.exit(0 if worst < 1e-8 else 1)
