@@ -471,12 +471,12 @@ struct PanelArgs {
     int Mp, P, mode, lik;
 };
 
-// FUSE (MOMENTS + UPPER only): the mean GEMV rides on the first column tile, whose k-range covers every chunk of the
-// row panel: each thread multiplies the eight A values it stages by gamma (kept in dynamic LDS, Mp elements) before
+// FUSE (MOMENTS, triangular modes): the mean GEMV rides on the column tile whose k-range covers every chunk of the
+// row panel (the first one for UPPER, the last one for LOWER): each thread multiplies the eight A values it stages by gamma (kept in dynamic LDS, Mp elements) before
 // storing them, which removes the separate sweep of the panel from HBM (1.0 of 18.3 ms at N = 1e6, M = 1024).
 template <typename T, int MODE, int TRI, bool FUSE = false>
 __global__ __launch_bounds__(NTHREADS, 2) void panel_kernel(PanelArgs<T> a) {
-    static_assert(!FUSE || (MODE == MODE_MOMENTS && TRI == TSVGP_TRI_UPPER), "FUSE needs a full k sweep on tile 0");
+    static_assert(!FUSE || (MODE == MODE_MOMENTS && TRI != TSVGP_TRI_DENSE), "FUSE rides on the tile with the full k sweep");
     extern __shared__ __attribute__((aligned(16))) unsigned char panel_dyn_smem[];
     T* const gsm = reinterpret_cast<T*>(panel_dyn_smem);  // FUSE: gamma_p, Mp elements
     constexpr int RS = RowStride<T>::value;
@@ -639,9 +639,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void panel_kernel(PanelArgs<T> a) {
                 rs_mine += keep;
             }
         };  // tile_body
-        if constexpr (FUSE) {
+        if constexpr (FUSE && TRI == TSVGP_TRI_UPPER) {  // upper triangle: the FIRST column tile sweeps every k-chunk
             tile_body(0, std::true_type{});
             for (int it = 1; it < ntile; ++it) tile_body(it, std::false_type{});
+        } else if constexpr (FUSE) {  // lower triangle: the LAST one does
+            for (int it = 0; it + 1 < ntile; ++it) tile_body(it, std::false_type{});
+            tile_body(ntile - 1, std::true_type{});
         } else {
             for (int it = 0; it < ntile; ++it) tile_body(it, std::false_type{});
         }
@@ -1549,7 +1552,10 @@ int moments(const T* A, const T* Tm, const T* gamma, const T* Y, double kdiag, i
     a.mode = mode;
     a.lik = lik;
     const dim3 grid((unsigned)(Np / TILE)), block(NTHREADS);
-    if (mode == TSVGP_TRI_LOWER)
+    if (mode == TSVGP_TRI_LOWER && (size_t)Mp * sizeof(T) <= 8192)
+        hipLaunchKernelGGL((panel_kernel<T, MODE_MOMENTS, TSVGP_TRI_LOWER, true>), grid, block, (size_t)Mp * sizeof(T),
+                           (hipStream_t)stream, a);
+    else if (mode == TSVGP_TRI_LOWER)
         hipLaunchKernelGGL((panel_kernel<T, MODE_MOMENTS, TSVGP_TRI_LOWER>), grid, block, 0, (hipStream_t)stream, a);
     else if (mode == TSVGP_TRI_UPPER && (size_t)Mp * sizeof(T) <= 8192)
         // gamma fits beside the staging buffers without costing the second workgroup per CU: fused mean
