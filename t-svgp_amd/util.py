@@ -48,12 +48,6 @@ def rev_cholesky(a: torch.Tensor, infos: list, potrf=None, inverse: bool = False
     return torch.flip(res, (-2, -1))
 
 
-def chol_solve_upper(U: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
-    """(U U^T)^-1 b by two triangular solves.  U [M, M] upper, b [..., M, K]."""
-    x = torch.linalg.solve_triangular(U, b, upper=True)
-    return torch.linalg.solve_triangular(U.transpose(-1, -2), x, upper=False)
-
-
 def _check_site_shapes(K, lambda_1, lambda_2_sqrt, who):
     if K.dim() < 2 or K.shape[-1] != K.shape[-2]:
         raise ValueError(f"{who}: K must be [..., M, M]")
