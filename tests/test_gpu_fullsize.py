@@ -70,3 +70,27 @@ def test_conjugate_fixed_point_full_size():
     mu_b, var_b = model.new_predict_f(Xs)
     assert relerr(mu_a.cpu().numpy(), mu_b.cpu().numpy()) < 1e-9
     assert relerr(var_a.cpu().numpy(), var_b.cpu().numpy()) < 1e-8
+
+
+def test_mstep_gradient_full_size():
+    """d ELBO / d (lengthscale, variance, noise) at N = 1e6 (977 row blocks of the gradient kernel, every partial buffer
+    in play) against central differences of the HIP ELBO itself (the oracle cannot run this size)."""
+    p = pkg()
+    N, M, D = 1_000_000, 512, 8
+    X, Y, Z = synthetic(N=N, M=M, D=D, lik="gaussian", seed=2)
+    Xd, Yd = torch.as_tensor(X, device="cuda:0"), torch.as_tensor(Y, device="cuda:0")
+    model = p.t_SVGP(p.SquaredExponential(1.0, 1.0), p.Gaussian(0.1), Z, num_data=N)
+    for _ in range(2):
+        model.natgrad_step((Xd, Yd), lr=0.8)
+    elbo, grads = model.elbo_and_grads((Xd, Yd))
+    assert abs(float(elbo) - float(model.elbo((Xd, Yd)))) < 1e-11 * abs(float(elbo))
+    for name, par in (("lengthscales", model.kernel.lengthscales), ("variance", model.kernel.variance),
+                      ("likelihood_variance", model.likelihood.variance)):
+        base, h = float(par.value), 1e-5
+        par.assign(base + h)
+        up = float(model.elbo((Xd, Yd)))
+        par.assign(base - h)
+        dn = float(model.elbo((Xd, Yd)))
+        par.assign(base)
+        ref = (up - dn) / (2 * h)
+        assert abs(float(grads[name]) - ref) < 1e-5 * abs(ref), (name, float(grads[name]), ref)
