@@ -39,12 +39,17 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
             return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC",
-           "-I", os.path.join(_ROOT, "include"), *SOURCES, "-o", LIB_PATH]
+           "-I", os.path.join(_ROOT, "include"), *SOURCES, "-o"]
+    # build beside the target and rename: a concurrent loader (several ranks of one job) never maps a half-written file
+    tmp = f"{LIB_PATH}.{os.getpid()}.tmp"
     if verbose:
-        print(" ".join(cmd))
-    res = subprocess.run(cmd, capture_output=True, text=True)
+        print(" ".join(cmd + [LIB_PATH]))
+    res = subprocess.run(cmd + [tmp], capture_output=True, text=True)
     if res.returncode != 0:
+        if os.path.exists(tmp):
+            os.remove(tmp)
         raise HipExtensionError("hipcc failed:\n" + res.stdout + res.stderr)
+    os.replace(tmp, LIB_PATH)
     return LIB_PATH
 
 
