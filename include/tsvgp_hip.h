@@ -39,6 +39,13 @@ extern "C" {
 #define TSVGP_LIK_BERNOULLI 2 /* gpflow.likelihoods.Bernoulli, probit + 1e-3 jitter, 20-pt Gauss-Hermite */
 #define TSVGP_LIK_NOCROP 0x100 /* OR-ed into the selector: leave g1 = d ve/d var uncropped (reference
                                   src/models/tsvgp_white.py:188-191 has no crop; src/models/tsvgp.py:262-263 has) */
+#define TSVGP_LIK_MEANONLY 0x200 /* OR-ed into the selector (NONE or GAUSSIAN only): skip the variance product.  Under a
+                                    Gaussian likelihood g0 = (y - mean)/s2 and g1 = -1/(2 s2) do not depend on the
+                                    predictive variance, so the natural-gradient step (src/models/tsvgp.py:246-263)
+                                    needs the mean alone: one HBM-bound sweep of A instead of the MFMA product.
+                                    Tm and mode are ignored, var must be NULL, ve_partial is written as NaN (the
+                                    variational expectation itself does need the variance), nonpos_partial counts rows with a
+                                    non-finite mean or gradient. */
 
 /* k-range selectors of the panel product C[n,i] = sum_j A[n,j] * Tm[i,j] */
 #define TSVGP_TRI_LOWER 0 /* j <= i  (forward substitution with the inverted factor)   */

@@ -21,6 +21,7 @@ SOURCES = [os.path.join(CSRC, "tsvgp_kernels.hip")]
 TILE = 128
 LIK_NONE, LIK_GAUSSIAN, LIK_BERNOULLI = 0, 1, 2
 LIK_NOCROP = 0x100
+LIK_MEANONLY = 0x200
 KERNEL_SE, KERNEL_MATERN32, KERNEL_MATERN52 = 0, 2, 3
 TRI_LOWER, TRI_UPPER, TRI_DENSE = 0, 1, 2
 

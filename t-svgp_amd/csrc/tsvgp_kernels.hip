@@ -202,7 +202,7 @@ __device__ __forceinline__ void bern_point(double f, bool y1, double& lp, double
 
 __device__ __forceinline__ void lik_eval(int lik_flags, double s2, double m, double v, double y, double& g0, double& g1,
                                          double& ve) {
-    const int lik = lik_flags & ~TSVGP_LIK_NOCROP;
+    const int lik = lik_flags & 0xFF;
     if (lik == TSVGP_LIK_GAUSSIAN) {
         const double r = y - m;
         g0 = r / s2;
@@ -698,6 +698,73 @@ __global__ __launch_bounds__(NTHREADS, 2) void panel_kernel(PanelArgs<T> a) {
             if (a.ve_partial) a.ve_partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
             if (a.nonpos_partial) a.nonpos_partial[blockIdx.x] = redi[0] + redi[1] + redi[2] + redi[3];
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// mean_lik_kernel (TSVGP_LIK_MEANONLY): mean[n, p] = sum_j A[n, j] * gamma[j, p] and, for the Gaussian likelihood,
+// g0 = (y - mean) / s2, g1 = -1 / (2 s2) -- neither depends on the predictive variance.  HBM bound: one sweep of A.
+// One workgroup per 128-row panel (same grid as panel_kernel, so the per-workgroup partial buffers keep their
+// meaning); a wave owns 32 rows and reads two of them at a time with 16-byte loads, gamma [P][Mp] in dynamic LDS.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(NTHREADS) void mean_lik_kernel(PanelArgs<T> a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char mean_dyn_smem[];
+    T* const gs = reinterpret_cast<T*>(mean_dyn_smem);
+    constexpr int V = 16 / sizeof(T);
+    typedef T vec_t __attribute__((ext_vector_type(V)));
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int Mp = a.Mp, P = a.P;
+    __shared__ int bad;  // rows whose mean or gradient is not finite: reported through nonpos_partial
+    if (t == 0) bad = 0;
+    for (int i = t; i < Mp * P; i += NTHREADS) {
+        const int p = i / Mp, j = i - p * Mp;
+        gs[i] = a.gamma[(size_t)j * P + p];
+    }
+    __syncthreads();
+    const int64_t nw = (int64_t)blockIdx.x * TILE + w * (TILE / 4);
+    for (int r = 0; r < TILE / 4; r += 2) {
+        const T* r0 = a.A + (nw + r) * (int64_t)Mp;
+        const T* r1 = r0 + Mp;
+        for (int p = 0; p < P; ++p) {  // P > 1 re-reads the two rows from cache
+            const T* gp = gs + p * Mp;
+            T s0 = T(0), s1 = T(0);
+#pragma unroll 4
+            for (int j = lane * V; j < Mp; j += 64 * V) {
+                const vec_t x0 = *reinterpret_cast<const vec_t*>(r0 + j);
+                const vec_t x1 = *reinterpret_cast<const vec_t*>(r1 + j);
+                const vec_t g = *reinterpret_cast<const vec_t*>(gp + j);
+#pragma unroll
+                for (int q = 0; q < V; ++q) {
+                    s0 += x0[q] * g[q];
+                    s1 += x1[q] * g[q];
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                s0 += __shfl_xor(s0, o);
+                s1 += __shfl_xor(s1, o);
+            }
+            if (lane < 2) {
+                const int64_t n = nw + r + lane;
+                const double mu = (double)(lane ? s1 : s0);
+                double g0 = 0.0, g1 = 0.0, ve = 0.0;
+                if (n < a.N) {
+                    if (a.mean) a.mean[n * P + p] = (T)mu;
+                    if (a.lik != TSVGP_LIK_NONE) lik_eval(a.lik, a.lik_param, mu, 0.0, (double)a.Y[n * P + p], g0, g1, ve);
+                    if (!(fabs(mu) <= 1.79769313486231570815e308) || !(fabs(g0) <= 1.79769313486231570815e308)) atomicAdd(&bad, 1);
+                }
+                if (a.lik != TSVGP_LIK_NONE) {
+                    a.g0[n * P + p] = (T)g0;  // rows >= N: zeros (the padding contract of site_accum)
+                    a.g1[n * P + p] = (T)g1;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (t == 0) {
+        if (a.ve_partial) a.ve_partial[blockIdx.x] = __builtin_nan("");
+        if (a.nonpos_partial) a.nonpos_partial[blockIdx.x] = bad;
     }
 }
 
@@ -1524,11 +1591,15 @@ template <typename T>
 int moments(const T* A, const T* Tm, const T* gamma, const T* Y, double kdiag, int lik, double lik_param, T* mean,
             T* var, T* g0, T* g1, double* ve_partial, int32_t* nonpos_partial, int64_t N, int64_t Np, int Mp, int P,
             int mode, void* stream) {
-    if (!A || !Tm || !gamma || N <= 0 || Np < N || (Np % TILE) || Mp <= 0 || (Mp % TILE) || P <= 0 || mode < 0 ||
-        mode > 2)
-        return TSVGP_EINVAL;
-    const int lik_base = lik & ~TSVGP_LIK_NOCROP;
+    const bool mean_only = (lik & TSVGP_LIK_MEANONLY) != 0;
+    if (!A || !gamma || N <= 0 || Np < N || (Np % TILE) || Mp <= 0 || (Mp % TILE) || P <= 0) return TSVGP_EINVAL;
+    if (!mean_only && (!Tm || mode < 0 || mode > 2)) return TSVGP_EINVAL;
+    if (lik & ~(0xFF | TSVGP_LIK_NOCROP | TSVGP_LIK_MEANONLY)) return TSVGP_EINVAL;
+    const int lik_base = lik & 0xFF;
     if (lik_base != TSVGP_LIK_NONE && lik_base != TSVGP_LIK_GAUSSIAN && lik_base != TSVGP_LIK_BERNOULLI) return TSVGP_EINVAL;
+    // mean only: the Bernoulli gradients do depend on the variance; gamma [P][Mp] has to fit the LDS
+    if (mean_only && (lik_base == TSVGP_LIK_BERNOULLI || var || (size_t)Mp * P * sizeof(T) > 65536)) return TSVGP_EINVAL;
+    lik &= ~TSVGP_LIK_MEANONLY;
     if (lik_base == TSVGP_LIK_NONE) lik = TSVGP_LIK_NONE;
     if (lik != TSVGP_LIK_NONE && (!Y || !g0 || !g1)) return TSVGP_EINVAL;
     if (lik_base == TSVGP_LIK_GAUSSIAN && !(lik_param > 0.0)) return TSVGP_EINVAL;
@@ -1552,7 +1623,9 @@ int moments(const T* A, const T* Tm, const T* gamma, const T* Y, double kdiag, i
     a.mode = mode;
     a.lik = lik;
     const dim3 grid((unsigned)(Np / TILE)), block(NTHREADS);
-    if (mode == TSVGP_TRI_LOWER && (size_t)Mp * sizeof(T) <= 8192)
+    if (mean_only)
+        hipLaunchKernelGGL((mean_lik_kernel<T>), grid, block, (size_t)Mp * P * sizeof(T), (hipStream_t)stream, a);
+    else if (mode == TSVGP_TRI_LOWER && (size_t)Mp * sizeof(T) <= 8192)
         hipLaunchKernelGGL((panel_kernel<T, MODE_MOMENTS, TSVGP_TRI_LOWER, true>), grid, block, (size_t)Mp * sizeof(T),
                            (hipStream_t)stream, a);
     else if (mode == TSVGP_TRI_LOWER)

@@ -274,7 +274,7 @@ class EStepEngine:
     # ------------------------------------------------------------------ one N-pass
     def run(self, X, Y, Z, kernel, *, moment_Tm, moment_mode, gamma, lik_id=B.LIK_NONE, lik_param=0.0,
             whiten_T=None, whiten_mode=B.TRI_UPPER, project_T=None, sites=False, want_moments=False, want_grads=False,
-            b_tag=None) -> EStepStats:
+            b_tag=None, mean_only=False) -> EStepStats:
         """One pass over the shard's rows.
 
         X [N, D], Y [N, P] (or None when lik_id == NONE), Z [M, D];
@@ -289,11 +289,16 @@ class EStepEngine:
         b_tag: a hashable description of (X, Z, kernel parameters, jitter).  When it equals the tag of the B buffer left
         by the previous call, the fill and the whitening are skipped and B is reused ("warm" E-step: consecutive
         E-steps with unchanged hyperparameters, as in the reference's E/M loop, experiments/uci_regression.py:152-153).
+        mean_only (likelihood NONE or GAUSSIAN): skip the variance product of the moments (TSVGP_LIK_MEANONLY) -- the
+        Gaussian g0, g1 do not depend on it; ``var`` is then None and ``ve_sum`` NaN.
         """
         if isinstance(kernel, SeparateIndependent):
             return self._run_separate(X, Y, Z, kernel, moment_Tm=moment_Tm, moment_mode=moment_mode, gamma=gamma,
                                       lik_id=lik_id, lik_param=lik_param, whiten_T=whiten_T, whiten_mode=whiten_mode,
-                                      project_T=project_T, sites=sites, want_moments=want_moments, want_grads=want_grads)
+                                      project_T=project_T, sites=sites, want_moments=want_moments, want_grads=want_grads,
+                                      mean_only=mean_only)
+        if mean_only and (lik_id & 0xFF) not in (B.LIK_NONE, B.LIK_GAUSSIAN):
+            raise ValueError("mean_only needs a likelihood whose gradients do not depend on the predictive variance")
         T, dev = self.dtype, self.device
         X = X.to(device=dev, dtype=T).contiguous()
         Z = Z.to(device=dev, dtype=T).contiguous()
@@ -341,15 +346,16 @@ class EStepEngine:
         g0 = self._get("g0", (Np, P), T) if need_g else None
         g1 = self._get("g1", (Np, P), T) if need_g else None
         mean = torch.empty((N, P), dtype=T, device=dev) if want_moments else None
-        var = torch.empty((N, P), dtype=T, device=dev) if want_moments else None
+        var = torch.empty((N, P), dtype=T, device=dev) if (want_moments and not mean_only) else None
+        lik_flags = (lik_id | B.LIK_MEANONLY) if mean_only else lik_id
         with torch.cuda.device(dev):
             self._launch("tsvgp_moments", lambda: self._fn("tsvgp_moments")(
-                A.data_ptr(), Tm.data_ptr(), gam.data_ptr(), _ptr(Y) if need_g else None, variance, lik_id,
+                A.data_ptr(), Tm.data_ptr(), gam.data_ptr(), _ptr(Y) if need_g else None, variance, lik_flags,
                 float(lik_param), _ptr(mean), _ptr(var), _ptr(g0), _ptr(g1), ve_partial.data_ptr(),
                 nonpos_partial.data_ptr(), N, Np, Mp, P, moment_mode, self._stream()))
         stats = EStepStats(n_rows=N, ve_sum=ve_partial.sum(), nonpos=nonpos_partial.sum().to(torch.float64))
         if want_moments:
-            stats.mean, stats.var = mean.to(torch.float64), var.to(torch.float64)
+            stats.mean, stats.var = mean.to(torch.float64), (None if var is None else var.to(torch.float64))
         if want_grads and need_g:
             stats.g0, stats.g1 = g0[:N].to(torch.float64), g1[:N].to(torch.float64)
 

@@ -135,7 +135,7 @@ class t_SVGP(base_SVGP):
 
     def __init__(self, kernel, likelihood, inducing_variable, *, mean_function=None, num_latent_gps: int = 1,
                  lambda_1=None, lambda_2_sqrt=None, num_data=None, force=False, compute_dtype=None, device=None,
-                 cache_whitened=False, projection="auto", use_graph=False):
+                 cache_whitened=False, projection="auto", use_graph=False, skip_unused_variance=False):
         super().__init__(kernel, likelihood, inducing_variable, mean_function=mean_function,
                          num_latent_gps=num_latent_gps, num_data=num_data, compute_dtype=compute_dtype, device=device)
         self.num_inducing = self.inducing_variable.num_inducing
@@ -163,6 +163,11 @@ class t_SVGP(base_SVGP):
         # Opt-in: replay natgrad_step from a captured hipGraph (see _graph_step); pays off when the step is launch bound
         self.use_graph = use_graph
         self._graphs = {}
+        # Opt-in, Gaussian likelihood only: natgrad_step skips the predictive-variance product.  The reference computes
+        # the variance because autodiff needs the forward pass (tsvgp.py:246-259), but d ve/d mean = (y - mean)/s2 and
+        # d ve/d var = -1/(2 s2) do not depend on it, so the updated sites are the same numbers; what is lost is the
+        # var > 0 check of the step (tsvgp.py:113), which elbo / predict_f still make.
+        self.skip_unused_variance = skip_unused_variance
         self.name = "t_svgp"  # tf.Module derives this from the class name (experiments/uci_regression.py:150)
 
     def _init_variational_parameters(self, num_inducing, lambda_1, lambda_2_sqrt, **kwargs):
@@ -534,7 +539,8 @@ class t_SVGP(base_SVGP):
                                     moment_mode=ops["moment_mode"], gamma=ops["gamma"],
                                     lik_id=self.likelihood.lik_id, lik_param=self.likelihood.lik_param,
                                     whiten_T=ops["whiten_T"], whiten_mode=ops["whiten_mode"], project_T=ops["project_T"],
-                                    sites=True, b_tag=warm_key)
+                                    sites=True, b_tag=warm_key,
+                                    mean_only=self.skip_unused_variance and self.likelihood.lik_id == B.LIK_GAUSSIAN)
         return self._apply_site_update(st, ops, lr, jitter, inplace=inplace)
 
     # -- hipGraph replay of the step (launch-bound problem sizes) -------------------------------------------------

@@ -20,7 +20,8 @@ class NumpyShardEngine:
         return torch.as_tensor(k.K(Z.cpu().numpy()))
 
     def run(self, X, Y, Z, kernel, *, moment_Tm, moment_mode, gamma, lik_id=0, lik_param=0.0, whiten_T=None,
-            whiten_mode=1, project_T=None, sites=False, want_moments=False, want_grads=False, b_tag=None):
+            whiten_mode=1, project_T=None, sites=False, want_moments=False, want_grads=False, b_tag=None,
+            mean_only=False):
         if hasattr(kernel, "kernels"):  # one pass per latent, as EStepEngine._run_separate
             parts = [self.run(X, None if Y is None else Y[:, p:p + 1], Z, kp, moment_Tm=moment_Tm[p:p + 1],
                               moment_mode=moment_mode, gamma=gamma[:, p:p + 1], lik_id=lik_id, lik_param=lik_param,
@@ -28,7 +29,8 @@ class NumpyShardEngine:
                                         else (whiten_T[p] if whiten_T.dim() == 3 else whiten_T)),
                               whiten_mode=whiten_mode, sites=sites, want_moments=want_moments, want_grads=want_grads,
                               project_T=(project_T[p] if isinstance(project_T, (list, tuple)) else None if project_T is None
-                                         else (project_T[p] if project_T.dim() == 3 else project_T)))
+                                         else (project_T[p] if project_T.dim() == 3 else project_T)),
+                              mean_only=mean_only)
                      for p, kp in enumerate(kernel.kernels)]
             st = _Stats()
             st.n_rows = parts[0].n_rows
@@ -66,4 +68,8 @@ class NumpyShardEngine:
                 As = A if project_T is None else A @ np.tril(project_T.cpu().numpy()).T  # projected route: a = U9^-T b
                 st.acc2 = torch.as_tensor(np.einsum("nm,no,nl->lmo", As, As, g1))
                 st.acc1 = torch.as_tensor(np.einsum("nm,nl->lm", As, g0))
+        if mean_only:  # TSVGP_LIK_MEANONLY: no variance, no variational expectation; non-finite rows are counted
+            assert lik_id in (0, 1)
+            st.var, st.ve_sum = None, torch.tensor(float("nan"), dtype=torch.float64)
+            st.nonpos = torch.tensor(float(np.sum(~np.isfinite(mean))))
         return st

@@ -126,6 +126,51 @@ def test_moments_and_likelihood_map(engines, dtype, tol, lik, N, M, P, mode):
 
 
 @pytest.mark.parametrize("dtype,tol", DTYPES)
+@pytest.mark.parametrize("lik", ["none", "gaussian"])
+@pytest.mark.parametrize("N,M,P", [(100, 128, 1), (300, 256, 2), (129, 384, 3), (1000, 1024, 1)])
+def test_moments_mean_only(engines, dtype, tol, lik, N, M, P):
+    """TSVGP_LIK_MEANONLY: mean and the Gaussian gradient map without the variance product; Tm is not read."""
+    eng = engines[dtype]
+    B = pkg()._backend
+    rng = np.random.RandomState(5)
+    Np = B.round_up(N)
+    A = np.zeros((Np, M))
+    A[:N] = rng.randn(N, M) / np.sqrt(M)
+    gamma, Y = rng.randn(M, P), rng.randn(N, P)
+    t = lambda a: torch.as_tensor(a, dtype=dtype, device="cuda:0").contiguous()
+    At, gt, Yt = t(A), t(gamma), t(Y)
+    mean = torch.empty((N, P), dtype=dtype, device="cuda:0")
+    g0 = torch.full((Np, P), float("nan"), dtype=dtype, device="cuda:0")
+    g1 = torch.full((Np, P), float("nan"), dtype=dtype, device="cuda:0")
+    vep = torch.zeros(Np // 128, dtype=torch.float64, device="cuda:0")
+    npp = torch.full((Np // 128,), 7, dtype=torch.int32, device="cuda:0")
+    lik_id = {"none": 0, "gaussian": 1}[lik] | B.LIK_MEANONLY
+    fn = eng._fn("tsvgp_moments")
+    call = lambda a_ptr, lid, var_ptr: fn(a_ptr, None, gt.data_ptr(), Yt.data_ptr(), 2.5, lid, 0.3, mean.data_ptr(), var_ptr,
+                                          g0.data_ptr(), g1.data_ptr(), vep.data_ptr(), npp.data_ptr(), N, Np, M, P, 1,
+                                          eng._stream())
+    B.check(call(At.data_ptr(), lik_id, None), "moments (mean only)")
+    torch.cuda.synchronize()
+    mref = At.double().cpu().numpy()[:N] @ gt.double().cpu().numpy()
+    assert relerr(mean.cpu().numpy(), mref) < tol * 20
+    assert int(npp.sum()) == 0 and torch.isnan(vep).all()
+    if lik == "gaussian":
+        mu = mean.double().cpu().numpy()
+        ltol = 1e-12 if dtype == torch.float64 else 1e-5
+        np.testing.assert_allclose(g0.double().cpu().numpy()[:N], (Yt.double().cpu().numpy() - mu) / 0.3, rtol=ltol, atol=ltol)
+        np.testing.assert_allclose(g1.double().cpu().numpy()[:N], -0.5 / 0.3, rtol=ltol)
+        assert np.all(g0.cpu().numpy()[N:] == 0) and np.all(g1.cpu().numpy()[N:] == 0)
+    # a non-finite row is counted (the step's status check then raises as for a non-positive variance)
+    Abad = At.clone()
+    Abad[N // 2, 3] = float("nan")
+    B.check(call(Abad.data_ptr(), lik_id, None), "moments (mean only)")
+    assert int(npp.sum()) == P
+    # rejected: Bernoulli (its gradients need the variance), a variance output
+    assert call(At.data_ptr(), 2 | B.LIK_MEANONLY, None) == 1
+    assert call(At.data_ptr(), lik_id, mean.data_ptr()) == 1
+
+
+@pytest.mark.parametrize("dtype,tol", DTYPES)
 @pytest.mark.parametrize("Np,Mp,P,nsplit", [(128, 128, 1, 1), (1024, 256, 2, 3), (640, 384, 1, 7), (4096, 128, 3, 64)])
 def test_site_accum(engines, dtype, tol, Np, Mp, P, nsplit):
     eng = engines[dtype]

@@ -257,6 +257,39 @@ def test_both_projection_routes_match_oracle(lik, P, projection):
     assert abs(e_h - e_o) / abs(e_o) < 1e-9
 
 
+@pytest.mark.parametrize("P,separate", [(1, False), (2, False), (2, True)])
+@pytest.mark.parametrize("projection", ["whitened", "direct", "projected"])
+def test_skip_unused_variance_matches_oracle(P, separate, projection):
+    """Gaussian likelihood: d ve/d mean and d ve/d var do not depend on the predictive variance, so natgrad_step may skip
+    the variance product (TSVGP_LIK_MEANONLY): same sites as the oracle, which computes it as the reference does."""
+    p = pkg()
+    rng = np.random.RandomState(12)
+    X, Y, _ = synthetic(N=1500, M=70, D=5, P=P, lik="gaussian", seed=8)
+    Z = rng.randn(70, 5) * 1.5
+    mk = lambda m, ls: m.SquaredExponential(1.0, ls)
+    kh = p.SeparateIndependent([mk(p, 1.0), mk(p, 1.3)]) if separate else mk(p, 1.0)
+    ko = O.SeparateIndependent([mk(O, 1.0), mk(O, 1.3)]) if separate else mk(O, 1.0)
+    hip = p.t_SVGP(kh, p.Gaussian(0.1), Z, num_latent_gps=P, projection=projection, skip_unused_variance=True)
+    ora = O.t_SVGP(ko, O.Gaussian(0.1), Z, num_latent_gps=P)
+    for _ in range(4):
+        hip.natgrad_step((X, Y), lr=0.7)
+        ora.natgrad_step((X, Y), lr=0.7)
+        _compare_state(hip, ora, 1e-8)
+    assert abs(float(hip.elbo((X, Y))) - float(ora.elbo((X, Y)))) < 1e-9 * abs(float(ora.elbo((X, Y))))
+    # the flag is inert for a likelihood whose gradients need the variance
+    Xb, Yb, _ = synthetic(N=600, M=70, D=5, P=1, lik="bernoulli", seed=9)
+    hb = p.t_SVGP(p.SquaredExponential(1.0, 1.0), p.Bernoulli(), Z, skip_unused_variance=True)
+    ob = O.t_SVGP(O.SquaredExponential(1.0, 1.0), O.Bernoulli(), Z)
+    hb.natgrad_step((Xb, Yb), lr=0.5)
+    ob.natgrad_step((Xb, Yb), lr=0.5)
+    _compare_state(hb, ob, 1e-8)
+    # a NaN target no longer shows in a variance: the non-finite mean / gradient count raises instead
+    Ybad = Y.copy()
+    Ybad[7, 0] = np.nan
+    with pytest.raises(FloatingPointError):
+        hip.natgrad_step((X, Ybad), lr=0.7)
+
+
 def test_auto_projection_gate():
     """"auto" picks the direct route only when cond(K_uu + jitter I) is small; ill-conditioned K_uu stays whitened."""
     p = pkg()

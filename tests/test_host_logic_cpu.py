@@ -54,6 +54,33 @@ def test_host_prelude_and_epilogue_match_oracle(lik, P):
     assert abs(float(hip.prior_kl()) - ora.prior_kl()) < 1e-8 * max(1.0, abs(ora.prior_kl()))
 
 
+def test_skip_unused_variance_host_logic():
+    """skip_unused_variance asks the N-pass for the mean only under a Gaussian likelihood (and leaves other
+    likelihoods alone); the step is the oracle's, which computes the variance as the reference does."""
+    X, Y, Z = synthetic(N=300, M=24, D=2, P=2, lik="gaussian", seed=2)
+    hip, ora = _pair(Z, "gaussian", 2)
+    hip.skip_unused_variance = True
+    seen = []
+    inner = hip._engine.run
+    hip._engine.run = lambda *a, **k: (seen.append(k.get("mean_only")), inner(*a, **k))[1]
+    for _ in range(3):
+        hip.natgrad_step((X, Y), lr=0.7)
+        ora.natgrad_step((X, Y), lr=0.7)
+        assert relerr(hip.lambda_1.numpy(), ora.lambda_1) < 1e-9
+        assert relerr(hip.lambda_2.numpy(), ora.lambda_2) < 1e-9
+    assert seen == [True] * 3
+    assert abs(float(hip.elbo((X, Y))) - ora.elbo((X, Y))) < 1e-9 * abs(ora.elbo((X, Y)))  # elbo keeps the variance
+    Xb, Yb, Zb = synthetic(N=300, M=24, D=2, P=1, lik="bernoulli", seed=2)
+    hb, ob = _pair(Zb, "bernoulli", 1)
+    hb.skip_unused_variance = True
+    seen_b = []
+    inner_b = hb._engine.run
+    hb._engine.run = lambda *a, **k: (seen_b.append(k.get("mean_only")), inner_b(*a, **k))[1]
+    hb.natgrad_step((Xb, Yb), lr=0.5)
+    ob.natgrad_step((Xb, Yb), lr=0.5)
+    assert seen_b == [False] and relerr(hb.lambda_1.numpy(), ob.lambda_1) < 1e-9
+
+
 def test_util_functions_match_oracle():
     p = pkg()
     rng = np.random.RandomState(0)
