@@ -269,8 +269,9 @@ def test_skip_unused_variance_matches_oracle(P, separate, projection):
     mk = lambda m, ls: m.SquaredExponential(1.0, ls)
     kh = p.SeparateIndependent([mk(p, 1.0), mk(p, 1.3)]) if separate else mk(p, 1.0)
     ko = O.SeparateIndependent([mk(O, 1.0), mk(O, 1.3)]) if separate else mk(O, 1.0)
-    hip = p.t_SVGP(kh, p.Gaussian(0.1), Z, num_latent_gps=P, projection=projection, skip_unused_variance=True)
-    ora = O.t_SVGP(ko, O.Gaussian(0.1), Z, num_latent_gps=P)
+    wrap = (lambda m: m.SharedIndependentInducingVariables(Z)) if separate else (lambda m: Z)
+    hip = p.t_SVGP(kh, p.Gaussian(0.1), wrap(p), num_latent_gps=P, projection=projection, skip_unused_variance=True)
+    ora = O.t_SVGP(ko, O.Gaussian(0.1), wrap(O), num_latent_gps=P)
     for _ in range(4):
         hip.natgrad_step((X, Y), lr=0.7)
         ora.natgrad_step((X, Y), lr=0.7)
