@@ -34,7 +34,10 @@
 namespace {
 
 constexpr int TILE = TSVGP_TILE;  // 128
-constexpr int KC = 16;            // k-chunk
+constexpr int KC = 16;            // k-chunk of the site-accumulation kernel ([k][row] images)
+#ifndef TSVGP_PANEL_KC_F32
+#define TSVGP_PANEL_KC_F32 32
+#endif
 constexpr int LDS_KS = 144;       // [k][row] image: k stride (elements)
 constexpr int NTHREADS = 256;
 constexpr int MODE_STORE = 0;
@@ -70,27 +73,32 @@ struct Mfma<float> {
     static __device__ __forceinline__ int row(int lane, int r) { return (lane >> 4) * 4 + r; }
 };
 
-// [row][k] LDS image: row stride in elements.  17 doubles / 18 floats make the fragment reads (the compiler pairs them
-// as ds_read2_b64 / ds_read2_b32, banked modulo 32 dwords per lane group) and the 8-byte staging writes conflict free.
+// k-chunk of the panel kernels ([row][k] images): 16 doubles or 32 floats -- the same 128 bytes per row, the same 64
+// bytes staged per thread and operand, and the same MFMA time between two barriers for both types (an fp32 MFMA takes
+// half the cycles of an fp64 one; with 16-float chunks the barrier and the staging latency weigh twice as much).
+// Row stride in elements: 17 doubles / 34 floats (18 for 16-float chunks) make the fragment reads (banked modulo 32
+// dwords per group of 32 lanes) and the 8-byte staging writes conflict free.
 template <typename T>
-struct RowStride {
-    static constexpr int value = sizeof(T) == 8 ? 17 : 18;
+struct PanelK {
+    static constexpr int KC = sizeof(T) == 8 ? 16 : TSVGP_PANEL_KC_F32;
+    static constexpr int H = KC / 2;  // elements one thread stages per operand and chunk
+    static constexpr int RS = KC + (sizeof(T) == 8 ? 1 : 2);
 };
 
-// 8 consecutive elements of one row: global -> registers (16-byte loads) and registers -> LDS (8-byte stores: the rows
+// H consecutive elements of one row: global -> registers (16-byte loads) and registers -> LDS (8-byte stores: the rows
 // of the double image are only 8-byte aligned).
-template <typename T>
-__device__ __forceinline__ void load8(T (&r)[8], const T* __restrict__ p) {
+template <typename T, int H>
+__device__ __forceinline__ void load_run(T (&r)[H], const T* __restrict__ p) {
     if constexpr (sizeof(T) == 8) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < H / 2; ++q) {
             v2d v = *reinterpret_cast<const v2d*>(p + 2 * q);
             r[2 * q] = v[0];
             r[2 * q + 1] = v[1];
         }
     } else {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < H / 4; ++q) {
             v4f v = *reinterpret_cast<const v4f*>(p + 4 * q);
             r[4 * q] = v[0];
             r[4 * q + 1] = v[1];
@@ -99,14 +107,14 @@ __device__ __forceinline__ void load8(T (&r)[8], const T* __restrict__ p) {
         }
     }
 }
-template <typename T>
-__device__ __forceinline__ void store_rowk8(T* p, const T (&r)[8]) {
+template <typename T, int H>
+__device__ __forceinline__ void store_run(T* p, const T (&r)[H]) {
     if constexpr (sizeof(T) == 8) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) p[q] = r[q];
+        for (int q = 0; q < H; ++q) p[q] = r[q];
     } else {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < H / 2; ++q) {
             v2f v;
             v[0] = r[2 * q];
             v[1] = r[2 * q + 1];
@@ -121,18 +129,20 @@ __device__ __forceinline__ void store_rowk8(T* p, const T (&r)[8]) {
 // row pairing {w, 7 - w} gives every wave 9 of its 16 accumulators on a diagonal tile of the symmetric product.
 __device__ __forceinline__ int row_block(int w, int slot) { return slot == 0 ? w : 7 - w; }
 
-// One k-chunk (16) of MFMAs on [row][k] images: acc[s][n] += A(row block s) * B(column block n)^T.
-// NMASK (compile time): bit n set = column block n takes part.
-template <typename T, int NMASK>
+// One k-chunk of MFMAs on [row][k] images: acc[s][n] += A(row block s) * B(column block n)^T.
+// MLO / MHI (compile time): bit n set = column block n takes part in the first / second half of the chunk's k-steps
+// (a 32-wide chunk spans two 16-wide k-blocks of a triangular operand; for 16-wide chunks both masks are equal).
+template <typename T, int MLO, int MHI>
 __device__ __forceinline__ void mma_chunk_rowk(typename Mfma<T>::acc_t (&acc)[2][8], const T* __restrict__ As,
                                                const T* __restrict__ Bs, int w, int lane) {
-    constexpr int RS = RowStride<T>::value;
+    constexpr int RS = PanelK<T>::RS, PKC = PanelK<T>::KC;
     const int lr = lane & 15, lk = lane >> 4;
     const T* ap0 = As + (w * 16 + lr) * RS + lk;
     const T* ap1 = As + ((7 - w) * 16 + lr) * RS + lk;
     const T* bp = Bs + lr * RS + lk;
 #pragma unroll
-    for (int ks = 0; ks < KC / 4; ++ks) {
+    for (int ks = 0; ks < PKC / 4; ++ks) {
+        const int NMASK = (ks < PKC / 8) ? MLO : MHI;
         T a[2], b[8];
         a[0] = ap0[ks * 4];
         a[1] = ap1[ks * 4];
@@ -200,6 +210,24 @@ __device__ __forceinline__ void bern_point(double f, bool y1, double& lp, double
     }
 }
 
+// Gauss-Hermite partial sums over the node pairs [i0, i1) of the Bernoulli map (two threads share a row in the panel kernel)
+__device__ __forceinline__ void bern_sums(double m, double sd, bool y1, int i0, int i1, double& a0, double& a1, double& av) {
+    a0 = a1 = av = 0.0;
+#pragma unroll 1
+    for (int i = i0; i < i1; ++i) {
+        const double z = GH_X[i], w = GH_W[i];
+        double lp, dl;
+        bern_point(m + sd * z, y1, lp, dl);
+        av += w * lp;
+        a0 += w * dl;
+        a1 += w * dl * z;
+        bern_point(m - sd * z, y1, lp, dl);
+        av += w * lp;
+        a0 += w * dl;
+        a1 -= w * dl * z;
+    }
+}
+
 __device__ __forceinline__ void lik_eval(int lik_flags, double s2, double m, double v, double y, double& g0, double& g1,
                                          double& ve) {
     const int lik = lik_flags & 0xFF;
@@ -210,21 +238,8 @@ __device__ __forceinline__ void lik_eval(int lik_flags, double s2, double m, dou
         ve = -0.5 * 1.83787706640934548356 - 0.5 * log(s2) - 0.5 * (r * r + v) / s2;
     } else {  // Bernoulli, probit, 20-pt Gauss-Hermite; derivative OF the quadrature sum
         const double sd = sqrt(v);
-        const bool y1 = (y == 1.0);
-        double a0 = 0.0, a1 = 0.0, av = 0.0;
-#pragma unroll 1
-        for (int i = 0; i < 10; ++i) {
-            const double z = GH_X[i], w = GH_W[i];
-            double lp, dl;
-            bern_point(m + sd * z, y1, lp, dl);
-            av += w * lp;
-            a0 += w * dl;
-            a1 += w * dl * z;
-            bern_point(m - sd * z, y1, lp, dl);
-            av += w * lp;
-            a0 += w * dl;
-            a1 -= w * dl * z;
-        }
+        double a0, a1, av;
+        bern_sums(m, sd, y == 1.0, 0, 10, a0, a1, av);
         g0 = a0;
         g1 = a1 / (2.0 * sd);
         ve = av;
@@ -479,7 +494,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void panel_kernel(PanelArgs<T> a) {
     static_assert(!FUSE || (MODE == MODE_MOMENTS && TRI != TSVGP_TRI_DENSE), "FUSE rides on the tile with the full k sweep");
     extern __shared__ __attribute__((aligned(16))) unsigned char panel_dyn_smem[];
     T* const gsm = reinterpret_cast<T*>(panel_dyn_smem);  // FUSE: gamma_p, Mp elements
-    constexpr int RS = RowStride<T>::value;
+    constexpr int RS = PanelK<T>::RS, KC = PanelK<T>::KC, H = PanelK<T>::H;  // KC shadows the site kernel's constant
     constexpr int CPT = TILE / KC;  // chunks per 128-wide k-tile
     __shared__ __attribute__((aligned(16))) T lds[2][2][TILE * RS];
     __shared__ double rowq[TILE];
@@ -494,8 +509,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void panel_kernel(PanelArgs<T> a) {
     const int Mp = a.Mp;
     const int ntile = Mp / TILE, nchunk = Mp / KC;
 
-    const T* Arow = a.A + (n0 + srow) * (int64_t)Mp + skh * 8;
-    T* const lds_wr = &lds[0][0][srow * RS + skh * 8];
+    const T* Arow = a.A + (n0 + srow) * (int64_t)Mp + skh * H;
+    T* const lds_wr = &lds[0][0][srow * RS + skh * H];
     constexpr int BUF_STRIDE = 2 * TILE * RS, OP_STRIDE = TILE * RS;
     double ve_acc = 0.0;
     int nonpos = 0;
@@ -516,14 +531,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void panel_kernel(PanelArgs<T> a) {
             T* gs = &lds[0][0][0];
             for (int j = t; j < Mp; j += NTHREADS) gs[j] = a.gamma[(size_t)j * a.P + p];
             __syncthreads();
-            const T* gk = gs + skh * 8;
+            const T* gk = gs + skh * H;
 #ifndef TSVGP_EXP_NOGEMV  // ablation switch (tools/exp_moments.py)
 #pragma unroll 4
             for (int c = 0; c < nchunk; ++c) {
-                T ra[8];
-                load8(ra, Arow + c * KC);
+                T ra[H];
+                load_run<T, H>(ra, Arow + c * KC);
 #pragma unroll
-                for (int q = 0; q < 8; ++q) mpart += ra[q] * gk[c * KC + q];
+                for (int q = 0; q < H; ++q) mpart += ra[q] * gk[c * KC + q];
             }
 #endif
             __syncthreads();
@@ -531,7 +546,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void panel_kernel(PanelArgs<T> a) {
 
         auto tile_body = [&](const int it, auto first_tag) {
             constexpr bool FIRST = decltype(first_tag)::value;  // FUSE: the tile that also accumulates the mean
-            const T* Trow = Tp + (size_t)(it * TILE + srow) * Mp + skh * 8;
+            const T* Trow = Tp + (size_t)(it * TILE + srow) * Mp + skh * H;
 
             acc_t acc[2][8];
 #pragma unroll
@@ -539,38 +554,39 @@ __global__ __launch_bounds__(NTHREADS, 2) void panel_kernel(PanelArgs<T> a) {
 #pragma unroll
                 for (int n = 0; n < 8; ++n) acc[s][n] = acc_t{0, 0, 0, 0};
 
-            T ra[8], rb[8];
+            T ra[H], rb[H];
             int buf = 0;
             // one pipeline step: prefetch chunk `cnext` to registers, MFMAs on the chunk in LDS buffer `buf`, then stage
             // the prefetched chunk into the other buffer; one barrier per chunk.
 #define TSVGP_FETCH(cnext)                    \
     {                                         \
-        load8(ra, Arow + (cnext) * KC);       \
-        load8(rb, Trow + (cnext) * KC);       \
+        load_run<T, H>(ra, Arow + (cnext) * KC); \
+        load_run<T, H>(rb, Trow + (cnext) * KC); \
     }
 #define TSVGP_STAGE(cnext, b_)                                           \
     {                                                                    \
         if constexpr (FIRST) {                                           \
-            const T* gq = gsm + (cnext) * KC + skh * 8;                  \
-            _Pragma("unroll") for (int q = 0; q < 8; ++q) mpart += ra[q] * gq[q]; \
+            const T* gq = gsm + (cnext) * KC + skh * H;                  \
+            _Pragma("unroll") for (int q = 0; q < H; ++q) mpart += ra[q] * gq[q]; \
         }                                                                \
-        store_rowk8(lds_wr + (b_) * BUF_STRIDE, ra);                     \
-        store_rowk8(lds_wr + (b_) * BUF_STRIDE + OP_STRIDE, rb);         \
+        store_run<T, H>(lds_wr + (b_) * BUF_STRIDE, ra);                 \
+        store_run<T, H>(lds_wr + (b_) * BUF_STRIDE + OP_STRIDE, rb);     \
     }
 #ifdef TSVGP_EXP_NOLOAD
 #define TSVGP_EXP_HASNEXT(x) false
 #else
 #define TSVGP_EXP_HASNEXT(x) (x)
 #endif
-#define TSVGP_STEP(NMASK, cnext, has_next_)                                                     \
+#define TSVGP_STEP2(MLO, MHI, cnext, has_next_)                                                 \
     {                                                                                           \
         const bool has_next = TSVGP_EXP_HASNEXT(has_next_);                                     \
         if (has_next) TSVGP_FETCH(cnext)                                                        \
-        mma_chunk_rowk<T, NMASK>(acc, &lds[buf][0][0], &lds[buf][1][0], w, lane);               \
+        mma_chunk_rowk<T, MLO, MHI>(acc, &lds[buf][0][0], &lds[buf][1][0], w, lane);            \
         if (has_next) TSVGP_STAGE(cnext, buf ^ 1)                                               \
         __syncthreads();                                                                        \
         buf ^= 1;                                                                               \
     }
+#define TSVGP_STEP(NMASK, cnext, has_next_) TSVGP_STEP2(NMASK, NMASK, cnext, has_next_)
             const int c_first = (TRI == TSVGP_TRI_UPPER) ? it * CPT : 0;
             TSVGP_FETCH(c_first)
             TSVGP_STAGE(c_first, 0)
@@ -582,29 +598,44 @@ __global__ __launch_bounds__(NTHREADS, 2) void panel_kernel(PanelArgs<T> a) {
                 // full k-tiles 0..it-1, then the diagonal k-tile: chunk cl only meets column blocks cb >= cl
                 const int cd = it * CPT;
                 for (int c = 0; c < cd; ++c) TSVGP_STEP(0xFF, c + 1, true)
-                TSVGP_STEP(0xFF, cd + 1, true)
-                TSVGP_STEP(0xFE, cd + 2, true)
-                TSVGP_STEP(0xFC, cd + 3, true)
-                TSVGP_STEP(0xF8, cd + 4, true)
-                TSVGP_STEP(0xF0, cd + 5, true)
-                TSVGP_STEP(0xE0, cd + 6, true)
-                TSVGP_STEP(0xC0, cd + 7, true)
-                TSVGP_STEP(0x80, cd + 8, false)
+                if constexpr (KC == 16) {
+                    TSVGP_STEP(0xFF, cd + 1, true)
+                    TSVGP_STEP(0xFE, cd + 2, true)
+                    TSVGP_STEP(0xFC, cd + 3, true)
+                    TSVGP_STEP(0xF8, cd + 4, true)
+                    TSVGP_STEP(0xF0, cd + 5, true)
+                    TSVGP_STEP(0xE0, cd + 6, true)
+                    TSVGP_STEP(0xC0, cd + 7, true)
+                    TSVGP_STEP(0x80, cd + 8, false)
+                } else {  // 32-wide chunks: two 16-wide k-blocks per chunk
+                    TSVGP_STEP2(0xFF, 0xFE, cd + 1, true)
+                    TSVGP_STEP2(0xFC, 0xF8, cd + 2, true)
+                    TSVGP_STEP2(0xF0, 0xE0, cd + 3, true)
+                    TSVGP_STEP2(0xC0, 0x80, cd + 4, false)
+                }
             } else {
                 // the diagonal k-tile first: chunk cl only meets column blocks cb <= cl; then full k-tiles it+1..
                 const int cd = it * CPT;
                 const bool more = (it + 1 < ntile);
-                TSVGP_STEP(0x01, cd + 1, true)
-                TSVGP_STEP(0x03, cd + 2, true)
-                TSVGP_STEP(0x07, cd + 3, true)
-                TSVGP_STEP(0x0F, cd + 4, true)
-                TSVGP_STEP(0x1F, cd + 5, true)
-                TSVGP_STEP(0x3F, cd + 6, true)
-                TSVGP_STEP(0x7F, cd + 7, true)
-                TSVGP_STEP(0xFF, cd + 8, more)
+                if constexpr (KC == 16) {
+                    TSVGP_STEP(0x01, cd + 1, true)
+                    TSVGP_STEP(0x03, cd + 2, true)
+                    TSVGP_STEP(0x07, cd + 3, true)
+                    TSVGP_STEP(0x0F, cd + 4, true)
+                    TSVGP_STEP(0x1F, cd + 5, true)
+                    TSVGP_STEP(0x3F, cd + 6, true)
+                    TSVGP_STEP(0x7F, cd + 7, true)
+                    TSVGP_STEP(0xFF, cd + 8, more)
+                } else {
+                    TSVGP_STEP2(0x01, 0x03, cd + 1, true)
+                    TSVGP_STEP2(0x07, 0x0F, cd + 2, true)
+                    TSVGP_STEP2(0x1F, 0x3F, cd + 3, true)
+                    TSVGP_STEP2(0x7F, 0xFF, cd + 4, more)
+                }
                 for (int c = cd + CPT; c < nchunk; ++c) TSVGP_STEP(0xFF, c + 1, (c + 1 < nchunk))
             }
 #undef TSVGP_STEP
+#undef TSVGP_STEP2
 #undef TSVGP_STAGE
 #undef TSVGP_FETCH
 
@@ -657,24 +688,40 @@ __global__ __launch_bounds__(NTHREADS, 2) void panel_kernel(PanelArgs<T> a) {
             }
             mpart += __shfl_xor(mpart, 1);
             __syncthreads();
-            if (skh == 0) {
+            {
                 const int64_t n = n0 + srow;
+                const bool live = n < a.N;
                 const double q = rowq[srow];
                 const double mu = (double)mpart;
                 const double v = a.kdiag - q;
                 double g0 = 0.0, g1 = 0.0, ve = 0.0;
-                if (n < a.N) {
-                    if (!(v > 0.0)) nonpos += 1;
-                    if (a.mean) a.mean[n * a.P + p] = (T)mu;
-                    if (a.var) a.var[n * a.P + p] = (T)v;
-                    if (a.lik != TSVGP_LIK_NONE) {
-                        lik_eval(a.lik, a.lik_param, mu, v, (double)a.Y[n * a.P + p], g0, g1, ve);
+                if ((a.lik & 0xFF) == TSVGP_LIK_BERNOULLI) {
+                    // the quadrature is the long pole of this epilogue (20 erf / exp / log in fp64 per row): the two
+                    // threads that staged a row take five node pairs each and add up
+                    double a0, a1, av;
+                    const double sd = sqrt(live ? v : 1.0);
+                    bern_sums(live ? mu : 0.0, sd, live && (double)a.Y[n * a.P + p] == 1.0, skh * 5, skh * 5 + 5, a0, a1, av);
+                    a0 += __shfl_xor(a0, 1);
+                    a1 += __shfl_xor(a1, 1);
+                    av += __shfl_xor(av, 1);
+                    g0 = a0;
+                    g1 = a1 / (2.0 * sd);
+                    if (!(a.lik & TSVGP_LIK_NOCROP)) g1 = fmin(g1, -1e-8);  // reference tsvgp.py:262-263
+                    ve = av;
+                } else if (a.lik != TSVGP_LIK_NONE && live) {
+                    lik_eval(a.lik, a.lik_param, mu, v, (double)a.Y[n * a.P + p], g0, g1, ve);
+                }
+                if (skh == 0) {
+                    if (live) {
+                        if (!(v > 0.0)) nonpos += 1;
+                        if (a.mean) a.mean[n * a.P + p] = (T)mu;
+                        if (a.var) a.var[n * a.P + p] = (T)v;
                         ve_acc += ve;
                     }
-                }
-                if (a.lik != TSVGP_LIK_NONE) {
-                    a.g0[n * a.P + p] = (T)g0;  // rows >= N: zeros (the padding contract of site_accum)
-                    a.g1[n * a.P + p] = (T)g1;
+                    if (a.lik != TSVGP_LIK_NONE) {
+                        a.g0[n * a.P + p] = (T)(live ? g0 : 0.0);  // rows >= N: zeros (the padding contract of site_accum)
+                        a.g1[n * a.P + p] = (T)(live ? g1 : 0.0);
+                    }
                 }
             }
             __syncthreads();  // rowq reused by the next latent
