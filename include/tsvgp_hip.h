@@ -43,7 +43,7 @@ extern "C" {
                                     Gaussian likelihood g0 = (y - mean)/s2 and g1 = -1/(2 s2) do not depend on the
                                     predictive variance, so the natural-gradient step (src/models/tsvgp.py:246-263)
                                     needs the mean alone: one HBM-bound sweep of A instead of the MFMA product.
-                                    Tm and mode are ignored, var must be NULL, ve_partial is written as NaN (the
+                                    Tm and mode are ignored, var must be NULL, Mp*P*sizeof(T) <= 128 KB (gamma sits in LDS), ve_partial is written as NaN (the
                                     variational expectation itself does need the variance), nonpos_partial counts rows with a
                                     non-finite mean or gradient. */
 

@@ -1679,7 +1679,17 @@ int moments(const T* A, const T* Tm, const T* gamma, const T* Y, double kdiag, i
     const int lik_base = lik & 0xFF;
     if (lik_base != TSVGP_LIK_NONE && lik_base != TSVGP_LIK_GAUSSIAN && lik_base != TSVGP_LIK_BERNOULLI) return TSVGP_EINVAL;
     // mean only: the Bernoulli gradients do depend on the variance; gamma [P][Mp] has to fit the LDS
-    if (mean_only && (lik_base == TSVGP_LIK_BERNOULLI || var || (size_t)Mp * P * sizeof(T) > 65536)) return TSVGP_EINVAL;
+    constexpr size_t MEAN_LDS_MAX = 128 * 1024;
+    if (mean_only && (lik_base == TSVGP_LIK_BERNOULLI || var || (size_t)Mp * P * sizeof(T) > MEAN_LDS_MAX)) return TSVGP_EINVAL;
+    if (mean_only) {  // more than the default 64 KB of dynamic LDS has to be asked for (once per type)
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mean_lik_kernel<T>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)MEAN_LDS_MAX) != hipSuccess)
+                return TSVGP_ELAUNCH;
+            attr_set = true;
+        }
+    }
     lik &= ~TSVGP_LIK_MEANONLY;
     if (lik_base == TSVGP_LIK_NONE) lik = TSVGP_LIK_NONE;
     if (lik != TSVGP_LIK_NONE && (!Y || !g0 || !g1)) return TSVGP_EINVAL;

@@ -127,7 +127,7 @@ def test_moments_and_likelihood_map(engines, dtype, tol, lik, N, M, P, mode):
 
 @pytest.mark.parametrize("dtype,tol", DTYPES)
 @pytest.mark.parametrize("lik", ["none", "gaussian"])
-@pytest.mark.parametrize("N,M,P", [(100, 128, 1), (300, 256, 2), (129, 384, 3), (1000, 1024, 1)])
+@pytest.mark.parametrize("N,M,P", [(100, 128, 1), (300, 256, 2), (129, 384, 3), (1000, 1024, 1), (150, 1152, 8)])
 def test_moments_mean_only(engines, dtype, tol, lik, N, M, P):
     """TSVGP_LIK_MEANONLY: mean and the Gaussian gradient map without the variance product; Tm is not read."""
     eng = engines[dtype]
