@@ -45,7 +45,7 @@ reference is **unpinned beyond those checks**.
 
 Also restated here, with the same status: ``t_SVGP_white``
 (``src/models/tsvgp_white.py``; pinned by ``tests/models/test_tsvgp_white.py:64-115``
-and the SGPR equality of ``tests/models/test_condit.py:69-83``, closed forms),
+and the SGPR equality and extra-data conditioning of ``tests/models/test_condit.py:69-104``, closed forms),
 the multi-output layout ``SeparateIndependent`` +
 ``SharedIndependentInducingVariables`` (GPflow's
 ``separate_independent_conditional`` and batched ``gauss_kl`` [ext]; pinned by
@@ -719,6 +719,21 @@ class t_SVGP_white:
         if not np.all(var > 0):  # :131
             raise FloatingPointError("predict_f: non-positive predictive variance")
         return mu, var
+
+    def predict_f_extra_data(self, Xnew, extra_data, jitter=DEFAULT_JITTER):
+        """:134-160.  Prediction at Xnew conditioned on ``extra_data`` as well: the sites get the natural-gradient
+        contribution of the extra points (one full step, no learning rate) without the state being touched."""
+        Xe, Ye = extra_data
+        grad_mu = self.compute_data_natural_params((np.asarray(Xe, dtype=np.float64), np.asarray(Ye, dtype=np.float64)))  # :141
+        lambda_1 = self.lambda_1  # :143
+        lambda_2 = -0.5 * self.lambda_2  # :144
+        K_uu = Kuu(self.inducing_variable, self.kernel, jitter=jitter)  # :146
+        lambda_1c = lambda_1 + K_uu @ grad_mu[0]  # :148
+        lambda_2c = -2 * (lambda_2 + K_uu @ grad_mu[1] @ K_uu)  # :149
+        K_uf = Kuf(self.inducing_variable, self.kernel, Xnew)  # :152
+        K_ff = self.kernel.K_diag(Xnew)[..., None]
+        mu, var = conditional_from_precision_sites_white(K_uu, K_ff, K_uf, lambda_1c, L2=lambda_2c)  # :155-156
+        return mu, var  # no assert_positive on this path
 
     def elbo(self, data):
         """:162-177."""

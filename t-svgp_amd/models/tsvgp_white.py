@@ -78,9 +78,11 @@ class t_SVGP_white(base_SVGP):
             return a.to(self.device)
         return torch.as_tensor(np.asarray(a)).to(self.device)
 
-    def _operands(self, jitter=None):
+    def _operands(self, jitter=None, *, kuu_jitter=None, lambda_1=None, lambda_2=None):
         """Everything the N-pass needs (see the table in the module docstring); with ``jitter`` also K9^-1 for the
-        site update.  No host synchronisation: factorisation statuses go to ops["infos"]."""
+        site update.  No host synchronisation: factorisation statuses go to ops["infos"].
+        ``kuu_jitter`` (default: gpflow's default_jitter, as predict_f) is the jitter of the K_uu the conditional is built
+        on; ``lambda_1`` / ``lambda_2`` replace the state (predict_f_extra_data)."""
         eng = self._get_engine()
         Z = self._Z()
         M = Z.shape[0]
@@ -88,8 +90,9 @@ class t_SVGP_white(base_SVGP):
         potrf = getattr(eng, "cholesky", None)
         Kzz = eng.kuu(Z, self.kernel)
         Id = torch.eye(M, dtype=torch.float64, device=Kzz.device)
-        K6 = Kzz + default_jitter() * Id
-        l1, L2 = self.lambda_1.value, self.lambda_2.value
+        K6 = Kzz + (default_jitter() if kuu_jitter is None else kuu_jitter) * Id
+        l1 = self.lambda_1.value if lambda_1 is None else lambda_1
+        L2 = self.lambda_2.value if lambda_2 is None else lambda_2
         E = 0.5 * (L2 + L2.transpose(-1, -2)) + 1e-9 * Id  # util.py:76 (jitter argument default)
         mats = [K6[None], E] + ([(Kzz + jitter * Id)[None]] if jitter is not None else [])
         U, Uinv = rev_cholesky(torch.cat(mats, dim=0), infos, potrf, inverse=True)
@@ -173,9 +176,12 @@ class t_SVGP_white(base_SVGP):
         scale = (float(self.num_data) / rows) if self.num_data is not None else 1.0
         return ve_sum * scale - kl
 
-    def natgrad_step(self, dataset, lr=0.1, jitter=1e-9):
-        """One natural-gradient step on (lambda_1, Lambda_2) (tsvgp_white.py:183-248); returns None."""
-        X, Y = self._as_device(dataset[0]), self._as_device(dataset[1])
+    def _kuu_grad_mu(self, X, Y, jitter=1e-9, kuu_jitter=0.0):
+        """compute_data_natural_params (tsvgp_white.py:183-212) with K_uu + kuu_jitter I already applied, which is how both
+        callers use it: returns (K grad_mu[0] [M, 1], K grad_mu[1] K [1, M, M], rows, nonpos, ops).
+        With s1 = sum g0 k, S2 = sum g1 k k^T and K9 = K_uu + jitter I:  grad_mu[0] = K9^-1 (s1 - 2 S2 K9^-1 meanZ),
+        grad_mu[1] = K9^-1 S2 K9^-1, so K grad_mu = (I - (jitter - kuu_jitter) K9^-1)(...): no product with an
+        ill-conditioned inverse is ever formed."""
         ops = self._operands(jitter=jitter)
         # tsvgp_white.py:188-191: no crop of d ve / d var in this class
         st = self._run(X, Y, ops, self.likelihood.lik_id | B.LIK_NOCROP, sites=True)
@@ -183,14 +189,20 @@ class t_SVGP_white(base_SVGP):
         if self._reduce():
             D_.all_reduce_sum(packed)
         acc2, acc1, _, nonpos, rows = D_.unpack_stats(packed, self.num_latent_gps, self.num_inducing, True)
-        U6, Uinv6, Kzz, K9inv, Id = ops["U6"], ops["Uinv6"], ops["Kzz"], ops["K9inv"], ops["Id"]
+        U6, Uinv6, K9inv, Id = ops["U6"], ops["Uinv6"], ops["K9inv"], ops["Id"]
         S2 = U6 @ acc2 @ U6.transpose(-1, -2)  # sum g1 k k^T   [1, M, M]
         s1 = U6 @ acc1.transpose(-1, -2)  # sum g0 k     [M, 1]
-        Mj = Id - jitter * K9inv  # Kuu K9^-1
+        Mj = Id - (jitter - kuu_jitter) * K9inv  # (Kuu + kuu_jitter I) K9^-1
         gamma_k = Uinv6.transpose(-1, -2) @ ops["gamma"]  # R^-1 lambda_1
-        a_meanZ = Mj @ gamma_k  # K9^-1 meanZ, meanZ = Kuu R^-1 lambda_1 (predict_f at Z, :186)
-        KG1K = Mj @ S2 @ Mj.transpose(-1, -2)  # Kuu G1 Kuu
-        Kg0 = Mj @ s1 - 2.0 * (Mj @ (S2[0] @ a_meanZ))  # Kuu (G0 - 2 G1 meanZ), util.py:429-438
+        a_meanZ = (Id - jitter * K9inv) @ gamma_k  # K9^-1 meanZ, meanZ = Kuu R^-1 lambda_1 (predict_f at Z, :186)
+        KG1K = Mj @ S2 @ Mj.transpose(-1, -2)  # K G1 K
+        Kg0 = Mj @ s1 - 2.0 * (Mj @ (S2[0] @ a_meanZ))  # K (G0 - 2 G1 meanZ), util.py:429-438
+        return Kg0, KG1K, rows, nonpos, ops
+
+    def natgrad_step(self, dataset, lr=0.1, jitter=1e-9):
+        """One natural-gradient step on (lambda_1, Lambda_2) (tsvgp_white.py:183-248); returns None."""
+        X, Y = self._as_device(dataset[0]), self._as_device(dataset[1])
+        Kg0, KG1K, rows, nonpos, ops = self._kuu_grad_mu(X, Y, jitter=jitter, kuu_jitter=0.0)  # :231: Kuu without jitter
         scale = (float(self.num_data) / rows) if self.num_data is not None else 1.0
         lambda_1 = (1.0 - lr) * self.lambda_1.value + lr * scale * Kg0  # :244
         lambda_2 = (1.0 - lr) * self.lambda_2.value - 2.0 * lr * scale * KG1K  # :241-248 (Lambda_2 = -2 lambda_2)
@@ -203,3 +215,21 @@ class t_SVGP_white(base_SVGP):
             self.lambda_1.assign(old_l1)  # the reference raises before its assigns: leave the state untouched
             self.sites.assign_lambda_2(old_L2)
             raise
+
+    def predict_f_extra_data(self, Xnew, extra_data, jitter=None):
+        """Prediction at Xnew conditioned on ``extra_data`` as well (tsvgp_white.py:134-160): the sites receive the
+        extra points' natural-gradient contribution (a full step, no learning rate, no minibatch scale) for this call
+        only; the state is not touched.  ``jitter`` (default: gpflow's default_jitter) is the jitter of the K_uu the
+        contribution is mapped with and the conditional is built on (:146); the projection inside
+        compute_data_natural_params keeps its own 1e-9 (:183).  With more than one rank ``extra_data`` is this rank's
+        shard of the extra points."""
+        jitter = default_jitter() if jitter is None else float(jitter)
+        Xe, Ye = self._as_device(extra_data[0]), self._as_device(extra_data[1])
+        Kg0, KG1K, _, nonpos, ops = self._kuu_grad_mu(Xe, Ye, jitter=1e-9, kuu_jitter=jitter)  # :141
+        self._check(ops, nonpos)  # predict_f(X) inside compute_data_natural_params asserts positivity (:131)
+        lambda_1c = self.lambda_1.value + Kg0  # :148
+        lambda_2c = self.lambda_2.value - 2.0 * KG1K  # :149
+        ops_c = self._operands(kuu_jitter=jitter, lambda_1=lambda_1c, lambda_2=0.5 * (lambda_2c + lambda_2c.transpose(-1, -2)))
+        st = self._run(self._as_device(Xnew), None, ops_c, B.LIK_NONE, want_moments=True)
+        self._check(ops_c, torch.zeros(1, dtype=torch.float64, device=self.device))  # no assert_positive on this path (:155-158)
+        return st.mean, st.var

@@ -102,3 +102,34 @@ def test_white_api_and_errors():
     with pytest.raises(ValueError):
         m.natgrad_step((X, Y[:, :0]), lr=0.5)  # Y must be [N, 1]
     assert np.array_equal(m.lambda_1.numpy(), l1) and np.array_equal(m.lambda_2.numpy(), L2)
+
+
+@pytest.mark.parametrize("lik", ["gaussian", "bernoulli"])
+def test_white_predict_f_extra_data(lik):
+    """predict_f_extra_data (tsvgp_white.py:134-160) on the HIP path: against the oracle, and the reference's own
+    relation (tests/models/test_condit.py:84-104: stepping on data + extra == conditioning on extra, Gaussian, lr=1)."""
+    p = pkg()
+    rng = np.random.RandomState(41)
+    X, Y, _ = synthetic(N=700, M=40, D=3, P=1, lik=lik, seed=6)
+    Xe, Ye, _ = synthetic(N=450, M=40, D=3, P=1, lik=lik, seed=7)
+    Z = rng.randn(40, 3) * 1.3
+    mk = lambda mod: mod.t_SVGP_white(mod.SquaredExponential(1.1, 1.0), mod.Gaussian(0.2) if lik == "gaussian" else mod.Bernoulli(), Z)
+    hip, ora = mk(p), mk(O)
+    for _ in range(3):
+        hip.natgrad_step((X, Y), lr=0.8)
+        ora.natgrad_step((X, Y), lr=0.8)
+    l1, L2 = hip.lambda_1.numpy().copy(), hip.lambda_2.numpy().copy()
+    Xs = X[:200] + 0.05
+    for kw in ({}, dict(jitter=1e-5)):
+        mh, vh = hip.predict_f_extra_data(Xs, (Xe, Ye), **kw)
+        mo, vo = ora.predict_f_extra_data(Xs, (Xe, Ye), **kw)
+        assert relerr(mh.cpu().numpy(), mo) < 1e-8 and relerr(vh.cpu().numpy(), vo) < 1e-8
+    assert np.array_equal(hip.lambda_1.numpy(), l1) and np.array_equal(hip.lambda_2.numpy(), L2)
+    if lik == "gaussian":
+        one, both = mk(p), mk(p)
+        one.natgrad_step((X, Y), lr=1.0)
+        both.natgrad_step((np.vstack([X, Xe]), np.vstack([Y, Ye])), lr=1.0)
+        m1, v1 = both.predict_f(Xs)
+        m2, v2 = one.predict_f_extra_data(Xs, extra_data=(Xe, Ye))
+        np.testing.assert_array_almost_equal(m1.cpu().numpy(), m2.cpu().numpy(), decimal=4)
+        np.testing.assert_array_almost_equal(v1.cpu().numpy(), v2.cpu().numpy(), decimal=4)

@@ -81,6 +81,24 @@ def test_skip_unused_variance_host_logic():
     assert seen_b == [False] and relerr(hb.lambda_1.numpy(), ob.lambda_1) < 1e-9
 
 
+def test_white_predict_f_extra_data_host_logic():
+    """t_SVGP_white.predict_f_extra_data (tsvgp_white.py:134-160): the M x M algebra of the conditioned sites against
+    the oracle with the NumPy N-pass plugged in, Gaussian and Bernoulli, both jitter settings of the reference's test."""
+    for lik in ("gaussian", "bernoulli"):
+        X, Y, Z = synthetic(N=200, M=16, D=2, P=1, lik=lik, seed=3)
+        Xe, Ye, _ = synthetic(N=120, M=16, D=2, P=1, lik=lik, seed=4)
+        hip, ora = _pair(Z, lik, 1, kind="white")
+        for _ in range(2):
+            hip.natgrad_step((X, Y), lr=0.8)
+            ora.natgrad_step((X, Y), lr=0.8)
+        l1 = hip.lambda_1.numpy().copy()
+        for kw in ({}, dict(jitter=1e-4)):
+            mh, vh = hip.predict_f_extra_data(X[:50] + 0.1, (Xe, Ye), **kw)
+            mo, vo = ora.predict_f_extra_data(X[:50] + 0.1, (Xe, Ye), **kw)
+            assert relerr(mh.numpy(), mo) < 1e-8 and relerr(vh.numpy(), vo) < 1e-8
+        assert np.array_equal(hip.lambda_1.numpy(), l1)
+
+
 def test_util_functions_match_oracle():
     p = pkg()
     rng = np.random.RandomState(0)

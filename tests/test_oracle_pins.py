@@ -361,3 +361,30 @@ def test_white_model_pins():
         m2, v2 = O.sgpr_predict_f(k1, Xs, Ys, Zs, 0.3, Ys)
         np.testing.assert_array_almost_equal(m1, m2, decimal=6)
         np.testing.assert_array_almost_equal(v1, v2, decimal=6)
+
+
+def test_white_extra_data_conditioning_pin():
+    """Reference tests/models/test_condit.py:84-104 on the oracle: a model stepped (lr=1) on data + extra data predicts
+    what a model stepped on the data alone predicts through predict_f_extra_data(extra) (decimal=4 there), with the
+    call's jitter=0.0 as in the test and with its default; and an independent closed form: for a Gaussian likelihood
+    both equal Titsias' collapsed SGPR posterior on the concatenated data."""
+    k1 = O.SquaredExponential(1.0, 1.0)
+    for seed in range(4):
+        rs = np.random.RandomState(seed)
+        X, Y, Z = rs.randn(10, 1), rs.randn(10, 1), rs.randn(3, 1)
+        Xe, Ye = rs.randn(10, 1), rs.randn(10, 1)
+        Xc, Yc = np.vstack([X, Xe]), np.vstack([Y, Ye])
+        both, one = O.t_SVGP_white(k1, O.Gaussian(0.3), Z.copy()), O.t_SVGP_white(k1, O.Gaussian(0.3), Z.copy())
+        both.natgrad_step((Xc, Yc), lr=1.0)
+        one.natgrad_step((X, Y), lr=1.0)
+        l1, L2 = one.lambda_1.copy(), one.lambda_2.copy()
+        m, v = both.predict_f(X)
+        for jit in (0.0, None):
+            kw = {} if jit is None else dict(jitter=jit)
+            m_, v_ = one.predict_f_extra_data(X, extra_data=(Xe, Ye), **kw)
+            np.testing.assert_array_almost_equal(m, m_, decimal=4)
+            np.testing.assert_array_almost_equal(v, v_, decimal=4)
+        assert np.array_equal(one.lambda_1, l1) and np.array_equal(one.lambda_2, L2)  # the state is not touched
+        m2, v2 = O.sgpr_predict_f(k1, Xc, Yc, Z, 0.3, X)
+        np.testing.assert_array_almost_equal(m_, m2, decimal=4)
+        np.testing.assert_array_almost_equal(v_, v2, decimal=4)
