@@ -34,6 +34,7 @@ import torch
 from .. import _backend as B
 from .. import distributed as D_
 from ..base import default_device, default_float, default_jitter, to_tensor
+from ..estep import EStepStats
 from ..inducing_variables import inducingpoint_wrapper
 from ..kernels import SeparateIndependent, latent_kernels
 from ..sites import DenseSites
@@ -428,71 +429,98 @@ class t_SVGP(base_SVGP):
         A2 = sum g1 k k^T, U = K_fu Q, and ``tsvgp_kernel_grad``) and an M x M part in which a1, A2 are constants
         (torch autograd over K_uu(theta, Z), its factorisations and the KL).
         Returns (elbo, {"variance", "lengthscales", "Z", "likelihood_variance" (Gaussian only)}), gradients of the ELBO
-        with respect to the constrained parameter values.  With more than one rank ``data`` is this rank's shard."""
-        if isinstance(self.kernel, SeparateIndependent):
-            raise NotImplementedError("elbo_and_grads covers one shared kernel")
+        with respect to the constrained parameter values; with one kernel per latent (``SeparateIndependent``) the kernel
+        entries are named "kernels.<p>.variance" / "kernels.<p>.lengthscales".  With more than one rank ``data`` is this
+        rank's shard."""
+        sep = isinstance(self.kernel, SeparateIndependent)
         X, Y = self._as_device(data[0]), self._as_device(data[1])
         eng, P, M = self._get_engine(), self.num_latent_gps, self.num_inducing
+        Dn = X.shape[1]
         ops = self._site_operands()
         Dm, beta = ops["D"], ops["beta"]
         gaussian = self.likelihood.lik_id == B.LIK_GAUSSIAN
-        # the TRUE d ve / d var here: the crop of tsvgp.py:262-263 belongs to the site update, not to the ELBO (with the
-        # 1e-3 jitter of the probit link log p is not log-concave in the far tails, so some g1 are positive)
-        st = eng.run(X, Y, ops["Z"], self.kernel, moment_Tm=Dm, moment_mode=ops["moment_mode"], gamma=beta,
-                     lik_id=self.likelihood.lik_id | B.LIK_NOCROP, lik_param=self.likelihood.lik_param, sites=True,
-                     want_moments=gaussian)
-        Kfu, g0, g1 = eng._buf["Kfu"], eng._buf["g0"], eng._buf["g1"]  # [Np, Mp], [Np, P] (rows >= N are zero)
+        kernels = list(self.kernel.kernels) if sep else [self.kernel]
+        nk = len(kernels)
         Q = Dm.transpose(-1, -2) @ Dm  # [P, M, M]
-        Ubuf = eng._get("U", tuple(Kfu.shape), Kfu.dtype)
-        dvar = torch.zeros((), dtype=torch.float64, device=self.device)
-        dls = torch.zeros(X.shape[1], dtype=torch.float64, device=self.device)
-        dZ = torch.zeros((M, X.shape[1]), dtype=torch.float64, device=self.device)
-        for p in range(P):
-            eng.trmm(Kfu, eng._pad_square(0.5 * (Q[p] + Q[p].T), Kfu.shape[1], "pad_Q"), Ubuf, B.TRI_DENSE)  # U = K_fu Q_p
-            v, l, z = eng.kernel_grad(X, ops["Z"], self.kernel, Ubuf, g0[:, p], g1[:, p], beta[:, p])
-            dvar, dls, dZ = dvar + v, dls + l, dZ + z
-        extra = [dvar.reshape(1), dls, dZ.reshape(-1), g1.sum(dim=0, dtype=torch.float64).sum().reshape(1)]
-        if gaussian:  # d ve / d s2 = -1/(2 s2) + ((y - m)^2 + v) / (2 s2^2), summed
-            res = torch.sum((Y.to(st.mean.dtype) - st.mean) ** 2 + st.var)
-            extra.append(res.reshape(1))
+        dvar = torch.zeros(nk, dtype=torch.float64, device=self.device)
+        dls = torch.zeros((nk, Dn), dtype=torch.float64, device=self.device)
+        dZ = torch.zeros((M, Dn), dtype=torch.float64, device=self.device)
+        sum_g1 = torch.zeros(nk, dtype=torch.float64, device=self.device)
+        res = torch.zeros((), dtype=torch.float64, device=self.device)
+        # One N-pass per kernel: a shared kernel serves all P latents from one K(X, Z); separate kernels take their
+        # latent alone, through the same buffers (as EStepEngine._run_separate).
+        # The TRUE d ve / d var here: the crop of tsvgp.py:262-263 belongs to the site update, not to the ELBO (with the
+        # 1e-3 jitter of the probit link log p is not log-concave in the far tails, so some g1 are positive)
+        parts = []
+        for ki, kern in enumerate(kernels):
+            lat = [ki] if sep else list(range(P))
+            sl = slice(lat[0], lat[-1] + 1)
+            st = eng.run(X, Y[:, sl], ops["Z"], kern, moment_Tm=Dm[sl], moment_mode=ops["moment_mode"], gamma=beta[:, sl],
+                         lik_id=self.likelihood.lik_id | B.LIK_NOCROP, lik_param=self.likelihood.lik_param, sites=True,
+                         want_moments=gaussian)
+            parts.append(st)
+            Kfu, g0, g1 = eng._buf["Kfu"], eng._buf["g0"], eng._buf["g1"]  # [Np, Mp], [Np, len(lat)] (rows >= N are zero)
+            Ubuf = eng._get("U", tuple(Kfu.shape), Kfu.dtype)
+            for c, p_ in enumerate(lat):
+                eng.trmm(Kfu, eng._pad_square(0.5 * (Q[p_] + Q[p_].T), Kfu.shape[1], "pad_Q"), Ubuf, B.TRI_DENSE)  # U = K_fu Q_p
+                v, l, z = eng.kernel_grad(X, ops["Z"], kern, Ubuf, g0[:, c], g1[:, c], beta[:, p_])
+                dvar[ki] += v
+                dls[ki] += l
+                dZ += z
+            sum_g1[ki] = g1.sum(dtype=torch.float64)
+            if gaussian:  # d ve / d s2 = -1/(2 s2) + ((y - m)^2 + v) / (2 s2^2), summed
+                res = res + torch.sum((Y[:, sl].to(st.mean.dtype) - st.mean) ** 2 + st.var)
+        if sep:
+            st = EStepStats(n_rows=parts[0].n_rows, ve_sum=sum(s_.ve_sum for s_ in parts),
+                            nonpos=sum(s_.nonpos for s_ in parts))
+            st.acc2, st.acc1 = torch.cat([s_.acc2 for s_ in parts], dim=0), torch.cat([s_.acc1 for s_ in parts], dim=0)
+        extra = [dvar, dls.reshape(-1), dZ.reshape(-1), sum_g1, res.reshape(1)]
         packed = torch.cat([D_.pack_stats(st, with_sites=True)] + extra)
         if self._reduce():
             D_.all_reduce_sum(packed)
         base = P * M * M + P * M + 3
         acc2, acc1, ve_sum, nonpos, rows = D_.unpack_stats(packed[:base], P, M, True)
         tail = packed[base:]
-        Dn = X.shape[1]
-        dvar, dls, dZ, sum_g1 = tail[0], tail[1:1 + Dn], tail[1 + Dn:1 + Dn + M * Dn].reshape(M, Dn), tail[1 + Dn + M * Dn]
+        o = 0
+        dvar, o = tail[o:o + nk], o + nk
+        dls, o = tail[o:o + nk * Dn].reshape(nk, Dn), o + nk * Dn
+        dZ, o = tail[o:o + M * Dn].reshape(M, Dn), o + M * Dn
+        sum_g1, o = tail[o:o + nk], o + nk
+        res = tail[o]
         self._check_step(ops, nonpos)
         scale = (float(self.num_data) / rows) if self.num_data is not None else 1.0
 
         # M x M part by autograd: a1, A2, sum g1 are constants here
-        k = self.kernel
-        var_t = k.variance.value.detach().to(self.device).clone().requires_grad_(True)
-        ls_t = k.lengthscales.value.detach().to(self.device).clone().requires_grad_(True)
+        var_t = [k.variance.value.detach().to(self.device).clone().requires_grad_(True) for k in kernels]
+        ls_t = [k.lengthscales.value.detach().to(self.device).clone().requires_grad_(True) for k in kernels]
         Z_t = self._Z().detach().clone().requires_grad_(True)
         l1, L = self.lambda_1.value.detach(), self.lambda_2_sqrt.value.detach()
         Id = ops["Id"]
         with torch.enable_grad():
-            K6 = k.K_torch(Z_t, var_t, ls_t) + default_jitter() * Id
+            K6 = torch.stack([k.K_torch(Z_t, v_, l_) for k, v_, l_ in zip(kernels, var_t, ls_t)]) + default_jitter() * Id
+            K6 = K6.expand(P, M, M)  # one shared kernel: the same matrix for every latent
             W = Id + L.transpose(-1, -2) @ (K6 @ L)
             cW = torch.linalg.cholesky(0.5 * (W + W.transpose(-1, -2)))
             Dt = torch.linalg.solve_triangular(cW, L.transpose(-1, -2), upper=False)
             Qt = Dt.transpose(-1, -2) @ Dt
-            K6l = K6 @ l1
+            K6l = torch.einsum("pmk,kp->mp", K6, l1)
             beta_t = l1 - torch.einsum("pmk,kp->mp", Qt, K6l)
-            kl = 0.5 * (torch.sum((K6 @ beta_t) * beta_t) - torch.sum(Qt * K6)
+            kl = 0.5 * (torch.einsum("mp,pmk,kp->", beta_t, K6, beta_t) - torch.sum(Qt * K6)
                         + 2.0 * torch.sum(torch.log(torch.diagonal(cW, dim1=-2, dim2=-1))))
-            surrogate = scale * (torch.sum(beta_t * acc1.transpose(-1, -2)) - torch.sum(Qt * acc2) + var_t * sum_g1) - kl
-            g_var, g_ls, g_Z = torch.autograd.grad(surrogate, [var_t, ls_t, Z_t])
-        ls_shape = k.lengthscales.value.shape
-        n_ls = scale * dls
-        grads = {"variance": g_var + scale * dvar,
-                 "lengthscales": g_ls + (n_ls.sum() if len(ls_shape) == 0 else n_ls.reshape(ls_shape)),
-                 "Z": g_Z + scale * dZ}
+            knn = sum(v_ * s_ for v_, s_ in zip(var_t, sum_g1))  # sum_np g1 * k(x, x), k(x, x) = variance
+            surrogate = scale * (torch.sum(beta_t * acc1.transpose(-1, -2)) - torch.sum(Qt * acc2) + knn) - kl
+            g_all = torch.autograd.grad(surrogate, var_t + ls_t + [Z_t])
+        g_var, g_ls, g_Z = g_all[:nk], g_all[nk:2 * nk], g_all[-1]
+        grads = {"Z": g_Z + scale * dZ}
+        for ki, k in enumerate(kernels):
+            ls_shape = k.lengthscales.value.shape
+            n_ls = scale * dls[ki]
+            pre = f"kernels.{ki}." if sep else ""
+            grads[pre + "variance"] = g_var[ki] + scale * dvar[ki]
+            grads[pre + "lengthscales"] = g_ls[ki] + (n_ls.sum() if len(ls_shape) == 0 else n_ls.reshape(ls_shape))
         if gaussian:
             s2 = self.likelihood.lik_param
-            grads["likelihood_variance"] = scale * (-0.5 * rows * P / s2 + 0.5 * tail[-1] / (s2 * s2))
+            grads["likelihood_variance"] = scale * (-0.5 * rows * P / s2 + 0.5 * res / (s2 * s2))
         elbo = ve_sum * scale - kl.detach()
         return elbo, grads
 

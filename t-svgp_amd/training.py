@@ -38,9 +38,17 @@ class Adam:
 
 
 def trainable_parameters(model) -> dict:
-    """name -> (Parameter, positive?) for what the reference's M-step trains."""
-    out = {"variance": (model.kernel.variance, True), "lengthscales": (model.kernel.lengthscales, True),
-           "Z": (model.inducing_variable.Z, False)}
+    """name -> (Parameter, positive?) for what the reference's M-step trains; the names are those of
+    ``t_SVGP.elbo_and_grads`` ("kernels.<p>.variance" ... with one kernel per latent)."""
+    kern = model.kernel
+    if hasattr(kern, "kernels"):  # SeparateIndependent
+        out = {}
+        for p, k in enumerate(kern.kernels):
+            out[f"kernels.{p}.variance"] = (k.variance, True)
+            out[f"kernels.{p}.lengthscales"] = (k.lengthscales, True)
+    else:
+        out = {"variance": (kern.variance, True), "lengthscales": (kern.lengthscales, True)}
+    out["Z"] = (model.inducing_variable.Z, False)
     if hasattr(model.likelihood, "variance"):
         out["likelihood_variance"] = (model.likelihood.variance, True)
     return out

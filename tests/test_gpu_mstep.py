@@ -155,3 +155,64 @@ def test_em_loop_matches_oracle_driven_loop():
     assert abs(float(hip.likelihood.variance.value) - float(theta["likelihood_variance"])) < 1e-5
     assert np.max(np.abs(hip.inducing_variable.Z.numpy() - theta["Z"])) < 1e-5
     assert logf[1] > logf[0]
+
+
+@pytest.mark.parametrize("lik", ["gaussian", "bernoulli"])
+def test_elbo_gradients_separate_kernels(lik):
+    """One kernel per latent on shared inducing points (SeparateIndependent, docs/notebooks/heteroskedastic.py:62-76): the
+    gradient entries "kernels.<p>.variance" / "kernels.<p>.lengthscales", Z and the noise against central differences of
+    the oracle's ELBO; then one Adam M-step moves every kernel's parameters."""
+    p = pkg()
+    rng = np.random.RandomState(43)
+    N, M, D, P = 400, 20, 2, 3
+    X, Y, _ = synthetic(N=N, M=M, D=D, P=P, lik=lik, seed=8)
+    Z = rng.randn(M, D) * 1.2
+    names = ["SquaredExponential", "Matern52", "SquaredExponential"]
+    var0, ls0, noise = [1.3, 0.8, 1.1], [np.array([0.9, 1.4]), np.array([1.2, 1.2]), np.array([1.6, 0.7])], 0.2
+
+    def mk(mod, var=var0, ls=ls0, Zv=Z, nz=noise, **kw):
+        kern = mod.SeparateIndependent([getattr(mod, n)(v, l) for n, v, l in zip(names, var, ls)])
+        return mod.t_SVGP(kern, mod.Gaussian(nz) if lik == "gaussian" else mod.Bernoulli(),
+                          mod.SharedIndependentInducingVariables(Zv), num_latent_gps=P, num_data=N, **kw)
+
+    hip, ora = mk(p), mk(O)
+    for _ in range(3):
+        hip.natgrad_step((X, Y), lr=0.7)
+        ora.natgrad_step((X, Y), lr=0.7)
+    state = dict(lambda_1=ora.lambda_1.copy(), lambda_2_sqrt=ora.lambda_2_sqrt.copy())
+    f = lambda **kw: mk(O, **kw, **state).elbo((X, Y))
+    elbo, grads = hip.elbo_and_grads((X, Y))
+    assert abs(float(elbo) - f()) < 1e-9 * abs(f())
+    h = 1e-5
+    scale = 1.0
+    for k in range(P):
+        up, dn = list(var0), list(var0)
+        up[k], dn[k] = var0[k] + h, var0[k] - h
+        ref = (f(var=up) - f(var=dn)) / (2 * h)
+        scale = max(scale, abs(ref))
+        assert abs(float(grads[f"kernels.{k}.variance"]) - ref) < 2e-6 * max(abs(ref), scale), (k, ref)
+        g_ls = grads[f"kernels.{k}.lengthscales"].cpu().numpy()
+        for d in range(D):
+            up, dn = [l.copy() for l in ls0], [l.copy() for l in ls0]
+            up[k][d] += h
+            dn[k][d] -= h
+            ref = (f(ls=up) - f(ls=dn)) / (2 * h)
+            assert abs(g_ls[d] - ref) < 2e-6 * max(abs(ref), scale), (k, d, g_ls[d], ref)
+    g_Z = grads["Z"].cpu().numpy()
+    for (m_, d) in [(0, 0), (7, 1), (M - 1, 0)]:
+        up, dn = Z.copy(), Z.copy()
+        up[m_, d] += h
+        dn[m_, d] -= h
+        ref = (f(Zv=up) - f(Zv=dn)) / (2 * h)
+        assert abs(g_Z[m_, d] - ref) < 2e-6 * max(abs(ref), scale), (m_, d, g_Z[m_, d], ref)
+    if lik == "gaussian":
+        ref = (f(nz=noise + h) - f(nz=noise - h)) / (2 * h)
+        assert abs(float(grads["likelihood_variance"]) - ref) < 2e-6 * max(abs(ref), scale)
+    # the M-step driver sees every kernel's parameters
+    T = p.training
+    before = float(hip.elbo((X, Y)))
+    T.m_step(hip, (X, Y), T.Adam(0.01), steps=3)
+    assert set(T.trainable_parameters(hip)) >= {f"kernels.{k}.{n}" for k in range(P) for n in ("variance", "lengthscales")}
+    for k in range(P):
+        assert abs(float(hip.kernel.kernels[k].variance.value) - var0[k]) > 1e-3
+    assert float(hip.elbo((X, Y))) > before
