@@ -11,6 +11,8 @@
 //   panel_kernel<MOMENTS>  same product, but the tile is squared and row-summed in registers (never stored); the mean
 //                       GEMV rides on the first column tile (FUSE) or runs as a pre-pass; the likelihood-gradient map
 //                       runs in the epilogue.
+//   mean_lik_kernel     the moments without the variance product (TSVGP_LIK_MEANONLY): mean GEMV + Gaussian gradient
+//                       map in one sweep of the operand.  HBM bound.
 //   syrk_kernel         weighted Gram  sum_n g1[n] a_n a_n^T  over an N-slice per workgroup (lower tiles only) + the
 //                       first-order sum on diagonal tiles.  MFMA bound.  Partial tiles -> syrk_reduce_kernel (fixed order).
 //   potrf_diag_kernel, chol_tile_kernel, trtri_level_kernel   blocked Cholesky of the M x M site matrices and the
@@ -18,10 +20,10 @@
 //   kgrad_kernel        kernel-parameter gradient contraction of the M-step.  HBM bound.
 //
 // Tiling shared by the N-sized MFMA kernels: 128x128 output tile per 256-thread workgroup; wave w owns row blocks
-// {w, 7 - w} x all eight 16-column blocks (acc[2][8]); k-chunks of 16 staged global->registers->LDS with two LDS
-// buffers and one barrier per chunk; 2 workgroups per CU (<= 80 KB LDS, <= 256 VGPRs each) so one workgroup's barrier
+// {w, 7 - w} x all eight 16-column blocks (acc[2][8]); k-chunks of 16 (32 floats in the panel kernels) staged
+// global->registers->LDS with two LDS buffers and one barrier per chunk, two chunks per loop body; 2 workgroups per CU (<= 80 KB LDS, <= 256 VGPRs each) so one workgroup's barrier
 // and staging hide under the other's MFMAs.  LDS images are padded so that every fragment read and every staging write
-// is bank-conflict free: [row][k] images use a row stride of 17 doubles / 18 floats, [k][row] images a k stride of 144.
+// is bank-conflict free: [row][k] images use a row stride of 17 doubles / 34 floats, [k][row] images a k stride of 144.
 
 #include <hip/hip_runtime.h>
 

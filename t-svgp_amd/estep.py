@@ -5,11 +5,16 @@ Data layout in HBM (T = compute dtype, fp64 or fp32; Np/Mp = N/M rounded up to 1
     X    [N  x D ]  inputs (row-major, read once per pass by the fill kernel)
     Y    [N  x P ]  targets
     Kfu  [Np x Mp]  cross-covariance K(X, Z), written once by ``tsvgp_se_fill``
-    B    [Np x Mp]  whitened cross-covariance  B = Kfu L^-T  (L = chol(Kuu + jitter I)), written by ``tsvgp_trmm``
+    B    [Np x Mp]  whitened cross-covariance  B = Kfu U9^-T  (Kuu + jitter I = U9 U9^T), written by ``tsvgp_trmm``
+                    (whitened / projected routes only; on the projected route a = U9^-T b then overwrites Kfu)
     g0,g1[Np x P ]  likelihood gradients (rows >= N are zero)
     work            partial 128x128 tiles of the weighted Gram, [P][nsplit][ntri][128*128] (+ first-order partials)
 
-Kernel sequence of ``run(..., sites=True)``:  fill -> trmm(LOWER) -> moments(UPPER or DENSE) -> site_accum.
+Kernel sequence of ``run(..., sites=True)`` by projection route (models/tsvgp.py):
+    direct:     fill -> moments(UPPER, on Kfu) -> site_accum(Kfu)
+    whitened:   fill -> trmm(UPPER) -> moments(UPPER, on B) -> site_accum(B)
+    projected:  fill -> trmm(UPPER) -> moments(UPPER, on B) -> trmm(LOWER) -> site_accum(a)
+``mean_only`` replaces the moments product by one HBM-bound sweep (Gaussian likelihood, TSVGP_LIK_MEANONLY).
 """
 from __future__ import annotations
 
