@@ -61,3 +61,12 @@ def all_reduce_sum(packed: torch.Tensor) -> torch.Tensor:
     if world_size() > 1:
         dist.all_reduce(packed, op=dist.ReduceOp.SUM)
     return packed
+
+
+def broadcast_from_rank0(t: torch.Tensor) -> torch.Tensor:
+    """In-place broadcast of rank 0's values (no-op for a single process).  Used for host-side DECISIONS derived from
+    replicated data (the projection route from cond(K_uu)): every rank must take the same branch even if a library
+    routine were to round differently from one device to the next."""
+    if world_size() > 1:
+        dist.broadcast(t, src=0)
+    return t

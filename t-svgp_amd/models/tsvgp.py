@@ -235,7 +235,8 @@ class t_SVGP(base_SVGP):
             Kzz = self._get_engine().kuu(self._Z(), self.kernel)  # [M, M] or [P, M, M]
             ev = torch.linalg.eigvalsh(Kzz + jitter * torch.eye(Kzz.shape[-1], dtype=Kzz.dtype, device=Kzz.device))
             lo, hi = ev[..., 0], ev[..., -1]
-            cond = torch.where(lo > 0, hi / lo, torch.full_like(lo, float("inf"))).reshape(-1).tolist()
+            cond = torch.where(lo > 0, hi / lo, torch.full_like(lo, float("inf"))).reshape(-1)
+            cond = D_.broadcast_from_rank0(cond.contiguous()).tolist()  # one decision for all ranks
             self._cond_cache = (key, cond if len(cond) == P else cond * P, {})
         dmax, wmax = self.DIRECT_MAX_COND[self.compute_dtype], self.WHITENED_MAX_COND[self.compute_dtype]
         routes = ["direct" if c <= dmax else "whitened" if c <= wmax else "projected" for c in self._cond_cache[1]]
