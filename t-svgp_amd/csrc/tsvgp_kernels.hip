@@ -294,15 +294,8 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, TSV
     typedef typename Mfma<T>::pair_t pair_t;
 
     const int t = threadIdx.x;
-    const int64_t n0 = (int64_t)blockIdx.x * FILL_ROWS;
     const int m = blockIdx.y * FILL_COLS + 2 * t;  // this thread's column pair
-    const bool v0 = (m < M), v1 = (m + 1 < M);
-
-    for (int idx = t; idx < FILL_ROWS * DT; idx += NTHREADS) {
-        const int rr = idx / DT, d = idx - rr * DT;
-        const int64_t n = n0 + rr;
-        Xs[rr][d] = (n < N && d < D) ? X[n * D + d] * inv_ls[d] : T(0);
-    }
+    const bool v0 = (m < M), v1 = (m + 1 < M), active = (m < cols_pad);
     T z0[DT], z1[DT];
 #pragma unroll
     for (int d = 0; d < DT; ++d) {
@@ -310,30 +303,43 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, TSV
         z0[d] = (v0 && d < D) ? Z[(int64_t)m * D + d] * il : T(0);
         z1[d] = (v1 && d < D) ? Z[(int64_t)(m + 1) * D + d] * il : T(0);
     }
-    __syncthreads();
-    if (m >= cols_pad) return;
-#pragma unroll 2
-    for (int rr = 0; rr < FILL_ROWS; ++rr) {
-        const int64_t n = n0 + rr;
-        if (n >= rows_pad) break;
-        T s0 = T(0), s1 = T(0);
-#pragma unroll
-        for (int d = 0; d < DT; ++d) {
-            const T x = Xs[rr][d];
-            const T d0 = x - z0[d], d1 = x - z1[d];
-            s0 += d0 * d0;
-            s1 += d1 * d1;
+    // Row blocks are dealt round-robin to the workgroups of a column tile.  The default grid has one workgroup per
+    // row block; a smaller grid (tsvgp_kernel_fill's cap) leaves CU slots free for work on another stream.
+    const int64_t nrb = (rows_pad + FILL_ROWS - 1) / FILL_ROWS;
+    for (int64_t rb = blockIdx.x; rb < nrb; rb += gridDim.x) {
+        const int64_t n0 = rb * FILL_ROWS;
+        for (int idx = t; idx < FILL_ROWS * DT; idx += NTHREADS) {
+            const int rr = idx / DT, d = idx - rr * DT;
+            const int64_t n = n0 + rr;
+            Xs[rr][d] = (n < N && d < D) ? X[n * D + d] * inv_ls[d] : T(0);
         }
-        pair_t out;
-        const bool rowok = (n < N);
+        __syncthreads();
+        if (active) {
+#pragma unroll 2
+            for (int rr = 0; rr < FILL_ROWS; ++rr) {
+                const int64_t n = n0 + rr;
+                if (n >= rows_pad) break;
+                T s0 = T(0), s1 = T(0);
+#pragma unroll
+                for (int d = 0; d < DT; ++d) {
+                    const T x = Xs[rr][d];
+                    const T d0 = x - z0[d], d1 = x - z1[d];
+                    s0 += d0 * d0;
+                    s1 += d1 * d1;
+                }
+                pair_t out;
+                const bool rowok = (n < N);
 #ifdef TSVGP_EXP_NOEXP  // ablation switch (tools/exp_fill.py): the store-bound floor of the kernel
-        out[0] = (rowok && v0) ? variance * (T(1) - T(0.5) * s0) : T(0);
-        out[1] = (rowok && v1) ? variance * (T(1) - T(0.5) * s1) : T(0);
+                out[0] = (rowok && v0) ? variance * (T(1) - T(0.5) * s0) : T(0);
+                out[1] = (rowok && v1) ? variance * (T(1) - T(0.5) * s1) : T(0);
 #else
-        out[0] = (rowok && v0) ? variance * kernel_profile<KIND>(s0) : T(0);
-        out[1] = (rowok && v1) ? variance * kernel_profile<KIND>(s1) : T(0);
+                out[0] = (rowok && v0) ? variance * kernel_profile<KIND>(s0) : T(0);
+                out[1] = (rowok && v1) ? variance * kernel_profile<KIND>(s1) : T(0);
 #endif
-        *reinterpret_cast<pair_t*>(K + n * ldk + m) = out;
+                *reinterpret_cast<pair_t*>(K + n * ldk + m) = out;
+            }
+        }
+        if (rb + gridDim.x < nrb) __syncthreads();  // Xs is rewritten by the next row block
     }
 }
 
@@ -1624,6 +1630,10 @@ int kernel_fill(int kind, const T* X, const T* Z, const T* inv_ls, T variance, T
     if (ldk < cols_pad || (ldk % 2) != 0) return TSVGP_EINVAL;
     if (D > 32) return TSVGP_EINVAL;  // input dimensions are padded to a compile-time size (1, 2, 4, 8, 16, 32)
     dim3 grid((unsigned)((rows_pad + FILL_ROWS - 1) / FILL_ROWS), (unsigned)((cols_pad + FILL_COLS - 1) / FILL_COLS));
+    if (const char* cap = getenv("TSVGP_FILL_GRID")) {  // experiment (tools/exp_overlap2.py): fewer, looping workgroups
+        const long c = atol(cap);
+        if (c > 0 && (unsigned)c < grid.x) grid.x = (unsigned)c;
+    }
     const int DT = D <= 1 ? 1 : D <= 2 ? 2 : D <= 4 ? 4 : D <= 8 ? 8 : D <= 16 ? 16 : 32;
 #define TSVGP_FILL_LAUNCH(KIND_, DT_)                                                                                 \
     hipLaunchKernelGGL((se_fill_kernel<T, KIND_, DT_>), grid, dim3(NTHREADS), 0, (hipStream_t)stream, X, Z, inv_ls,   \

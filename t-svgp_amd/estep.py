@@ -63,6 +63,7 @@ class EStepEngine:
         self.nsplit_override = None
         self.syrk_oversubscribe = 8
         self._b_tag = None  # identifies the contents of the cached whitened buffer B
+        self._side = None  # side stream of start_fill
         self.profile = None  # set to a dict to record (start, stop) HIP events per kernel launch on the launch stream
 
     # ------------------------------------------------------------------ helpers
@@ -276,10 +277,47 @@ class EStepEngine:
         out.acc2, out.acc1 = cat("acc2", 0), cat("acc1", 0)
         return out
 
+    # ------------------------------------------------------------------ K(X, Z) fill beside the M x M prelude
+    def start_fill(self, X, Z, kernel, b_tag=None, want="Kfu"):
+        """Starts the K(X, Z) fill of the next ``run`` on a side stream and returns a ticket for ``run(prefill=...)``.
+        The fill needs only X, Z and the kernel parameters, so it can run beside the latency-bound M x M prelude
+        (factorisations of one workgroup each, small GEMMs) that the main stream executes between this call and
+        ``run``: 3.26 -> 2.6 ms for the pair at N = 1e6, M = 1024 (tools/exp_overlap2.py).  Returns None when there is
+        nothing to overlap: separate kernels (one fill per latent), an operand ``run`` would reuse (warm E-steps), a
+        stream capture in progress."""
+        if (isinstance(kernel, SeparateIndependent) or self.device.type != "cuda"
+                or torch.cuda.is_current_stream_capturing()):
+            return None
+        T, dev = self.dtype, self.device
+        N, D = X.shape
+        M = Z.shape[0]
+        Np, Mp = B.round_up(N), B.round_up(M)
+        if (b_tag is not None and self._b_tag == (want, b_tag) and self._buf.get(want) is not None
+                and tuple(self._buf[want].shape) == (Np, Mp)):
+            return None
+        main = torch.cuda.current_stream(dev)
+        if self._side is None:
+            self._side = torch.cuda.Stream(dev)
+        side = self._side
+        Xc = X.to(device=dev, dtype=T).contiguous()
+        Zc = Z.to(device=dev, dtype=T).contiguous()
+        inv_ls = kernel.inv_lengthscales(D, T, dev)
+        variance = kernel.variance.item()
+        self._b_tag = None
+        Kfu = self._get("Kfu", (Np, Mp), T)
+        side.wait_stream(main)  # the buffer's last readers (the previous pass) and the conversions above
+        with torch.cuda.stream(side):
+            self.se_fill(Xc, Zc, inv_ls, variance, Kfu, kernel.kind)
+            done = torch.cuda.Event()
+            done.record(side)
+        for t in (Xc, Zc, inv_ls):  # temporaries of the main stream's allocator pool, read on the side stream
+            t.record_stream(side)
+        return dict(event=done, key=(X.data_ptr(), tuple(X.shape), Z.data_ptr(), tuple(Z.shape), id(kernel)), Kfu=Kfu)
+
     # ------------------------------------------------------------------ one N-pass
     def run(self, X, Y, Z, kernel, *, moment_Tm, moment_mode, gamma, lik_id=B.LIK_NONE, lik_param=0.0,
             whiten_T=None, whiten_mode=B.TRI_UPPER, project_T=None, sites=False, want_moments=False, want_grads=False,
-            b_tag=None, mean_only=False) -> EStepStats:
+            b_tag=None, mean_only=False, prefill=None) -> EStepStats:
         """One pass over the shard's rows.
 
         X [N, D], Y [N, P] (or None when lik_id == NONE), Z [M, D];
@@ -294,6 +332,8 @@ class EStepEngine:
         b_tag: a hashable description of (X, Z, kernel parameters, jitter).  When it equals the tag of the B buffer left
         by the previous call, the fill and the whitening are skipped and B is reused ("warm" E-step: consecutive
         E-steps with unchanged hyperparameters, as in the reference's E/M loop, experiments/uci_regression.py:152-153).
+        prefill: the ticket of ``start_fill`` for the same (X, Z, kernel): the fill is already under way on the side
+        stream; this call waits for it instead of filling.
         mean_only (likelihood NONE or GAUSSIAN): skip the variance product of the moments (TSVGP_LIK_MEANONLY) -- the
         Gaussian g0, g1 do not depend on it; ``var`` is then None and ``ve_sum`` NaN.
         """
@@ -332,7 +372,14 @@ class EStepEngine:
         else:
             self._b_tag = None
             Kfu = self._get("Kfu", (Np, Mp), T)
-            self.se_fill(X, Z, inv_ls, variance, Kfu, kernel.kind)
+            if prefill is not None:
+                if prefill["Kfu"] is not Kfu:
+                    raise RuntimeError("prefill ticket does not belong to this pass")
+                torch.cuda.current_stream(dev).wait_event(prefill["event"])
+            else:
+                if self._side is not None:  # a fill started for a pass that never ran must not land on top of this one
+                    torch.cuda.current_stream(dev).wait_stream(self._side)
+                self.se_fill(X, Z, inv_ls, variance, Kfu, kernel.kind)
             A = Kfu
             if whiten_T is not None:
                 Bw = self._get("B", (Np, Mp), T)

@@ -136,7 +136,8 @@ class t_SVGP(base_SVGP):
 
     def __init__(self, kernel, likelihood, inducing_variable, *, mean_function=None, num_latent_gps: int = 1,
                  lambda_1=None, lambda_2_sqrt=None, num_data=None, force=False, compute_dtype=None, device=None,
-                 cache_whitened=False, projection="auto", use_graph=False, skip_unused_variance=False):
+                 cache_whitened=False, projection="auto", use_graph=False, skip_unused_variance=False,
+                 overlap_fill=True):
         super().__init__(kernel, likelihood, inducing_variable, mean_function=mean_function,
                          num_latent_gps=num_latent_gps, num_data=num_data, compute_dtype=compute_dtype, device=device)
         self.num_inducing = self.inducing_variable.num_inducing
@@ -169,6 +170,8 @@ class t_SVGP(base_SVGP):
         # d ve/d var = -1/(2 s2) do not depend on it, so the updated sites are the same numbers; what is lost is the
         # var > 0 check of the step (tsvgp.py:113), which elbo / predict_f still make.
         self.skip_unused_variance = skip_unused_variance
+        # natgrad_step starts the K(X, Z) fill on a side stream before the M x M prelude (EStepEngine.start_fill)
+        self.overlap_fill = overlap_fill
         self.name = "t_svgp"  # tf.Module derives this from the class name (experiments/uci_regression.py:150)
 
     def _init_variational_parameters(self, num_inducing, lambda_1, lambda_2_sqrt, **kwargs):
@@ -563,13 +566,19 @@ class t_SVGP(base_SVGP):
         assignment.  Returns the status flags (device).  With ``inplace`` the state tensors are overwritten in place
         (what a captured graph needs) instead of being replaced."""
         warm_key = self._warm_key(X, jitter)
+        eng = self._get_engine()
+        # K(X, Z) depends on neither lambda nor the M x M factors: its fill runs on a side stream beside the prelude
+        pre = None
+        if self.overlap_fill and hasattr(eng, "start_fill"):
+            pre = eng.start_fill(X, self._Z(), self.kernel, b_tag=warm_key,
+                                 want="Kfu" if all(r == "direct" for r in routes) else "B")
         ops = self._site_operands(whiten_jitter=jitter, warm_key=warm_key, routes=routes)
-        st = self._get_engine().run(X, Y, ops["Z"], self.kernel, moment_Tm=ops["moment_Tm"],
-                                    moment_mode=ops["moment_mode"], gamma=ops["gamma"],
-                                    lik_id=self.likelihood.lik_id, lik_param=self.likelihood.lik_param,
-                                    whiten_T=ops["whiten_T"], whiten_mode=ops["whiten_mode"], project_T=ops["project_T"],
-                                    sites=True, b_tag=warm_key,
-                                    mean_only=self.skip_unused_variance and self.likelihood.lik_id == B.LIK_GAUSSIAN)
+        st = eng.run(X, Y, ops["Z"], self.kernel, moment_Tm=ops["moment_Tm"], prefill=pre,
+                     moment_mode=ops["moment_mode"], gamma=ops["gamma"],
+                     lik_id=self.likelihood.lik_id, lik_param=self.likelihood.lik_param,
+                     whiten_T=ops["whiten_T"], whiten_mode=ops["whiten_mode"], project_T=ops["project_T"],
+                     sites=True, b_tag=warm_key,
+                     mean_only=self.skip_unused_variance and self.likelihood.lik_id == B.LIK_GAUSSIAN)
         return self._apply_site_update(st, ops, lr, jitter, inplace=inplace)
 
     # -- hipGraph replay of the step (launch-bound problem sizes) -------------------------------------------------

@@ -21,7 +21,7 @@ class NumpyShardEngine:
 
     def run(self, X, Y, Z, kernel, *, moment_Tm, moment_mode, gamma, lik_id=0, lik_param=0.0, whiten_T=None,
             whiten_mode=1, project_T=None, sites=False, want_moments=False, want_grads=False, b_tag=None,
-            mean_only=False):
+            mean_only=False, prefill=None):
         if hasattr(kernel, "kernels"):  # one pass per latent, as EStepEngine._run_separate
             parts = [self.run(X, None if Y is None else Y[:, p:p + 1], Z, kp, moment_Tm=moment_Tm[p:p + 1],
                               moment_mode=moment_mode, gamma=gamma[:, p:p + 1], lik_id=lik_id, lik_param=lik_param,
