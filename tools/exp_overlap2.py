@@ -34,7 +34,10 @@ def timeit(fn, reps=10):
     torch.cuda.synchronize(); return (time.perf_counter() - t) / reps * 1e3
 
 main = torch.cuda.current_stream(dev)
-side = torch.cuda.Stream(dev)
+prio = int(os.environ.get("OVL_PRIO", "0"))
+side = torch.cuda.Stream(dev, priority=prio)
+print("stream priority range (torch):", torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else None,
+      "side priority", side.priority)
 print(f"routes {routes}")
 print(f"prelude alone          {timeit(prelude):.3f} ms")
 os.environ.pop("TSVGP_FILL_GRID", None)
@@ -47,9 +50,15 @@ for cap in [int(a) for a in sys.argv[1:]] or [256]:
         os.environ.pop("TSVGP_FILL_GRID", None)
     def both():
         e0 = torch.cuda.Event(); e0.record(main); side.wait_event(e0)
-        with torch.cuda.stream(side):
+        if os.environ.get("OVL_SWAP"):  # the prelude on the (high-priority) side stream, the fill on the main one
+            with torch.cuda.stream(side):
+                prelude()
+                e1 = torch.cuda.Event(); e1.record(side)
             fill()
-            e1 = torch.cuda.Event(); e1.record(side)
-        prelude()
+        else:
+            with torch.cuda.stream(side):
+                fill()
+                e1 = torch.cuda.Event(); e1.record(side)
+            prelude()
         main.wait_event(e1)
     print(f"cap {cap:5d} (x2 column tiles): fill alone {timeit(fill):.3f} ms   overlapped with the prelude {timeit(both):.3f} ms", flush=True)

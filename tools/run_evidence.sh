@@ -1,9 +1,9 @@
 #!/bin/bash
 # Collects the per-round evidence on the GPU box in one call: bench lines of every workload, the rocprofv3 kernel trace
-# and the PMC passes of the headline workload, under gpurun_out/v6r/ (copied into profiles/ by hand afterwards).
+# and the PMC passes of the headline workload, under gpurun_out/v7r/ (or $EVIDENCE_DIR) (copied into profiles/ by hand afterwards).
 set -e
 R=$PWD
-O=gpurun_out/v6r
+O=gpurun_out/${EVIDENCE_DIR:-v7r}
 mkdir -p $O
 python bench.py > $O/ns_bench.json 2> $O/ns_bench.err
 echo ns done
