@@ -491,3 +491,36 @@ def test_ill_conditioned_kuu_takes_the_projected_route():
     one = mk(O)
     one.natgrad_step((X, Y), lr=0.7)
     assert abs(float(forced.elbo((X, Y))) - one.elbo((X, Y))) < 1e-8 * abs(one.elbo((X, Y)))
+
+
+@pytest.mark.parametrize("lik", ["gaussian", "bernoulli"])
+def test_execution_options_do_not_change_the_step(lik):
+    """overlap_fill (K(X, Z) fill on a side stream beside the M x M prelude), use_graph, cache_whitened and (Gaussian)
+    skip_unused_variance are execution options: the state after the same steps is the same to rounding, on device tensors
+    that are reused from call to call (the side stream must order itself against the previous step's readers of the
+    K(X, Z) buffer and against predict_f / elbo calls in between)."""
+    p = pkg()
+    rng = np.random.RandomState(17)
+    X, Y, _ = synthetic(N=3000, M=130, D=5, P=1, lik=lik, seed=10)
+    Z = rng.randn(130, 5) * 1.4
+    Xd, Yd = torch.as_tensor(X, device="cuda:0"), torch.as_tensor(Y, device="cuda:0")
+    mk = lambda **kw: p.t_SVGP(p.SquaredExponential(1.0, 1.1), p.Gaussian(0.15) if lik == "gaussian" else p.Bernoulli(), Z,
+                               num_data=3000, **kw)
+    variants = {"plain": mk(overlap_fill=False), "overlap": mk(), "graph": mk(use_graph=True), "warm": mk(cache_whitened=True),
+                "whitened+overlap": mk(projection="whitened")}
+    if lik == "gaussian":
+        variants["skip"] = mk(skip_unused_variance=True)
+        variants["skip+graph+warm-off"] = mk(skip_unused_variance=True, use_graph=True)
+    elbos = {}
+    for name, m in variants.items():
+        for i in range(6):
+            m.natgrad_step((Xd, Yd), lr=0.6)
+            if i == 2:
+                m.predict_f(Xd[:300])  # overwrites the work buffers between two steps
+        elbos[name] = float(m.elbo((Xd, Yd)))
+    ref = variants["plain"]
+    for name, m in variants.items():
+        tol = 1e-9 if "whitened" in name else 1e-12
+        assert relerr(m.lambda_1.numpy(), ref.lambda_1.numpy()) < tol, name
+        assert relerr(m.lambda_2.cpu().numpy(), ref.lambda_2.cpu().numpy()) < tol, name
+        assert abs(elbos[name] - elbos["plain"]) < 1e-10 * abs(elbos["plain"]), name
