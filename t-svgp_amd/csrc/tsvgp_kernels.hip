@@ -37,6 +37,9 @@ namespace {
 
 constexpr int TILE = TSVGP_TILE;  // 128
 constexpr int KC = 16;            // k-chunk of the site-accumulation kernel ([k][row] images)
+#ifndef TSVGP_CHOL_PRIO
+#define TSVGP_CHOL_PRIO 3  // wave priority of the latency-bound factorisation kernels (s_setprio, 0..3)
+#endif
 #ifndef TSVGP_PANEL_KC_F32
 #define TSVGP_PANEL_KC_F32 32
 #endif
@@ -1313,6 +1316,9 @@ __global__ __launch_bounds__(CH_THREADS) void potrf_diag_kernel(double* __restri
                                                                 double* __restrict__ work, int* __restrict__ info,
                                                                 int need_inverse, double* __restrict__ Xout,
                                                                 double* __restrict__ Xtout, int ldx, int64_t xstride) {
+    // These few waves are the critical path of the M x M prelude while the K(X, Z) fill of the same step fills every CU
+    // from a side stream: ask the SIMD arbiter to issue them first.
+    __builtin_amdgcn_s_setprio(TSVGP_CHOL_PRIO);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     double* S = reinterpret_cast<double*>(smem_raw);  // [CH_NB][CH_LD]; lower: A -> L, strict upper: inv(L)^T
     __shared__ int fail;
@@ -1445,6 +1451,7 @@ __global__ __launch_bounds__(CH_THREADS) void potrf_diag_kernel(double* __restri
 template <int OP>
 __global__ __launch_bounds__(NTHREADS) void chol_tile_kernel(double* __restrict__ Amat, int lda, int64_t stride, int k,
                                                              int nt, const double* __restrict__ work) {
+    __builtin_amdgcn_s_setprio(TSVGP_CHOL_PRIO);
     const int lane = threadIdx.x & 63, li = lane & 15, g = lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b = blockIdx.y;
@@ -1526,6 +1533,7 @@ __global__ __launch_bounds__(NTHREADS) void trtri_level_kernel(const double* __r
                                                                int n) {
     // One workgroup per 32x32 output tile; its four waves split the k range (64-wide chunks, round robin) and the
     // partial tiles are summed through LDS: a lone wave per tile would sit out one load latency per chunk.
+    __builtin_amdgcn_s_setprio(TSVGP_CHOL_PRIO);
     __shared__ v4d part[NTHREADS / 64][4][64];
     const int lane = threadIdx.x & 63, li = lane & 15, g = lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
