@@ -114,8 +114,6 @@ class base_SVGP(abc.ABC):
         """The parameters the reference's M-step trains (``model.trainable_variables``, experiments/uci_regression.py:160):
         kernel variance(s) and lengthscales, the likelihood's parameters and the inducing inputs; the sites are not
         trainable (src/sites.py:56-63)."""
-        from ..kernels import latent_kernels
-
         out, seen = [], set()
         kernels = self.kernel.kernels if hasattr(self.kernel, "kernels") else [self.kernel]
         for k in kernels:

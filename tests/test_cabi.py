@@ -1,6 +1,5 @@
 """CPU checks of the C-ABI boundary: the in-tree library loads and exports every symbol include/tsvgp_hip.h declares,
 the ctypes prototypes cover exactly those symbols, and argument validation works without a GPU (no compute calls)."""
-import ctypes
 import os
 import re
 

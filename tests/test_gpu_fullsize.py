@@ -7,7 +7,6 @@ properties of the path.
                         parameters and the ELBO unchanged (reference tests/models/test_tsvgp.py:134-145 at N = 1e6).
 * two predictive routes agree -- predict_f (whitened / triangular) == new_predict_f (dense site form), tsvgp.py:215-232.
 """
-import numpy as np
 import pytest
 import torch
 

@@ -5,7 +5,6 @@ import os
 
 import numpy as np
 import pytest
-import torch
 
 from tests.helpers import pkg, relerr
 from tests.test_golden_cpu import FIXTURES, load_model

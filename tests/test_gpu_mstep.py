@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from oracle import tsvgp_oracle as O
-from tests.helpers import pkg, relerr, synthetic
+from tests.helpers import pkg, synthetic
 
 pytestmark = pytest.mark.gpu
 

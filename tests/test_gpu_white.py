@@ -4,7 +4,6 @@ import os
 
 import numpy as np
 import pytest
-import torch
 
 from oracle import tsvgp_oracle as O
 from tests.helpers import pkg, relerr, synthetic
