@@ -97,15 +97,16 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("TSVGP_HIP_LIB", LIB_PATH)  # experiments (tools/): an alternative build of the same sources
+    if not os.path.exists(path):
         raise HipExtensionError(
-            f"HIP extension not built: {LIB_PATH} is missing. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"HIP extension not built: {path} is missing. Run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback for the E-step."
         )
     try:
-        handle = ctypes.CDLL(LIB_PATH)
+        handle = ctypes.CDLL(path)
     except OSError as e:  # pragma: no cover - depends on the box
-        raise HipExtensionError(f"cannot load {LIB_PATH}: {e}") from e
+        raise HipExtensionError(f"cannot load {path}: {e}") from e
     for name, (restype, argtypes) in _PROTOTYPES.items():
         fn = getattr(handle, name)
         fn.restype = restype
