@@ -168,10 +168,11 @@ class EStepEngine:
         self.se_fill(Z, Z, inv_ls, kernel.variance.item(), out, kernel.kind)
         return out[:M, :M].contiguous()
 
-    def cholesky(self, A: torch.Tensor, inverse: bool = False):
+    def cholesky(self, A: torch.Tensor, inverse: bool = False, overwrite: bool = False):
         """Batched lower Cholesky on the GPU through ``tsvgp_potrf_f64`` (no host synchronisation).
         A [.., M, M] fp64 (lower triangle referenced) -> (L [.., M, M] with zeros above the diagonal, info [batch] int32);
-        with ``inverse`` also inv(L) (``tsvgp_potrf_inv_f64``), lower triangular with exact zeros above."""
+        with ``inverse`` also inv(L) (``tsvgp_potrf_inv_f64``), lower triangular with exact zeros above.
+        ``overwrite``: A is a temporary of the caller and may be factored in place (no copy when M is a multiple of 128)."""
         A = A.to(device=self.device, dtype=torch.float64)
         M = A.shape[-1]
         batch_shape = A.shape[:-2]
@@ -179,9 +180,13 @@ class EStepEngine:
         nb = 1
         for d in batch_shape:
             nb *= int(d)
-        W = torch.zeros((nb, Mp, Mp), dtype=torch.float64, device=self.device)
-        W[:, :M, :M] = A.reshape(nb, M, M)
-        if Mp > M:
+        if Mp == M:  # no padding: one copy (or none) instead of a zero fill plus a copy
+            W = A.reshape(nb, M, M)
+            if not (overwrite and W.is_contiguous() and W.data_ptr() == A.data_ptr()):
+                W = W.clone(memory_format=torch.contiguous_format)
+        else:
+            W = torch.zeros((nb, Mp, Mp), dtype=torch.float64, device=self.device)
+            W[:, :M, :M] = A.reshape(nb, M, M)
             W.diagonal(dim1=-2, dim2=-1)[:, M:] = 1.0  # chol([[A, 0], [0, I]]) = [[L, 0], [0, I]]  (a fill: capturable)
         info = torch.empty(nb, dtype=torch.int32, device=self.device)
         work = self._get("potrf_work", (nb, 128 * 128), torch.float64)

@@ -687,7 +687,8 @@ class t_SVGP(base_SVGP):
         lambda_1 = (1 - lr) * lambda_1 + lr * scale * grad_mu[0]  # tsvgp.py:296
         lambda_2 = (1 - lr) * lambda_2 + lr * scale * grad_mu[1]  # tsvgp.py:297
         final_info = []
-        lambda_2_sqrt = -cholesky_deferred(-2.0 * lambda_2 + ops["Id"] * jitter, final_info, ops["potrf"])  # tsvgp.py:300
+        lambda_2_sqrt = -cholesky_deferred(-2.0 * lambda_2 + ops["Id"] * jitter, final_info, ops["potrf"],
+                                           overwrite=True)  # tsvgp.py:300
         if inplace:
             self.lambda_1.value.copy_(lambda_1)
             self.lambda_2_sqrt.value.copy_(torch.tril(lambda_2_sqrt))

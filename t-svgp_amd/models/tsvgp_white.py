@@ -99,7 +99,7 @@ class t_SVGP_white(base_SVGP):
         U6, Uinv6, U_E = U[0], Uinv[0], U[1]
         H = (Uinv6 @ U_E).triu()
         Wm = Id + H.transpose(-1, -2) @ H
-        _, Cinv = cholesky_deferred(0.5 * (Wm + Wm.transpose(-1, -2))[None], infos, potrf, inverse=True)
+        _, Cinv = cholesky_deferred(0.5 * (Wm + Wm.transpose(-1, -2))[None], infos, potrf, inverse=True, overwrite=True)
         Tm = (Cinv[0] @ H.transpose(-1, -2)).tril()
         v = Uinv6 @ l1
         gamma = v - Tm.transpose(-1, -2) @ (Tm @ v)

@@ -20,13 +20,14 @@ def cholesky(a: torch.Tensor) -> torch.Tensor:
     return L
 
 
-def cholesky_deferred(a: torch.Tensor, infos: list, potrf=None, inverse: bool = False):
+def cholesky_deferred(a: torch.Tensor, infos: list, potrf=None, inverse: bool = False, overwrite: bool = False):
     """Cholesky without a host synchronisation: the LAPACK-style ``info`` tensor is appended to ``infos`` and
     checked later in one device->host read (see ``t_SVGP._check_step``).  ``potrf`` is the engine's HIP
-    factorisation (``EStepEngine.cholesky``); without it torch's is used.  With ``inverse`` returns (L, inv(L))."""
+    factorisation (``EStepEngine.cholesky``); without it torch's is used.  With ``inverse`` returns (L, inv(L)).
+    ``overwrite``: ``a`` is a temporary that the factorisation may destroy."""
     Linv = None
     if potrf is not None:
-        res = potrf(a, inverse=True) if inverse else potrf(a)
+        res = potrf(a, inverse=inverse, overwrite=overwrite)
         L, info = res[0], res[1]
         Linv = res[2] if inverse else None
     else:
@@ -42,7 +43,7 @@ def rev_cholesky(a: torch.Tensor, infos: list, potrf=None, inverse: bool = False
     """Upper-form Cholesky a = U U^T, U upper triangular: the lower factor of the index-reversed matrix, reversed back
     (J a J = C C^T  =>  a = (J C J)(J C J)^T, and U^-1 = J C^-1 J).  Status handling as in ``cholesky_deferred``.
     With ``inverse`` returns (U, inv(U))."""
-    res = cholesky_deferred(torch.flip(a, (-2, -1)), infos, potrf, inverse)
+    res = cholesky_deferred(torch.flip(a, (-2, -1)), infos, potrf, inverse, overwrite=True)  # the flipped copy is ours
     if inverse:
         return torch.flip(res[0], (-2, -1)), torch.flip(res[1], (-2, -1))
     return torch.flip(res, (-2, -1))
