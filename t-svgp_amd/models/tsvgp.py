@@ -41,6 +41,7 @@ from ..sites import DenseSites
 from ..util import (
     cholesky_deferred,
     gradient_transformation_mean_var_to_expectation,
+    info_sum,
     kl_from_dense_site,
     posterior_from_dense_site,
     rev_cholesky,
@@ -203,6 +204,13 @@ class t_SVGP(base_SVGP):
     def _Z(self) -> torch.Tensor:
         return self.inducing_variable.Z.value.to(self.device)
 
+    def _eye(self, M: int) -> torch.Tensor:
+        """Cached fp64 identity on the model device (read-only: callers add it, never write to it)."""
+        e = getattr(self, "_eye_cache", None)
+        if e is None or e.shape[0] != M or e.device != self.device:
+            e = self._eye_cache = torch.eye(M, dtype=torch.float64, device=self.device)
+        return e
+
     def _warm_key(self, X, jitter):
         """Cache key of everything B = K(X, Z) U9^-T depends on; None when caching is off or X is not a device tensor."""
         if not self.cache_whitened or not isinstance(X, torch.Tensor) or X.device != self.device:
@@ -264,30 +272,34 @@ class t_SVGP(base_SVGP):
         infos = []
         warm = self._warm if (warm_key is not None and self._warm is not None and self._warm[0] == warm_key) else None
         Kzz = warm[1]["Kzz"] if warm else eng.kuu(Z, self.kernel)  # HIP fill kernel, no jitter
-        Id = torch.eye(M, dtype=torch.float64, device=Kzz.device)
-        K6 = Kzz + default_jitter() * Id  # tsvgp.py:209-211
+        Id = self._eye(M)
+        K6 = Kzz.clone()
+        K6.diagonal(dim1=-2, dim2=-1).add_(default_jitter())  # tsvgp.py:209-211
         l1 = self.lambda_1.value
         L = self.lambda_2_sqrt.value
+        P_ = L.shape[0]
         potrf = getattr(eng, "cholesky", None)  # HIP blocked Cholesky (tsvgp_potrf_f64)
         # W = I + L^T K6 L (util.py:171-172, formed without chol(K6)).  The factorisations of W and K_uu + jitter I are
-        # independent and both latency bound (one workgroup per diagonal block): do them in ONE batched call.
-        W = Id + L.transpose(-1, -2) @ (K6 @ L)
-        W = 0.5 * (W + W.transpose(-1, -2))
+        # independent and both latency bound (one workgroup per diagonal block): do them in ONE batched call, whose
+        # input batch is assembled in place (the addition of I rides on the GEMM; no concatenation).  Only one
+        # triangle of W is read, so the rounding-level asymmetry of L^T (K6 L) needs no symmetrisation.
         # The factorisation also returns the inverse factors (tsvgp_potrf_inv_f64) and they are applied as GEMMs: a
         # rocBLAS trsm with an M x M right-hand side costs ~0.25 ms at M = 1024, a GEMM ~0.05 ms.
-        if whiten_jitter is not None and warm:
-            U9, Uinv9 = warm[1]["U9"], warm[1]["Uinv9"]
-            U_W, Uinv_W = rev_cholesky(W, infos, potrf, inverse=True)
+        with_k9 = whiten_jitter is not None and not warm
+        n9 = (Kzz.shape[0] if Kzz.dim() == 3 else 1) if with_k9 else 0
+        batch = torch.empty((P_ + n9, M, M), dtype=torch.float64, device=Kzz.device)
+        torch.baddbmm(Id.expand(P_, M, M), L.transpose(-1, -2), K6 @ L, out=batch[:P_])
+        if with_k9:
+            batch[P_:].copy_(Kzz if Kzz.dim() == 3 else Kzz[None])
+            batch[P_:].diagonal(dim1=-2, dim2=-1).add_(whiten_jitter)  # K9 = K_uu + jitter I, tsvgp.py:270
+        both, inv_both = rev_cholesky(batch, infos, potrf, inverse=True)
+        U_W, Uinv_W = both[:P_], inv_both[:P_]
+        if with_k9:
+            U9, Uinv9 = (both[P_:], inv_both[P_:]) if Kzz.dim() == 3 else (both[-1], inv_both[-1])
         elif whiten_jitter is not None:
-            K9 = Kzz + whiten_jitter * Id
-            both, inv_both = rev_cholesky(torch.cat([W, K9 if K9.dim() == 3 else K9[None]], dim=0), infos, potrf,
-                                          inverse=True)
-            P_ = W.shape[0]
-            U_W, Uinv_W = both[:P_], inv_both[:P_]
-            U9, Uinv9 = (both[P_:], inv_both[P_:]) if K9.dim() == 3 else (both[-1], inv_both[-1])
+            U9, Uinv9 = warm[1]["U9"], warm[1]["Uinv9"]
         else:
             U9, Uinv9 = None, None
-            U_W, Uinv_W = rev_cholesky(W, infos, potrf, inverse=True)
         Dm = (Uinv_W @ L.transpose(-1, -2)).triu()  # D = U_W^-1 L^T, [P, M, M], upper triangular
         DKl = torch.einsum("pmk,kp->pm", Dm, _kmv(K6, l1))
         beta = l1 - torch.einsum("pkm,pk->mp", Dm, DKl)  # K6^-1 m = l1 - D^T D K6 l1
@@ -325,8 +337,8 @@ class t_SVGP(base_SVGP):
     def _status_flags(self, ops, nonpos, extra_infos=()) -> torch.Tensor:
         """Device tensor [3]: failed prelude factorisations, count of non-positive variances, failed final one."""
         zero = torch.zeros(1, dtype=torch.float64, device=self.device)
-        final = torch.cat(list(extra_infos)).sum().reshape(1) if len(extra_infos) else zero
-        return torch.cat([torch.cat(list(ops["infos"])).sum().reshape(1), nonpos.reshape(1).to(torch.float64), final])
+        final = info_sum(extra_infos) if len(extra_infos) else zero
+        return torch.cat([info_sum(ops["infos"]), nonpos.reshape(1).to(torch.float64), final])
 
     @staticmethod
     def _judge(flags, soft_final=False):
@@ -682,13 +694,15 @@ class t_SVGP(base_SVGP):
 
         # tsvgp.py:286-291; `rows` = global number of rows, a device scalar (no synchronisation)
         scale = (float(self.num_data) / rows) if self.num_data is not None else 1.0
-        lambda_2 = -0.5 * self.lambda_2  # tsvgp.py:293
-        lambda_1 = self.lambda_1.value
-        lambda_1 = (1 - lr) * lambda_1 + lr * scale * grad_mu[0]  # tsvgp.py:296
-        lambda_2 = (1 - lr) * lambda_2 + lr * scale * grad_mu[1]  # tsvgp.py:297
+        lambda_1 = (1 - lr) * self.lambda_1.value + lr * scale * grad_mu[0]  # tsvgp.py:296
+        # tsvgp.py:293-300 in one pass: with lambda_2 = -1/2 L L^T the matrix to factor is
+        #   -2 [(1 - lr) lambda_2 + lr scale G1] + jitter I = (1 - lr) L L^T - 2 lr scale G1 + jitter I,
+        # and the old L L^T rides on a GEMM whose "C" operand is the scaled gradient
+        L_old = self.lambda_2_sqrt.value
+        target = torch.baddbmm(grad_mu[1] * (-2.0 * lr * scale), L_old, L_old.transpose(-1, -2), alpha=1.0 - lr)
+        target.diagonal(dim1=-2, dim2=-1).add_(jitter)
         final_info = []
-        lambda_2_sqrt = -cholesky_deferred(-2.0 * lambda_2 + ops["Id"] * jitter, final_info, ops["potrf"],
-                                           overwrite=True)  # tsvgp.py:300
+        lambda_2_sqrt = -cholesky_deferred(target, final_info, ops["potrf"], overwrite=True)  # tsvgp.py:300
         if inplace:
             self.lambda_1.value.copy_(lambda_1)
             self.lambda_2_sqrt.value.copy_(torch.tril(lambda_2_sqrt))

@@ -29,7 +29,7 @@ from .. import distributed as D_
 from ..base import default_jitter, to_tensor
 from ..kernels import SeparateIndependent
 from ..sites import DenseSites
-from ..util import cholesky_deferred, rev_cholesky
+from ..util import cholesky_deferred, info_sum, rev_cholesky
 from .tsvgp import base_SVGP
 
 
@@ -115,7 +115,7 @@ class t_SVGP_white(base_SVGP):
                                       want_moments=want_moments)
 
     def _check(self, ops, nonpos):
-        flags = torch.cat([torch.cat(list(ops["infos"])).sum().reshape(1), nonpos.reshape(1).to(torch.float64)]).cpu()
+        flags = torch.cat([info_sum(ops["infos"]), nonpos.reshape(1).to(torch.float64)]).cpu()
         if float(flags[0]) != 0:
             raise FloatingPointError("Cholesky decomposition was not successful (matrix not positive definite)")
         if not (float(flags[1]) == 0):  # tsvgp_white.py:131

@@ -35,8 +35,13 @@ def cholesky_deferred(a: torch.Tensor, infos: list, potrf=None, inverse: bool = 
         if inverse:
             Id = torch.eye(a.shape[-1], dtype=a.dtype, device=a.device)
             Linv = torch.linalg.solve_triangular(L, Id, upper=False)
-    infos.append(info.reshape(-1).to(torch.float64).abs().sum().reshape(1))
+    infos.append(info.reshape(-1).to(torch.int32))  # raw: reduced once per call by ``info_sum``
     return (L, Linv) if inverse else L
+
+
+def info_sum(infos) -> torch.Tensor:
+    """[1] fp64 tensor: sum of |info| over the factorisations collected by ``cholesky_deferred`` (0 = all succeeded)."""
+    return torch.cat(list(infos)).abs().sum().to(torch.float64).reshape(1)
 
 
 def rev_cholesky(a: torch.Tensor, infos: list, potrf=None, inverse: bool = False):
