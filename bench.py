@@ -187,16 +187,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    for _ in range(args.warmup):
+    # Per-kernel HIP events are recorded in the timed region, except where the model's default replays the step from a
+    # captured hipGraph (launch-bound sizes, configs[0]): events inside a replay would force the eager path.
+    replayed = args.model == "tsvgp" and world == 1 and model._wants_graph(Xd) and not w.get("separate")
+    for _ in range(max(args.warmup, 3 if replayed else 0)):  # a graph is captured on the second occurrence of a step
         model.natgrad_step((Xd, Yd), lr=0.8)
     barrier()
-    eng.profile = {}
+    eng.profile = None if replayed else {}
     t0 = time.perf_counter()
     for _ in range(args.steps):
         model.natgrad_step((Xd, Yd), lr=0.8)
     barrier()
     elapsed = time.perf_counter() - t0
-    prof = eng.profile_summary()
+    prof = {} if replayed else eng.profile_summary()
     eng.profile = None
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -221,11 +224,13 @@ def main():
     warm_elapsed = float(tw)
     model.cache_whitened = False
 
-    # launch-bound sizes (configs[0]): the same steps replayed from a captured hipGraph (t_SVGP(use_graph=True)), reported
-    # beside the headline like `warm`
+    # launch-bound sizes (configs[0]): t_SVGP(use_graph="auto"), the default, replays the step from a captured hipGraph
+    # there, so `value` above is the replayed rate; the other mode (eager) is reported beside it.  At the metric's
+    # sizes "auto" runs eagerly and this block is skipped.
     graph_line = None
     if world == 1 and args.model == "tsvgp" and w["N"] * w["M"] <= 10_000_000 and not w.get("separate"):
-        model.use_graph = True
+        auto_on = model._wants_graph(Xd)
+        model.use_graph = not auto_on
         for _ in range(4):
             model.natgrad_step((Xd, Yd), lr=0.8)
         barrier()
@@ -234,10 +239,13 @@ def main():
             model.natgrad_step((Xd, Yd), lr=0.8)
         barrier()
         tg = time.perf_counter() - t0
-        model.use_graph = False
-        graph_line = {"value": round(args.steps / tg, 4), "unit": "E-steps/s", "ms_per_step": round(tg / args.steps * 1e3, 4),
+        model.use_graph = "auto"
+        graph_line = {"mode": "eager (use_graph=False)" if auto_on else "hipGraph replay (use_graph=True)",
+                      "headline_mode": "hipGraph replay" if auto_on else "eager",
+                      "value": round(args.steps / tg, 4), "unit": "E-steps/s", "ms_per_step": round(tg / args.steps * 1e3, 4),
                       "captured": any(isinstance(e, dict) for e in model._graphs.values()),
-                      "note": "use_graph=True: the whole step (about 130 dispatches) replayed from one captured hipGraph"}
+                      "note": "use_graph: the whole step (about 120 dispatches) replayed from one captured hipGraph; "
+                              "\"auto\" (default) turns it on where N * M <= 4e6"}
 
     # Gaussian likelihood only, reported beside the headline like `warm` and never as `value`: natgrad_step without the
     # predictive-variance product (t_SVGP(skip_unused_variance=True): under a Gaussian likelihood neither gradient

@@ -135,7 +135,7 @@ class t_SVGP(base_SVGP):
 
     def __init__(self, kernel, likelihood, inducing_variable, *, mean_function=None, num_latent_gps: int = 1,
                  lambda_1=None, lambda_2_sqrt=None, num_data=None, force=False, compute_dtype=None, device=None,
-                 cache_whitened=False, projection="auto", use_graph=False, skip_unused_variance=False,
+                 cache_whitened=False, projection="auto", use_graph="auto", skip_unused_variance=False,
                  overlap_fill=True):
         super().__init__(kernel, likelihood, inducing_variable, mean_function=mean_function,
                          num_latent_gps=num_latent_gps, num_data=num_data, compute_dtype=compute_dtype, device=device)
@@ -161,7 +161,10 @@ class t_SVGP(base_SVGP):
             raise ValueError("projection must be 'auto', 'whitened', 'direct' or 'projected'")
         self.projection = projection
         self._cond_cache = None
-        # Opt-in: replay natgrad_step from a captured hipGraph (see _graph_step); pays off when the step is launch bound
+        # Replay natgrad_step from a captured hipGraph (see _graph_step): True, False or "auto" (by problem size, where
+        # the step is launch bound; see _wants_graph)
+        if use_graph not in (True, False, "auto"):
+            raise ValueError('use_graph must be True, False or "auto"')
         self.use_graph = use_graph
         self._graphs = {}
         # Opt-in, Gaussian likelihood only: natgrad_step skips the predictive-variance product.  The reference computes
@@ -547,7 +550,7 @@ class t_SVGP(base_SVGP):
         synchronisation; one device->host read of the status flags ends it."""
         X, Y = self._as_device(data[0]), self._as_device(data[1])
         routes = self._routes(jitter)
-        if self.use_graph and self._graph_step(X, Y, lr, jitter, routes):
+        if self._wants_graph(X) and self._graph_step(X, Y, lr, jitter, routes):
             return
         old_l1, old_L = self.lambda_1.value, self.lambda_2_sqrt.value
         while True:
@@ -592,6 +595,18 @@ class t_SVGP(base_SVGP):
         return self._apply_site_update(st, ops, lr, jitter, inplace=inplace)
 
     # -- hipGraph replay of the step (launch-bound problem sizes) -------------------------------------------------
+    GRAPH_AUTO_MAX_NM = 4_000_000  # "auto": replay when N * M is at most this (tools/bench_graph.py)
+
+    def _wants_graph(self, X) -> bool:
+        """use_graph = True / False, or "auto" (the default): replay from a captured graph where the step is launch
+        bound.  Measured eager -> replay, E-steps/s (tools/bench_graph.py): N=1000, M=32: 981 -> 1765; 2000 x 64:
+        1102 -> 2483; 5000 x 128: 1206 -> 2035; 20000 x 128: 1124 -> 1492; 20000 x 256: 702 -> 755; 50000 x 512:
+        518 -> 534 -- beyond a few million kernel-matrix entries the GPU time dominates and a graph (which owns its
+        work buffers, K(X, Z) among them) only costs memory."""
+        if self.use_graph == "auto":
+            return X.shape[0] * self.num_inducing <= self.GRAPH_AUTO_MAX_NM
+        return bool(self.use_graph)
+
     def _graph_step(self, X, Y, lr, jitter, routes) -> bool:
         """Runs the step by replaying a captured graph (torch.cuda.CUDAGraph = hipGraph on ROCm).  A step is ~130
         dispatches; at small N and M (BASELINE configs[0]) launching them costs more than running them.  The graph is
@@ -600,8 +615,10 @@ class t_SVGP(base_SVGP):
         key runs eagerly (library handles, buffers), the second captures, later ones replay.  Returns False when the
         caller should run eagerly (not capturable, first occurrence, or the replayed step failed its status check: the
         state has been restored and the eager path raises or retries exactly as without graphs)."""
+        if self.device.type != "cuda":
+            return False
         eng = self._get_engine()
-        if (D_.world_size() > 1 or self.cache_whitened or eng.profile is not None or self.device.type != "cuda"
+        if (D_.world_size() > 1 or self.cache_whitened or eng.profile is not None
                 or isinstance(self.kernel, SeparateIndependent)):
             return False
         lik_v = tuple(p.version for p in vars(self.likelihood).values() if hasattr(p, "version"))
