@@ -627,6 +627,8 @@ class t_SVGP(base_SVGP):
                tuple(routes), self.num_data)
         entry = self._graphs.get(key)
         if entry is None:
+            if len(self._graphs) >= 64:  # ever-changing inputs (fresh minibatch tensors): keep the markers bounded
+                self._graphs = {k: v for k, v in self._graphs.items() if isinstance(v, dict)}
             self._graphs[key] = "seen"
             return False
         l1p, Lp = self.lambda_1, self.sites._lambda_2_sqrt
