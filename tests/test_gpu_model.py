@@ -524,3 +524,28 @@ def test_execution_options_do_not_change_the_step(lik):
         assert relerr(m.lambda_1.numpy(), ref.lambda_1.numpy()) < tol, name
         assert relerr(m.lambda_2.cpu().numpy(), ref.lambda_2.cpu().numpy()) < tol, name
         assert abs(elbos[name] - elbos["plain"]) < 1e-10 * abs(elbos["plain"]), name
+
+
+def test_auto_graph_with_changing_minibatches():
+    """use_graph="auto" (the default) at a launch-bound size, fed a DIFFERENT minibatch on every call as fresh host
+    arrays: the device copies tend to land on recycled addresses, so a graph captured for one batch is replayed for
+    another -- it must read the data that is there now.  State against the oracle after every step."""
+    p = pkg()
+    rng = np.random.RandomState(23)
+    X, Y, _ = synthetic(N=2400, M=48, D=3, P=1, lik="bernoulli", seed=12)
+    Z = rng.randn(48, 3) * 1.3
+    hip = p.t_SVGP(p.SquaredExponential(1.0, 1.0), p.Bernoulli(), Z, num_data=2400)
+    ora = O.t_SVGP(O.SquaredExponential(1.0, 1.0), O.Bernoulli(), Z, num_data=2400)
+    assert hip.use_graph == "auto"
+    for i in range(8):
+        sl = slice(300 * i, 300 * (i + 1))
+        hip.natgrad_step((X[sl].copy(), Y[sl].copy()), lr=0.3)
+        ora.natgrad_step((X[sl], Y[sl]), lr=0.3)
+        _compare_state(hip, ora, 1e-8)
+    # and with device tensors that stay put: captured on the second call, replayed afterwards
+    Xd, Yd = torch.as_tensor(X[:300], device="cuda:0"), torch.as_tensor(Y[:300], device="cuda:0")
+    for i in range(5):
+        hip.natgrad_step((Xd, Yd), lr=0.3)
+        ora.natgrad_step((X[:300], Y[:300]), lr=0.3)
+        _compare_state(hip, ora, 1e-8)
+    assert any(isinstance(e, dict) for e in hip._graphs.values())
