@@ -15,7 +15,13 @@ through the same HIP kernels; only the M x M prelude / epilogue differ:
   lambda_1 += .. Kuu (G0 - 2 G1 meanZ)                      Kuu G1 Kuu = Mj S2 Mj^T,  Mj = Kuu K9^-1 = I - jitter K9^-1
   Lambda_2 += .. -2 Kuu G1 Kuu                              (the product with Mj is benign: no cancellation with K^-1)
 
-since  |LA^-1 k|^2 - |LR^-1 k|^2 = b^T (I - (I + G)^-1) b  with  G = U6^-1 E U6^-T = H H^T  and
+Direct route (``projection="auto"`` takes it when cond(K6) <= DIRECT_MAX_COND): no N-sized whitening.  With
+Q = K6^-1 - R^-1 = (T U6^-1)^T (T U6^-1) formed and factorised in M x M (Q = Lq Lq^T):  var = kff - |Lq^T k|^2, an upper
+triangular product on K(X, Z) itself;  mean = k^T (U6^-T gamma);  the sums run over k k^T, which is S2 directly.  One
+N M^2 product fewer (56 -> 40 ms at N = 1e6, M = 1024); forming Q squares cond(K6), hence the gate, and a failed
+factorisation of Q sends the call back to the whitened route.
+
+The whitened table rests on  |LA^-1 k|^2 - |LR^-1 k|^2 = b^T (I - (I + G)^-1) b  with  G = U6^-1 E U6^-T = H H^T  and
 I - (I + H H^T)^-1 = H (I + H^T H)^-1 H^T.  The reference's util functions take element [0] of a latent-batched product
 (util.py:87, :425), so the class is only defined for ONE latent GP; more raise NotImplementedError.
 """
@@ -33,13 +39,27 @@ from ..util import cholesky_deferred, info_sum, rev_cholesky
 from .tsvgp import base_SVGP
 
 
+class _DirectRouteFailed(Exception):
+    """The direct projection's own M x M factorisation failed: the caller repeats the call on the whitened route."""
+
+
 class t_SVGP_white(base_SVGP):
     """Class for the t-SVGP model with whitened parameterization (reference tsvgp_white.py:23-246)."""
 
     def __init__(self, kernel, likelihood, inducing_variable, *, mean_function=None, num_latent_gps: int = 1,
-                 lambda_1=None, lambda_2=None, num_data=None, compute_dtype=None, device=None):
+                 lambda_1=None, lambda_2=None, num_data=None, compute_dtype=None, device=None, projection="auto"):
         super().__init__(kernel, likelihood, inducing_variable, mean_function=mean_function,
                          num_latent_gps=num_latent_gps, num_data=num_data, compute_dtype=compute_dtype, device=device)
+        if projection not in ("auto", "whitened", "direct"):
+            raise ValueError("projection must be 'auto', 'whitened' or 'direct'")
+        # "whitened": b = U6^-1 k by an N-sized triangular product, moments and sums on b (any K_uu the reference can
+        # factorise).  "direct": no N-sized whitening -- the moments act on k with the triangular factor of
+        # Q = K6^-1 - R^-1 = (T U6^-1)^T (T U6^-1), formed and factorised in M x M, and the sums are taken over k k^T, which
+        # is what the update needs (Kuu G1 Kuu = Mj (sum g1 k k^T) Mj^T).  Forming Q squares cond(K6), hence "auto":
+        # direct when cond(K6) <= DIRECT_MAX_COND, and back to whitened if the factorisation of Q fails.
+        self.projection = projection
+        self._cond_cache = None
+        self._direct_failed = False
         if isinstance(kernel, SeparateIndependent):
             raise NotImplementedError("t_SVGP_white takes one shared kernel (util.py:52-56 asserts Kuu [M, M])")
         self.num_inducing = self.inducing_variable.num_inducing
@@ -78,7 +98,7 @@ class t_SVGP_white(base_SVGP):
             return a.to(self.device)
         return torch.as_tensor(np.asarray(a)).to(self.device)
 
-    def _operands(self, jitter=None, *, kuu_jitter=None, lambda_1=None, lambda_2=None):
+    def _operands(self, jitter=None, *, kuu_jitter=None, lambda_1=None, lambda_2=None, direct=False):
         """Everything the N-pass needs (see the table in the module docstring); with ``jitter`` also K9^-1 for the
         site update.  No host synchronisation: factorisation statuses go to ops["infos"].
         ``kuu_jitter`` (default: gpflow's default_jitter, as predict_f) is the jitter of the K_uu the conditional is built
@@ -103,23 +123,69 @@ class t_SVGP_white(base_SVGP):
         Tm = (Cinv[0] @ H.transpose(-1, -2)).tril()
         v = Uinv6 @ l1
         gamma = v - Tm.transpose(-1, -2) @ (Tm @ v)
-        ops = dict(Z=Z, Kzz=Kzz, K6=K6, Id=Id, infos=infos, U6=U6, Uinv6=Uinv6, moment_Tm=Tm[None], gamma=gamma)
+        ops = dict(Z=Z, Kzz=Kzz, K6=K6, Id=Id, infos=infos, U6=U6, Uinv6=Uinv6, moment_Tm=Tm[None], gamma=gamma,
+                   moment_mode=B.TRI_LOWER, whiten_T=Uinv6, direct=False, direct_info=None)
+        if direct:
+            # var = kff - k^T Q k with Q = U6^-T T^T T U6^-1 = K6^-1 - R^-1; Q = Lq Lq^T gives |Lq^T k|^2, an UPPER
+            # triangular product on K(X, Z) itself; mean = k^T (U6^-T gamma)
+            G = Tm @ Uinv6
+            Q = G.transpose(-1, -2) @ G
+            dinfo = []
+            Lq = cholesky_deferred(Q[None], dinfo, potrf, overwrite=True)
+            ops.update(moment_Tm=Lq.transpose(-1, -2).contiguous(), moment_mode=B.TRI_UPPER, whiten_T=None, direct=True,
+                       gamma=Uinv6.transpose(-1, -2) @ gamma, direct_info=dinfo)
         if jitter is not None:
             ops["K9inv"] = Uinv[2].transpose(-1, -2) @ Uinv[2]
         return ops
 
     def _run(self, X, Y, ops, lik_id, sites=False, want_moments=False):
-        return self._get_engine().run(X, Y, ops["Z"], self.kernel, moment_Tm=ops["moment_Tm"], moment_mode=B.TRI_LOWER,
+        return self._get_engine().run(X, Y, ops["Z"], self.kernel, moment_Tm=ops["moment_Tm"], moment_mode=ops["moment_mode"],
                                       gamma=ops["gamma"], lik_id=lik_id, lik_param=self.likelihood.lik_param,
-                                      whiten_T=ops["Uinv6"], whiten_mode=B.TRI_UPPER, sites=sites,
+                                      whiten_T=ops["whiten_T"], whiten_mode=B.TRI_UPPER, sites=sites,
                                       want_moments=want_moments)
 
     def _check(self, ops, nonpos):
-        flags = torch.cat([info_sum(ops["infos"]), nonpos.reshape(1).to(torch.float64)]).cpu()
+        parts = [info_sum(ops["infos"]), nonpos.reshape(1).to(torch.float64)]
+        if ops.get("direct_info"):
+            parts.append(info_sum(ops["direct_info"]))
+        flags = torch.cat(parts).cpu()
         if float(flags[0]) != 0:
             raise FloatingPointError("Cholesky decomposition was not successful (matrix not positive definite)")
+        if len(flags) > 2 and float(flags[2]) != 0:  # Q lost definiteness in M x M: not the reference's failure
+            raise _DirectRouteFailed()
         if not (float(flags[1]) == 0):  # tsvgp_white.py:131
+            if ops.get("direct") and self.projection == "auto":
+                raise _DirectRouteFailed()  # let the whitened route decide whether the variance really is non-positive
             raise FloatingPointError(f"non-positive predictive variance at {float(flags[1]):.0f} point(s)")
+
+    # -- projection route ------------------------------------------------------------------------------------------
+    DIRECT_MAX_COND = {torch.float64: 1.0e3, torch.float32: 30.0}
+
+    def _use_direct(self) -> bool:
+        """"auto": direct when cond(K_uu + default_jitter I) is small (one symmetric eigenvalue problem per change of the
+        kernel parameters or Z, decided on rank 0) and the route has not failed since."""
+        if self.projection != "auto":
+            return self.projection == "direct"
+        k, Zp = self.kernel, self.inducing_variable.Z
+        key = (id(k), k.variance.version, k.lengthscales.version, id(Zp), Zp.version)
+        if self._cond_cache is None or self._cond_cache[0] != key:
+            Kzz = self._get_engine().kuu(self._Z(), k)
+            ev = torch.linalg.eigvalsh(Kzz + default_jitter() * torch.eye(Kzz.shape[-1], dtype=Kzz.dtype, device=Kzz.device))
+            cond = torch.where(ev[0] > 0, ev[-1] / ev[0], torch.full_like(ev[0], float("inf"))).reshape(1)
+            self._cond_cache = (key, float(D_.broadcast_from_rank0(cond.contiguous())))
+            self._direct_failed = False
+        return not self._direct_failed and self._cond_cache[1] <= self.DIRECT_MAX_COND[self.compute_dtype]
+
+    def _routed(self, fn):
+        """fn(direct) on the chosen route; a direct attempt that fails in its own M x M algebra is repeated whitened."""
+        if self._use_direct():
+            try:
+                return fn(True)
+            except _DirectRouteFailed:
+                if self.projection != "auto":
+                    raise FloatingPointError("the direct projection lost definiteness; use projection='whitened'")
+                self._direct_failed = True
+        return fn(False)
 
     # -- reference API -----------------------------------------------------------------------------------------
     def get_mean_chol_cov_inducing_posterior(self):
@@ -154,35 +220,44 @@ class t_SVGP_white(base_SVGP):
         """tsvgp_white.py:122-132."""
         if full_cov or full_output_cov:
             raise NotImplementedError("full covariances are not on the E-step hot path")
-        ops = self._operands()
-        st = self._run(self._as_device(Xnew), None, ops, B.LIK_NONE, want_moments=True)
-        self._check(ops, st.nonpos)
-        return st.mean, st.var
+        Xd = self._as_device(Xnew)
+
+        def go(direct):
+            ops = self._operands(direct=direct)
+            st = self._run(Xd, None, ops, B.LIK_NONE, want_moments=True)
+            self._check(ops, st.nonpos)
+            return st.mean, st.var
+
+        return self._routed(go)
 
     def predict_y(self, Xnew):
         return self.likelihood.predict_mean_and_var(*self.predict_f(Xnew))
 
     def elbo(self, data):
         """tsvgp_white.py:162-177; with more than one rank ``data`` is this rank's row shard."""
-        X, Y = data
+        X, Y = self._as_device(data[0]), self._as_device(data[1])
         kl = self.prior_kl()
-        ops = self._operands()
-        st = self._run(self._as_device(X), self._as_device(Y), ops, self.likelihood.lik_id | B.LIK_NOCROP)
-        packed = D_.pack_stats(st, with_sites=False)
-        if self._reduce():
-            D_.all_reduce_sum(packed)
-        _, _, ve_sum, nonpos, rows = D_.unpack_stats(packed, self.num_latent_gps, self.num_inducing, False)
-        self._check(ops, nonpos)
-        scale = (float(self.num_data) / rows) if self.num_data is not None else 1.0
-        return ve_sum * scale - kl
 
-    def _kuu_grad_mu(self, X, Y, jitter=1e-9, kuu_jitter=0.0):
+        def go(direct):
+            ops = self._operands(direct=direct)
+            st = self._run(X, Y, ops, self.likelihood.lik_id | B.LIK_NOCROP)
+            packed = D_.pack_stats(st, with_sites=False)
+            if self._reduce():
+                D_.all_reduce_sum(packed)
+            _, _, ve_sum, nonpos, rows = D_.unpack_stats(packed, self.num_latent_gps, self.num_inducing, False)
+            self._check(ops, nonpos)
+            scale = (float(self.num_data) / rows) if self.num_data is not None else 1.0
+            return ve_sum * scale - kl
+
+        return self._routed(go)
+
+    def _kuu_grad_mu(self, X, Y, jitter=1e-9, kuu_jitter=0.0, direct=False):
         """compute_data_natural_params (tsvgp_white.py:183-212) with K_uu + kuu_jitter I already applied, which is how both
         callers use it: returns (K grad_mu[0] [M, 1], K grad_mu[1] K [1, M, M], rows, nonpos, ops).
         With s1 = sum g0 k, S2 = sum g1 k k^T and K9 = K_uu + jitter I:  grad_mu[0] = K9^-1 (s1 - 2 S2 K9^-1 meanZ),
         grad_mu[1] = K9^-1 S2 K9^-1, so K grad_mu = (I - (jitter - kuu_jitter) K9^-1)(...): no product with an
         ill-conditioned inverse is ever formed."""
-        ops = self._operands(jitter=jitter)
+        ops = self._operands(jitter=jitter, direct=direct)
         # tsvgp_white.py:188-191: no crop of d ve / d var in this class
         st = self._run(X, Y, ops, self.likelihood.lik_id | B.LIK_NOCROP, sites=True)
         packed = D_.pack_stats(st, with_sites=True)
@@ -190,10 +265,13 @@ class t_SVGP_white(base_SVGP):
             D_.all_reduce_sum(packed)
         acc2, acc1, _, nonpos, rows = D_.unpack_stats(packed, self.num_latent_gps, self.num_inducing, True)
         U6, Uinv6, K9inv, Id = ops["U6"], ops["Uinv6"], ops["K9inv"], ops["Id"]
-        S2 = U6 @ acc2 @ U6.transpose(-1, -2)  # sum g1 k k^T   [1, M, M]
-        s1 = U6 @ acc1.transpose(-1, -2)  # sum g0 k     [M, 1]
+        if ops["direct"]:  # the sums were taken over k itself
+            S2, s1, gamma_k = acc2, acc1.transpose(-1, -2), ops["gamma"]
+        else:
+            S2 = U6 @ acc2 @ U6.transpose(-1, -2)  # sum g1 k k^T   [1, M, M]
+            s1 = U6 @ acc1.transpose(-1, -2)  # sum g0 k     [M, 1]
+            gamma_k = Uinv6.transpose(-1, -2) @ ops["gamma"]  # R^-1 lambda_1
         Mj = Id - (jitter - kuu_jitter) * K9inv  # (Kuu + kuu_jitter I) K9^-1
-        gamma_k = Uinv6.transpose(-1, -2) @ ops["gamma"]  # R^-1 lambda_1
         a_meanZ = (Id - jitter * K9inv) @ gamma_k  # K9^-1 meanZ, meanZ = Kuu R^-1 lambda_1 (predict_f at Z, :186)
         KG1K = Mj @ S2 @ Mj.transpose(-1, -2)  # K G1 K
         Kg0 = Mj @ s1 - 2.0 * (Mj @ (S2[0] @ a_meanZ))  # K (G0 - 2 G1 meanZ), util.py:429-438
@@ -202,19 +280,23 @@ class t_SVGP_white(base_SVGP):
     def natgrad_step(self, dataset, lr=0.1, jitter=1e-9):
         """One natural-gradient step on (lambda_1, Lambda_2) (tsvgp_white.py:183-248); returns None."""
         X, Y = self._as_device(dataset[0]), self._as_device(dataset[1])
-        Kg0, KG1K, rows, nonpos, ops = self._kuu_grad_mu(X, Y, jitter=jitter, kuu_jitter=0.0)  # :231: Kuu without jitter
-        scale = (float(self.num_data) / rows) if self.num_data is not None else 1.0
-        lambda_1 = (1.0 - lr) * self.lambda_1.value + lr * scale * Kg0  # :244
-        lambda_2 = (1.0 - lr) * self.lambda_2.value - 2.0 * lr * scale * KG1K  # :241-248 (Lambda_2 = -2 lambda_2)
-        old_l1, old_L2 = self.lambda_1.value, self.lambda_2.value
-        self.lambda_1.assign(lambda_1)
-        self.sites.assign_lambda_2(0.5 * (lambda_2 + lambda_2.transpose(-1, -2)))
-        try:
-            self._check(ops, nonpos)
-        except FloatingPointError:
-            self.lambda_1.assign(old_l1)  # the reference raises before its assigns: leave the state untouched
-            self.sites.assign_lambda_2(old_L2)
-            raise
+
+        def go(direct):
+            Kg0, KG1K, rows, nonpos, ops = self._kuu_grad_mu(X, Y, jitter=jitter, kuu_jitter=0.0, direct=direct)  # :231
+            scale = (float(self.num_data) / rows) if self.num_data is not None else 1.0
+            lambda_1 = (1.0 - lr) * self.lambda_1.value + lr * scale * Kg0  # :244
+            lambda_2 = (1.0 - lr) * self.lambda_2.value - 2.0 * lr * scale * KG1K  # :241-248 (Lambda_2 = -2 lambda_2)
+            old_l1, old_L2 = self.lambda_1.value, self.lambda_2.value
+            self.lambda_1.assign(lambda_1)
+            self.sites.assign_lambda_2(0.5 * (lambda_2 + lambda_2.transpose(-1, -2)))
+            try:
+                self._check(ops, nonpos)
+            except (FloatingPointError, _DirectRouteFailed):
+                self.lambda_1.assign(old_l1)  # the reference raises before its assigns: leave the state untouched
+                self.sites.assign_lambda_2(old_L2)
+                raise
+
+        self._routed(go)
 
     def predict_f_extra_data(self, Xnew, extra_data, jitter=None):
         """Prediction at Xnew conditioned on ``extra_data`` as well (tsvgp_white.py:134-160): the sites receive the

@@ -132,3 +132,53 @@ def test_white_predict_f_extra_data(lik):
         m2, v2 = one.predict_f_extra_data(Xs, extra_data=(Xe, Ye))
         np.testing.assert_array_almost_equal(m1.cpu().numpy(), m2.cpu().numpy(), decimal=4)
         np.testing.assert_array_almost_equal(v1.cpu().numpy(), v2.cpu().numpy(), decimal=4)
+
+
+@pytest.mark.parametrize("lik", ["gaussian", "bernoulli"])
+@pytest.mark.parametrize("projection", ["direct", "whitened", "auto"])
+def test_white_projection_routes_match_oracle(lik, projection):
+    """The direct route of t_SVGP_white (no N-sized whitening: moments on K(X, Z) with the factor of Q = K6^-1 - R^-1,
+    sums over k k^T) and the whitened one are the same algebra; on a well-conditioned K_uu both meet the fp64 tolerance
+    against the oracle and "auto" takes the direct one."""
+    p = pkg()
+    rng = np.random.RandomState(51)
+    X, Y, _ = synthetic(N=1100, M=60, D=5, P=1, lik=lik, seed=9)
+    Z = rng.randn(60, 5) * 1.5
+    mk = lambda mod, **kw: mod.t_SVGP_white(mod.SquaredExponential(1.1, 1.0), mod.Gaussian(0.2) if lik == "gaussian" else mod.Bernoulli(),
+                                            Z, num_data=1100, **kw)
+    hip, ora = mk(p, projection=projection), mk(O)
+    assert hip._use_direct() == (projection != "whitened")
+    for _ in range(5):
+        hip.natgrad_step((X, Y), lr=0.7)
+        ora.natgrad_step((X, Y), lr=0.7)
+        assert relerr(hip.lambda_1.numpy(), ora.lambda_1) < 1e-8
+        assert relerr(hip.lambda_2.numpy(), ora.lambda_2) < 1e-8
+    assert abs(float(hip.elbo((X, Y))) - ora.elbo((X, Y))) < 1e-9 * abs(ora.elbo((X, Y)))
+    mu_h, var_h = hip.predict_f(X[:150] + 0.05)
+    mu_o, var_o = ora.predict_f(X[:150] + 0.05)
+    assert relerr(mu_h.cpu().numpy(), mu_o) < 1e-8 and relerr(var_h.cpu().numpy(), var_o) < 1e-8
+
+
+def test_white_auto_route_gate_and_fallback():
+    """"auto" stays whitened on an ill-conditioned K_uu; a forced direct route on such a K_uu either matches or reports
+    its own failure, and "auto" after a failure keeps working on the whitened route."""
+    p = pkg()
+    X, Y, Z = synthetic(N=800, M=64, D=1, P=1, lik="gaussian", seed=3)  # Z = X[:M] in 1-D: cond(K_uu) huge
+    hip = p.t_SVGP_white(p.SquaredExponential(1.0, 1.0), p.Gaussian(0.1), Z)
+    ora = O.t_SVGP_white(O.SquaredExponential(1.0, 1.0), O.Gaussian(0.1), Z)
+    assert not hip._use_direct()
+    hip.natgrad_step((X, Y), lr=0.8)
+    ora.natgrad_step((X, Y), lr=0.8)
+    assert relerr(hip.lambda_2.numpy(), ora.lambda_2) < 1e-7
+    # simulate a direct-route failure on a model that would choose it
+    rng = np.random.RandomState(4)
+    X2, Y2, _ = synthetic(N=500, M=32, D=4, P=1, lik="gaussian", seed=5)
+    Z2 = rng.randn(32, 4) * 1.5
+    h2 = p.t_SVGP_white(p.SquaredExponential(1.0, 1.0), p.Gaussian(0.1), Z2)
+    o2 = O.t_SVGP_white(O.SquaredExponential(1.0, 1.0), O.Gaussian(0.1), Z2)
+    assert h2._use_direct()
+    h2._direct_failed = True
+    assert not h2._use_direct()
+    h2.natgrad_step((X2, Y2), lr=0.8)
+    o2.natgrad_step((X2, Y2), lr=0.8)
+    assert relerr(h2.lambda_2.numpy(), o2.lambda_2) < 1e-8

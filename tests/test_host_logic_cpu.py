@@ -99,6 +99,34 @@ def test_white_predict_f_extra_data_host_logic():
         assert np.array_equal(hip.lambda_1.numpy(), l1)
 
 
+@pytest.mark.parametrize("lik", ["gaussian", "bernoulli"])
+def test_white_direct_route_host_logic(lik):
+    """t_SVGP_white(projection="direct"): moments on k with the factor of Q = K6^-1 - R^-1, sums over k k^T -- the same
+    step as the oracle's, with the NumPy N-pass plugged in; "auto" picks it on a well-conditioned K_uu."""
+    rng = np.random.RandomState(5)
+    X, Y, _ = synthetic(N=250, M=20, D=3, P=1, lik=lik, seed=8)
+    Z = rng.randn(20, 3) * 1.6  # spread inducing points: cond(K_uu) of order 10
+    hip, ora = _pair(Z, lik, 1, num_data=400, kind="white")
+    assert hip._use_direct()
+    seen = []
+    inner = hip._engine.run
+    hip._engine.run = lambda *a, **k: (seen.append(k.get("whiten_T") is None), inner(*a, **k))[1]
+    for _ in range(4):
+        hip.natgrad_step((X, Y), lr=0.7)
+        ora.natgrad_step((X, Y), lr=0.7)
+        assert relerr(hip.lambda_1.numpy(), ora.lambda_1) < 1e-9
+        assert relerr(hip.lambda_2.numpy(), ora.lambda_2) < 1e-9
+    assert abs(float(hip.elbo((X, Y))) - ora.elbo((X, Y))) < 1e-9 * abs(ora.elbo((X, Y)))
+    mh, vh = hip.predict_f(X[:40] + 0.1)
+    mo, vo = ora.predict_f(X[:40] + 0.1)
+    assert relerr(mh.numpy(), mo) < 1e-9 and relerr(vh.numpy(), vo) < 1e-9
+    assert all(seen)  # no N-sized whitening anywhere
+    hip.projection = "whitened"
+    hip.natgrad_step((X, Y), lr=0.7)
+    ora.natgrad_step((X, Y), lr=0.7)
+    assert relerr(hip.lambda_2.numpy(), ora.lambda_2) < 1e-9 and seen[-1] is False
+
+
 def test_util_functions_match_oracle():
     p = pkg()
     rng = np.random.RandomState(0)
