@@ -315,7 +315,7 @@ class EStepEngine:
             self.se_fill(Xc, Zc, inv_ls, variance, Kfu, kernel.kind)
             done = torch.cuda.Event()
             done.record(side)
-        for t in (Xc, Zc, inv_ls):  # temporaries of the main stream's allocator pool, read on the side stream
+        for t in (Xc, Zc, inv_ls, Kfu):  # blocks of the main stream's allocator pool that the side stream touches
             t.record_stream(side)
         return dict(event=done, key=(X.data_ptr(), tuple(X.shape), Z.data_ptr(), tuple(Z.shape), id(kernel)), Kfu=Kfu)
 
