@@ -37,6 +37,9 @@ namespace {
 
 constexpr int TILE = TSVGP_TILE;  // 128
 constexpr int KC = 16;            // k-chunk of the site-accumulation kernel ([k][row] images)
+#ifndef TSVGP_XTILE
+#define TSVGP_XTILE 1  // panel kernels: request the next column tile's first chunk before the current tile's epilogue
+#endif
 #ifndef TSVGP_CHOL_PRIO
 #define TSVGP_CHOL_PRIO 3  // wave priority of the latency-bound factorisation kernels (s_setprio, 0..3)
 #endif
@@ -560,7 +563,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void panel_kernel(PanelArgs<T> a) {
             __syncthreads();
         }
 
-        auto tile_body = [&](const int it, auto first_tag) {
+        // Registers of the global prefetch (DEPTH chunks in flight, see below).  They live outside the tile body so that
+        // the FIRST chunk of the next column tile can be requested before this tile's epilogue (TSVGP_XTILE): its load
+        // latency then hides behind the square-sum / store of the finished tile instead of opening the next one.
+        constexpr int DEPTH = PanelK<T>::DEPTH;
+        T ra[DEPTH][H], rb[DEPTH][H];
+        bool pre = false;  // ra[0] / rb[0] already hold the first chunk of the tile about to start
+        auto tile_body = [&](const int it, auto first_tag, const int it_next) {
             constexpr bool FIRST = decltype(first_tag)::value;  // FUSE: the tile that also accumulates the mean
             const T* Trow = Tp + (size_t)(it * TILE + srow) * Mp + skh * H;
 
@@ -575,8 +584,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void panel_kernel(PanelArgs<T> a) {
             // but that measured slower (8.68 vs 8.40 ms at N = 1e6, M = 1024), so both types run with one.  A set is
             // chosen by the parity of the chunk index, so every loop below steps by two chunks (all chunk ranges are
             // even); the pairing itself is worth 3 % (fp64) to 6 % (fp32) over a one-chunk loop body.
-            constexpr int DEPTH = PanelK<T>::DEPTH;
-            T ra[DEPTH][H], rb[DEPTH][H];
             int buf = 0;
             // one pipeline step on chunk c_: prefetch chunk c_ + DEPTH to registers, MFMAs on chunk c_ (LDS buffer
             // `buf`), then stage chunk c_ + 1 (fetched one step earlier when DEPTH == 2) into the other buffer;
@@ -614,7 +621,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void panel_kernel(PanelArgs<T> a) {
             const int cd = it * CPT;  // first chunk of the diagonal k-tile (even)
             const int c_first = (TRI == TSVGP_TRI_UPPER) ? cd : 0;
             const int c_end = (TRI == TSVGP_TRI_LOWER) ? cd + CPT : nchunk;
-            TSVGP_FETCH(0, c_first)
+            if (!pre) TSVGP_FETCH(0, c_first)
             TSVGP_STAGE(0, c_first, 0)
             if constexpr (DEPTH == 2) {
                 if (TSVGP_EXP_HASNEXT(c_first + 1 < c_end)) TSVGP_FETCH(1, c_first + 1)
@@ -673,6 +680,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void panel_kernel(PanelArgs<T> a) {
 #undef TSVGP_STEP2
 #undef TSVGP_STAGE
 #undef TSVGP_FETCH
+            pre = false;
+#if TSVGP_XTILE
+            if (DEPTH == 1 && it_next >= 0) {  // request the next tile's first chunk; the epilogue below covers its latency
+                const int cn = (TRI == TSVGP_TRI_UPPER) ? it_next * CPT : 0;
+                load_run<T, H>(ra[0], Arow + cn * KC);
+                load_run<T, H>(rb[0], Tp + (size_t)(it_next * TILE + srow) * Mp + skh * H + cn * KC);
+                pre = true;
+            }
+#endif
 
             if constexpr (MODE == MODE_STORE) {
                 T* Cb = a.C + n0 * (int64_t)Mp + it * TILE + (lane & 15);
@@ -705,14 +721,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void panel_kernel(PanelArgs<T> a) {
                 rs_mine += keep;
             }
         };  // tile_body
+        const auto next_of = [ntile](int it) { return it + 1 < ntile ? it + 1 : -1; };
         if constexpr (FUSE && TRI == TSVGP_TRI_UPPER) {  // upper triangle: the FIRST column tile sweeps every k-chunk
-            tile_body(0, std::true_type{});
-            for (int it = 1; it < ntile; ++it) tile_body(it, std::false_type{});
+            tile_body(0, std::true_type{}, next_of(0));
+            for (int it = 1; it < ntile; ++it) tile_body(it, std::false_type{}, next_of(it));
         } else if constexpr (FUSE) {  // lower triangle: the LAST one does
-            for (int it = 0; it + 1 < ntile; ++it) tile_body(it, std::false_type{});
-            tile_body(ntile - 1, std::true_type{});
+            for (int it = 0; it + 1 < ntile; ++it) tile_body(it, std::false_type{}, next_of(it));
+            tile_body(ntile - 1, std::true_type{}, -1);
         } else {
-            for (int it = 0; it < ntile; ++it) tile_body(it, std::false_type{});
+            for (int it = 0; it < ntile; ++it) tile_body(it, std::false_type{}, next_of(it));
         }
 
         if constexpr (MODE == MODE_MOMENTS) {
