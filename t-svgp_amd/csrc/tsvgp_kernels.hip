@@ -38,7 +38,8 @@ namespace {
 constexpr int TILE = TSVGP_TILE;  // 128
 constexpr int KC = 16;            // k-chunk of the site-accumulation kernel ([k][row] images)
 #ifndef TSVGP_XTILE
-#define TSVGP_XTILE 1  // panel kernels: request the next column tile's first chunk before the current tile's epilogue
+#define TSVGP_XTILE 2  // panel kernels: request the next column tile's first chunk before the current tile's epilogue (1);
+                       // also the first tile's first chunk before gamma is staged (2)
 #endif
 #ifndef TSVGP_CHOL_PRIO
 #define TSVGP_CHOL_PRIO 3  // wave priority of the latency-bound factorisation kernels (s_setprio, 0..3)
@@ -540,7 +541,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void panel_kernel(PanelArgs<T> a) {
         // summed over the 16 lanes that share (lane>>4) and lane lr keeps the one with index lr & 7.
         double rs_mine = 0.0;
         T mpart = T(0);
+        // Registers of the global prefetch (DEPTH chunks in flight, see below).  They live outside the tile body so that
+        // the FIRST chunk of the next column tile can be requested before this tile's epilogue (TSVGP_XTILE): its load
+        // latency then hides behind the square-sum / store of the finished tile instead of opening the next one.
+        constexpr int DEPTH = PanelK<T>::DEPTH;
+        T ra[DEPTH][H], rb[DEPTH][H];
+        bool pre = false;  // ra[0] / rb[0] already hold the first chunk of the tile about to start
         if constexpr (FUSE) {
+#if TSVGP_XTILE >= 2
+            // the first tile (it = 0 for both triangles) starts at chunk 0: its loads fly while gamma is staged
+            load_run<T, H>(ra[0], Arow);
+            load_run<T, H>(rb[0], Tp + (size_t)srow * Mp + skh * H);
+            pre = true;
+#endif
             for (int j = t; j < Mp; j += NTHREADS) gsm[j] = a.gamma[(size_t)j * a.P + p];
             __syncthreads();
         } else if constexpr (MODE == MODE_MOMENTS) {
@@ -563,12 +576,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void panel_kernel(PanelArgs<T> a) {
             __syncthreads();
         }
 
-        // Registers of the global prefetch (DEPTH chunks in flight, see below).  They live outside the tile body so that
-        // the FIRST chunk of the next column tile can be requested before this tile's epilogue (TSVGP_XTILE): its load
-        // latency then hides behind the square-sum / store of the finished tile instead of opening the next one.
-        constexpr int DEPTH = PanelK<T>::DEPTH;
-        T ra[DEPTH][H], rb[DEPTH][H];
-        bool pre = false;  // ra[0] / rb[0] already hold the first chunk of the tile about to start
         auto tile_body = [&](const int it, auto first_tag, const int it_next) {
             constexpr bool FIRST = decltype(first_tag)::value;  // FUSE: the tile that also accumulates the mean
             const T* Trow = Tp + (size_t)(it * TILE + srow) * Mp + skh * H;
