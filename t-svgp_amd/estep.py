@@ -168,12 +168,23 @@ class EStepEngine:
         self.se_fill(Z, Z, inv_ls, kernel.variance.item(), out, kernel.kind)
         return out[:M, :M].contiguous()
 
-    def cholesky(self, A: torch.Tensor, inverse: bool = False, overwrite: bool = False):
+    def cholesky(self, A: torch.Tensor, inverse: bool = False, overwrite: bool = False, robust: bool = False):
         """Batched lower Cholesky on the GPU through ``tsvgp_potrf_f64`` (no host synchronisation).
         A [.., M, M] fp64 (lower triangle referenced) -> (L [.., M, M] with zeros above the diagonal, info [batch] int32);
         with ``inverse`` also inv(L) (``tsvgp_potrf_inv_f64``), lower triangular with exact zeros above.
-        ``overwrite``: A is a temporary of the caller and may be factored in place (no copy when M is a multiple of 128)."""
+        ``overwrite``: A is a temporary of the caller and may be factored in place (no copy when M is a multiple of 128).
+        ``robust``: factor by substitution (rocSOLVER potrf + a triangular solve for the inverse) instead: the blocked
+        kernel solves its panels by multiplying with the INVERTED diagonal block, which costs it a factor cond(L_kk) of
+        accuracy in the trailing matrix -- irrelevant for the matrices of a well-conditioned K_uu (and 4x faster), but a
+        numerically barely definite matrix (cond ~ 1e14, lambda_min ~ 30 eps lambda_max) then fails where LAPACK-style
+        factorisations go through.  The callers ask for it on the "projected" route, whose matrices are of that kind."""
         A = A.to(device=self.device, dtype=torch.float64)
+        if robust:
+            L, info = torch.linalg.cholesky_ex(A, upper=False, check_errors=False)
+            if not inverse:
+                return L, info
+            eye = torch.eye(A.shape[-1], dtype=torch.float64, device=self.device)
+            return L, info, torch.linalg.solve_triangular(L, eye.expand_as(L), upper=False)
         M = A.shape[-1]
         batch_shape = A.shape[:-2]
         Mp = B.round_up(M)
@@ -322,7 +333,7 @@ class EStepEngine:
     # ------------------------------------------------------------------ one N-pass
     def run(self, X, Y, Z, kernel, *, moment_Tm, moment_mode, gamma, lik_id=B.LIK_NONE, lik_param=0.0,
             whiten_T=None, whiten_mode=B.TRI_UPPER, project_T=None, sites=False, want_moments=False, want_grads=False,
-            b_tag=None, mean_only=False, prefill=None) -> EStepStats:
+            b_tag=None, mean_only=False, prefill=None, moments_on_kfu=False, project_mode=B.TRI_LOWER) -> EStepStats:
         """One pass over the shard's rows.
 
         X [N, D], Y [N, P] (or None when lik_id == NONE), Z [M, D];
@@ -337,6 +348,9 @@ class EStepEngine:
         b_tag: a hashable description of (X, Z, kernel parameters, jitter).  When it equals the tag of the B buffer left
         by the previous call, the fill and the whitening are skipped and B is reused ("warm" E-step: consecutive
         E-steps with unchanged hyperparameters, as in the reference's E/M loop, experiments/uci_regression.py:152-153).
+        moments_on_kfu (with whiten_T): the moments act on K(X, Z) itself (moment_Tm / gamma in k coordinates) and only the
+        site sums use the whitened / projected operand, whose products then run AFTER the moments: the variant in
+        which nothing on the moments side depends on the factor of K_uu + jitter I.  project_mode: triangle of project_T.
         prefill: the ticket of ``start_fill`` for the same (X, Z, kernel): the fill is already under way on the side
         stream; this call waits for it instead of filling.
         mean_only (likelihood NONE or GAUSSIAN): skip the variance product of the moments (TSVGP_LIK_MEANONLY) -- the
@@ -346,7 +360,7 @@ class EStepEngine:
             return self._run_separate(X, Y, Z, kernel, moment_Tm=moment_Tm, moment_mode=moment_mode, gamma=gamma,
                                       lik_id=lik_id, lik_param=lik_param, whiten_T=whiten_T, whiten_mode=whiten_mode,
                                       project_T=project_T, sites=sites, want_moments=want_moments, want_grads=want_grads,
-                                      mean_only=mean_only)
+                                      mean_only=mean_only, moments_on_kfu=moments_on_kfu, project_mode=project_mode)
         if mean_only and (lik_id & 0xFF) not in (B.LIK_NONE, B.LIK_GAUSSIAN):
             raise ValueError("mean_only needs a likelihood whose gradients do not depend on the predictive variance")
         T, dev = self.dtype, self.device
@@ -370,6 +384,9 @@ class EStepEngine:
         # The N x M operand of the moments / site kernels: the whitened B = Kfu U^-T, or Kfu itself ("direct" route).
         # A tagged operand left by the previous call is reused when the tag matches (warm E-steps).
         want = "B" if whiten_T is not None else "Kfu"
+        late_whiten = moments_on_kfu and whiten_T is not None
+        if late_whiten:
+            b_tag = None  # K(X, Z) and B are both consumed in this pass: nothing to carry over
         reuse = (b_tag is not None and self._b_tag == (want, b_tag) and self._buf.get(want) is not None
                  and tuple(self._buf[want].shape) == (Np, Mp))
         if reuse:
@@ -386,7 +403,7 @@ class EStepEngine:
                     torch.cuda.current_stream(dev).wait_stream(self._side)
                 self.se_fill(X, Z, inv_ls, variance, Kfu, kernel.kind)
             A = Kfu
-            if whiten_T is not None:
+            if whiten_T is not None and not late_whiten:
                 Bw = self._get("B", (Np, Mp), T)
                 self.trmm(Kfu, self._pad_square(whiten_T, Mp, "pad_Linv"), Bw, whiten_mode)
                 A = Bw
@@ -416,11 +433,15 @@ class EStepEngine:
         if want_grads and need_g:
             stats.g0, stats.g1 = g0[:N].to(torch.float64), g1[:N].to(torch.float64)
 
+        if late_whiten and sites:  # the site sums' operand, now that the moments have read K(X, Z)
+            Bw = self._get("B", (Np, Mp), T)
+            self.trmm(A, self._pad_square(whiten_T, Mp, "pad_Linv"), Bw, whiten_mode)
+            A = Bw
         if sites and project_T is not None:
             if whiten_T is None:
                 raise ValueError("project_T needs whiten_T")
             Aproj = self._get("Kfu", (Np, Mp), T)  # K(X, Z) itself is no longer needed once B exists
-            self.trmm(A, self._pad_square(project_T, Mp, "pad_proj"), Aproj, B.TRI_LOWER)
+            self.trmm(A, self._pad_square(project_T, Mp, "pad_proj"), Aproj, project_mode)
             A = Aproj
         if sites:
             nsplit = self.nsplit_override or self.choose_nsplit(Mp, P)

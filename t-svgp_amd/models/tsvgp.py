@@ -27,6 +27,7 @@ whose error grows like cond(K9)^2 eps; it falls back to the whitened route if th
 from __future__ import annotations
 
 import abc
+import functools
 
 import numpy as np
 import torch
@@ -282,13 +283,22 @@ class t_SVGP(base_SVGP):
         L = self.lambda_2_sqrt.value
         P_ = L.shape[0]
         potrf = getattr(eng, "cholesky", None)  # HIP blocked Cholesky (tsvgp_potrf_f64)
+        if potrf is not None and routes is not None and any(r == "projected" for r in routes):
+            # cond(K_uu + jitter I) beyond 1e7: K9 and the new Lambda_2 are barely definite in fp64 there, and the
+            # factorisation that follows the reference's success / failure is the one by substitution (EStepEngine.cholesky)
+            potrf = functools.partial(potrf, robust=True)
         # W = I + L^T K6 L (util.py:171-172, formed without chol(K6)).  The factorisations of W and K_uu + jitter I are
         # independent and both latency bound (one workgroup per diagonal block): do them in ONE batched call, whose
         # input batch is assembled in place (the addition of I rides on the GEMM; no concatenation).  Only one
         # triangle of W is read, so the rounding-level asymmetry of L^T (K6 L) needs no symmetrisation.
         # The factorisation also returns the inverse factors (tsvgp_potrf_inv_f64) and they are applied as GEMMs: a
         # rocBLAS trsm with an M x M right-hand side costs ~0.25 ms at M = 1024, a GEMM ~0.05 ms.
-        with_k9 = whiten_jitter is not None and not warm
+        # Uniformly "projected" (cond(K9) beyond 1e7): K9 is factored in the REFERENCE's order (plain lower Cholesky,
+        # tsvgp.py:270) in its own call instead of joining the upper-form batch -- that close to singular, whether a
+        # factorisation goes through depends on the elimination order, and the reference's is the one to follow
+        lower9 = (whiten_jitter is not None and routes is not None and len(routes) > 0
+                  and all(r == "projected" for r in routes))
+        with_k9 = whiten_jitter is not None and not warm and not lower9
         n9 = (Kzz.shape[0] if Kzz.dim() == 3 else 1) if with_k9 else 0
         batch = torch.empty((P_ + n9, M, M), dtype=torch.float64, device=Kzz.device)
         torch.baddbmm(Id.expand(P_, M, M), L.transpose(-1, -2), K6 @ L, out=batch[:P_])
@@ -297,8 +307,15 @@ class t_SVGP(base_SVGP):
             batch[P_:].diagonal(dim1=-2, dim2=-1).add_(whiten_jitter)  # K9 = K_uu + jitter I, tsvgp.py:270
         both, inv_both = rev_cholesky(batch, infos, potrf, inverse=True)
         U_W, Uinv_W = both[:P_], inv_both[:P_]
+        L9inv = None
         if with_k9:
             U9, Uinv9 = (both[P_:], inv_both[P_:]) if Kzz.dim() == 3 else (both[-1], inv_both[-1])
+        elif lower9:
+            K9 = Kzz.clone()
+            K9.diagonal(dim1=-2, dim2=-1).add_(whiten_jitter)
+            _, L9inv = cholesky_deferred(K9 if K9.dim() == 3 else K9[None], infos, potrf, inverse=True, overwrite=True)
+            L9inv = L9inv if Kzz.dim() == 3 else L9inv[0]
+            U9, Uinv9 = None, None
         elif whiten_jitter is not None:
             U9, Uinv9 = warm[1]["U9"], warm[1]["Uinv9"]
         else:
@@ -312,6 +329,14 @@ class t_SVGP(base_SVGP):
         if whiten_jitter is None:
             return ops
         ops["U9"], ops["Uinv9"] = U9, Uinv9  # K_uu + jitter I = U9 U9^T, tsvgp.py:268-270
+        ops["moments_on_kfu"], ops["project_mode"] = False, B.TRI_LOWER
+        if lower9:
+            # a = K9^-1 k by two triangular products with the lower factor: b = L9^-1 k, a = L9^-T b; the moments act on
+            # K(X, Z) with D and beta, so nothing on their side depends on the factor of K9
+            ops["routes"] = list(routes)
+            ops.update(gamma=beta, moment_Tm=Dm, whiten_T=L9inv, whiten_mode=B.TRI_LOWER,
+                       project_T=L9inv.transpose(-1, -2).contiguous(), project_mode=B.TRI_UPPER, moments_on_kfu=True)
+            return ops
         if warm_key is not None and not warm:
             self._warm = (warm_key, dict(Kzz=Kzz, U9=U9, Uinv9=Uinv9))
         routes = list(routes) if routes is not None else ["whitened"] * self.num_latent_gps
@@ -384,14 +409,15 @@ class t_SVGP(base_SVGP):
 
     # -- predictions -------------------------------------------------------------------------------------------
     def predict_f(self, Xnew, full_cov=False, full_output_cov=False):
-        """Posterior prediction at new input Xnew [N, D] (tsvgp.py:97-114) through the whitened route the E-step uses."""
+        """Posterior prediction at new input Xnew [N, D] (tsvgp.py:97-114): mean = k^T beta, var = knn - |D k|^2 on
+        K(Xnew, Z) itself -- the reference's conditional only involves K_uu + 1e-6 I (tsvgp.py:209-211), and so does this
+        form (no factor of K_uu + 1e-9 I, no N-sized whitening)."""
         if full_cov or full_output_cov:
             raise NotImplementedError("full covariances are not on the E-step hot path")
         Xnew = self._as_device(Xnew)
-        ops = self._site_operands(whiten_jitter=1e-9)
-        st = self._get_engine().run(Xnew, None, ops["Z"], self.kernel, moment_Tm=ops["moment_Tm"],
-                                    moment_mode=ops["moment_mode"], gamma=ops["gamma"], whiten_T=ops["whiten_T"],
-                                    whiten_mode=ops["whiten_mode"], want_moments=True)
+        ops = self._site_operands()
+        st = self._get_engine().run(Xnew, None, ops["Z"], self.kernel, moment_Tm=ops["D"], moment_mode=ops["moment_mode"],
+                                    gamma=ops["beta"], want_moments=True)
         self._check_step(ops, st.nonpos)
         return st.mean, st.var
 
@@ -590,6 +616,7 @@ class t_SVGP(base_SVGP):
                      moment_mode=ops["moment_mode"], gamma=ops["gamma"],
                      lik_id=self.likelihood.lik_id, lik_param=self.likelihood.lik_param,
                      whiten_T=ops["whiten_T"], whiten_mode=ops["whiten_mode"], project_T=ops["project_T"],
+                     moments_on_kfu=ops["moments_on_kfu"], project_mode=ops["project_mode"],
                      sites=True, b_tag=warm_key,
                      mean_only=self.skip_unused_variance and self.likelihood.lik_id == B.LIK_GAUSSIAN)
         return self._apply_site_update(st, ops, lr, jitter, inplace=inplace)
@@ -619,7 +646,8 @@ class t_SVGP(base_SVGP):
             return False
         eng = self._get_engine()
         if (D_.world_size() > 1 or self.cache_whitened or eng.profile is not None
-                or isinstance(self.kernel, SeparateIndependent)):
+                or isinstance(self.kernel, SeparateIndependent)
+                or any(r == "projected" for r in routes)):  # its rocSOLVER factorisations cannot be captured
             return False
         lik_v = tuple(p.version for p in vars(self.likelihood).values() if hasattr(p, "version"))
         key = (X.data_ptr(), Y.data_ptr(), tuple(X.shape), tuple(Y.shape), X.dtype, Y.dtype, self._kernel_versions(),
@@ -687,7 +715,7 @@ class t_SVGP(base_SVGP):
         acc2, acc1, _, nonpos, rows = D_.unpack_stats(packed, P, M, True)
 
         Uinv9, Kzz, beta = ops["Uinv9"], ops["Kzz"], ops["beta"]
-        Uinv9t = Uinv9.transpose(-1, -2)
+        Uinv9t = Uinv9.transpose(-1, -2) if Uinv9 is not None else None  # None: projected route on the lower factor
         routes = ops["routes"]
         forms = {}
         if "direct" in routes:

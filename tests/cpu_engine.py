@@ -21,7 +21,7 @@ class NumpyShardEngine:
 
     def run(self, X, Y, Z, kernel, *, moment_Tm, moment_mode, gamma, lik_id=0, lik_param=0.0, whiten_T=None,
             whiten_mode=1, project_T=None, sites=False, want_moments=False, want_grads=False, b_tag=None,
-            mean_only=False, prefill=None):
+            mean_only=False, prefill=None, moments_on_kfu=False, project_mode=0):
         if hasattr(kernel, "kernels"):  # one pass per latent, as EStepEngine._run_separate
             parts = [self.run(X, None if Y is None else Y[:, p:p + 1], Z, kp, moment_Tm=moment_Tm[p:p + 1],
                               moment_mode=moment_mode, gamma=gamma[:, p:p + 1], lik_id=lik_id, lik_param=lik_param,
@@ -30,7 +30,7 @@ class NumpyShardEngine:
                               whiten_mode=whiten_mode, sites=sites, want_moments=want_moments, want_grads=want_grads,
                               project_T=(project_T[p] if isinstance(project_T, (list, tuple)) else None if project_T is None
                                          else (project_T[p] if project_T.dim() == 3 else project_T)),
-                              mean_only=mean_only)
+                              mean_only=mean_only, moments_on_kfu=moments_on_kfu, project_mode=project_mode)
                      for p, kp in enumerate(kernel.kernels)]
             st = _Stats()
             st.n_rows = parts[0].n_rows
@@ -43,12 +43,13 @@ class NumpyShardEngine:
         Xn, Zn = X.cpu().numpy(), Z.cpu().numpy()
         A = k.K(Xn, Zn)
         tri = {0: np.tril, 1: np.triu, 2: lambda a: a}  # the kernels only read the triangle the mode names
-        if whiten_T is not None:
-            A = A @ tri[whiten_mode](whiten_T.cpu().numpy()).T
+        Aw = A if whiten_T is None else A @ tri[whiten_mode](whiten_T.cpu().numpy()).T
+        Am = A if moments_on_kfu else Aw  # operand of the moments
+        A = Aw  # operand of the site sums
         Tm = tri[moment_mode](moment_Tm.cpu().numpy())
-        C = np.einsum("nj,pij->pni", A, Tm)
+        C = np.einsum("nj,pij->pni", Am, Tm)
         q = np.sum(C * C, axis=-1).T
-        mean = A @ gamma.cpu().numpy()
+        mean = Am @ gamma.cpu().numpy()
         var = k.variance - q
         st = _Stats()
         st.n_rows = Xn.shape[0]
@@ -65,7 +66,7 @@ class NumpyShardEngine:
             g1 = np.minimum(g1, -1e-8) if crop else g1
             st.ve_sum = torch.tensor(float(np.sum(lik.variational_expectations(mean, var, Yn))), dtype=torch.float64)
             if sites:
-                As = A if project_T is None else A @ np.tril(project_T.cpu().numpy()).T  # projected route: a = U9^-T b
+                As = A if project_T is None else A @ tri[project_mode](project_T.cpu().numpy()).T  # projected route: a = K9^-1 k
                 st.acc2 = torch.as_tensor(np.einsum("nm,no,nl->lmo", As, As, g1))
                 st.acc1 = torch.as_tensor(np.einsum("nm,nl->lm", As, g0))
         if mean_only:  # TSVGP_LIK_MEANONLY: no variance, no variational expectation; non-finite rows are counted

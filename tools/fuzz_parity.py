@@ -50,7 +50,10 @@ for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
             e = float("inf")
         except FloatingPointError:
             e = 0.0
-    worst = max(worst, e / max(1.0, cond * 2.2e-16 * 1e8 * 10))  # tolerance 1e-8, or 10 cond eps where that is larger
+    # tolerance 1e-8, or 100 cond eps where that is larger: the ORACLE's own rounding error is of that size (seed 5,
+    # trial 15: white model, cond 1e7 -- against an extended-precision solve the HIP predictive mean is off by 4e-9, the
+    # oracle's by 1.6e-7)
+    worst = max(worst, e / max(1.0, cond * 2.2e-16 * 1e8 * 100))
     print(f"trial {trial:2d} N={N} M={M} D={D} P={P} {lik} {kname} {'white' if white else route} cond {cond:.1e} max err {e:.1e}", flush=True)
-print("worst error relative to the tolerance max(1e-8, 10 cond eps), in units of 1e-8:", worst / 1e-8)
+print("worst error relative to the tolerance max(1e-8, 100 cond eps), in units of 1e-8:", worst / 1e-8)
 sys.exit(0 if worst < 1e-8 else 1)
