@@ -27,6 +27,8 @@ I - (I + H H^T)^-1 = H (I + H^T H)^-1 H^T.  The reference's util functions take 
 """
 from __future__ import annotations
 
+import functools
+
 import numpy as np
 import torch
 
@@ -108,6 +110,10 @@ class t_SVGP_white(base_SVGP):
         M = Z.shape[0]
         infos = []
         potrf = getattr(eng, "cholesky", None)
+        if potrf is not None and self._cond_k6() > self.ROBUST_MIN_COND:
+            # Lambda_2 + 1e-9 I and K_uu + jitter I are barely definite in fp64 on an ill-conditioned K_uu: the blocked
+            # kernel's inverse-based panels can fail there where a factorisation by substitution goes through
+            potrf = functools.partial(potrf, robust=True)
         Kzz = eng.kuu(Z, self.kernel)
         Id = torch.eye(M, dtype=torch.float64, device=Kzz.device)
         K6 = Kzz + (default_jitter() if kuu_jitter is None else kuu_jitter) * Id
@@ -161,11 +167,11 @@ class t_SVGP_white(base_SVGP):
     # -- projection route ------------------------------------------------------------------------------------------
     DIRECT_MAX_COND = {torch.float64: 1.0e3, torch.float32: 30.0}
 
-    def _use_direct(self) -> bool:
-        """"auto": direct when cond(K_uu + default_jitter I) is small (one symmetric eigenvalue problem per change of the
-        kernel parameters or Z, decided on rank 0) and the route has not failed since."""
-        if self.projection != "auto":
-            return self.projection == "direct"
+    ROBUST_MIN_COND = 1.0e6  # beyond this the factorisations run by substitution (EStepEngine.cholesky(robust=True))
+
+    def _cond_k6(self) -> float:
+        """cond(K_uu + default_jitter I): one symmetric eigenvalue problem per change of the kernel parameters or Z,
+        taken from rank 0."""
         k, Zp = self.kernel, self.inducing_variable.Z
         key = (id(k), k.variance.version, k.lengthscales.version, id(Zp), Zp.version)
         if self._cond_cache is None or self._cond_cache[0] != key:
@@ -174,7 +180,13 @@ class t_SVGP_white(base_SVGP):
             cond = torch.where(ev[0] > 0, ev[-1] / ev[0], torch.full_like(ev[0], float("inf"))).reshape(1)
             self._cond_cache = (key, float(D_.broadcast_from_rank0(cond.contiguous())))
             self._direct_failed = False
-        return not self._direct_failed and self._cond_cache[1] <= self.DIRECT_MAX_COND[self.compute_dtype]
+        return self._cond_cache[1]
+
+    def _use_direct(self) -> bool:
+        """"auto": direct when cond(K_uu + default_jitter I) is small and the route has not failed since."""
+        if self.projection != "auto":
+            return self.projection == "direct"
+        return self._cond_k6() <= self.DIRECT_MAX_COND[self.compute_dtype] and not self._direct_failed
 
     def _routed(self, fn):
         """fn(direct) on the chosen route; a direct attempt that fails in its own M x M algebra is repeated whitened."""
