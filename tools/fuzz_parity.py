@@ -8,9 +8,10 @@ from oracle import tsvgp_oracle as O
 p = importlib.import_module("t-svgp_amd")
 rng = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 worst = 0.0
+MAXN, MAXM = int(os.environ.get("FUZZ_MAXN", "3000")), int(os.environ.get("FUZZ_MAXM", "300"))  # larger: slower oracle
 rel = lambda a, b: float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
 for trial in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
-    N, M, D, P = int(rng.randint(1, 3000)), int(rng.randint(1, 300)), int(rng.randint(1, 9)), int(rng.randint(1, 4))
+    N, M, D, P = int(rng.randint(1, MAXN)), int(rng.randint(1, MAXM)), int(rng.randint(1, 9)), int(rng.randint(1, 4))
     lik = ["gaussian", "bernoulli"][rng.randint(2)]
     kname = ["SquaredExponential", "Matern52", "Matern32"][rng.randint(3)]
     route = ["auto", "whitened", "direct", "projected"][rng.randint(4)]
