@@ -36,7 +36,7 @@ def main():
                       X[: args.m].copy(), num_data=X.shape[0])
     t0 = time.perf_counter()
     logf, nlpd = gp.training.em_fit(model, (Xd, Yd), iterations=args.iters, n_e_steps=8, n_m_steps=20, nat_lr=0.8,
-                                    adam_lr=0.01, test_data=(Xt, Yt))
+                                    adam_lr=0.1, test_data=(Xt, Yt))  # experiments/uci_regression.py:20
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     for i, (e, n) in enumerate(zip(logf, nlpd)):

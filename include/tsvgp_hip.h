@@ -10,8 +10,13 @@
  * Conventions
  *   - extern "C", plain pointers and sizes; no torch / C++ types.
  *   - All pointers are DEVICE pointers (caller-allocated, caller-owned); `stream` is a
- *     hipStream_t passed as void* (NULL = default stream).  No global state, no
- *     allocation, no synchronisation inside: safe to capture into a hipGraph.
+ *     hipStream_t passed as void* (NULL = default stream).  No allocation and no
+ *     synchronisation inside: safe to capture into a hipGraph.  The only process-wide
+ *     state is one "dynamic-LDS opt-in done" flag per (kernel, device) for the two
+ *     kernels that use more than 64 KB of LDS (set on first use, thread-safe; any
+ *     device of the process may be current).
+ *   - Input dimension limits: D <= 32 for the fill (tsvgp_kernel_fill_*), D <= 16 for the
+ *     M-step gradient contraction (tsvgp_kernel_grad_*); larger D returns 1.
  *   - Suffix _f64 / _f32 selects the arithmetic type T of the N-sized arrays.
  *   - "Padded" dimensions: Np = N rounded up to 128, Mp = M rounded up to 128.  Work
  *     buffers (Kfu, B) are [Np x Mp] row-major with the padding ZERO-filled by the

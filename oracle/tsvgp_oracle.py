@@ -302,8 +302,15 @@ class Bernoulli:
         return g0, g1
 
     def predict_mean_and_var(self, Fmu, Fvar):
+        """Bernoulli._predict_mean_and_var with the probit link [ext]: closed form p = inv_probit(m / sqrt(1 + v))."""
         p = inv_probit(Fmu / np.sqrt(1.0 + Fvar))
         return p, p - p * p
+
+    def predict_log_density(self, Fmu, Fvar, Y):
+        """Bernoulli._predict_log_density [ext]: logdensities.bernoulli(Y, p) with p the predictive mean, summed over the
+        output columns (what experiments/uci_classification.py:139 averages into the NLPD)."""
+        p = self.predict_mean_and_var(Fmu, Fvar)[0]
+        return np.sum(np.log(np.where(np.asarray(Y) == 1, p, 1.0 - p)), axis=-1)
 
 
 # --------------------------------------------------------------------------
@@ -814,3 +821,47 @@ def gpr_predict_f(kernel, X, Y, noise_variance, Xnew):
     mean = A.T @ V
     var = kernel.K_diag(Xnew) - np.sum(A * A, 0)
     return mean, np.tile(var[:, None], [1, Y.shape[1]])
+
+
+# --------------------------------------------------------------------------
+# row-blocked evaluation of the same quantities (for sizes where the [M, N] temporaries of one call would not fit)
+# --------------------------------------------------------------------------
+def predict_f_chunked(model, Xnew, chunk_rows=20000):
+    """``base_SVGP.predict_f`` (src/models/tsvgp.py:97-114) over row blocks: (m, chol S) once (:102), then GPflow's
+    ``conditional`` [ext] per block of ``chunk_rows`` rows (rows are independent: the same numbers as one call)."""
+    Xnew = np.asarray(Xnew, dtype=np.float64)
+    q_mu, q_sqrt = model.get_mean_chol_cov_inducing_posterior()
+    mus, vrs = [], []
+    for lo in range(0, Xnew.shape[0], chunk_rows):
+        mu, var = conditional(Xnew[lo:lo + chunk_rows], model.inducing_variable, model.kernel, q_mu, q_sqrt=q_sqrt,
+                              white=False)
+        if not np.all(var > 0):  # :113
+            raise FloatingPointError("predict_f: non-positive predictive variance")
+        mus.append(mu)
+        vrs.append(var)
+    return np.concatenate(mus), np.concatenate(vrs)
+
+
+def elbo_chunked(model, data, chunk_rows=20000, progress=None):
+    """``base_SVGP.elbo`` (src/models/tsvgp.py:79-95) with the sum over the N rows taken block by block: the M x M part
+    (posterior factorisation :102, prior KL :65-70) once, then ``conditional`` [ext] + ``variational_expectations``
+    [ext] per block, the block sums added exactly (``math.fsum``).  What ``bench.py`` evaluates on the HIP model's
+    state at N = 1e6, M = 1024 ("ELBO match" half of the metric); ~4 N M^2 flops."""
+    import math
+
+    X, Y = data
+    X = np.asarray(X, dtype=np.float64)
+    Y = np.asarray(Y, dtype=np.float64)
+    kl = model.prior_kl()
+    q_mu, q_sqrt = model.get_mean_chol_cov_inducing_posterior()
+    sums = []
+    for lo in range(0, X.shape[0], chunk_rows):
+        mu, var = conditional(X[lo:lo + chunk_rows], model.inducing_variable, model.kernel, q_mu, q_sqrt=q_sqrt,
+                              white=False)
+        if not np.all(var > 0):  # :113
+            raise FloatingPointError("predict_f: non-positive predictive variance")
+        sums.append(float(np.sum(model.likelihood.variational_expectations(mu, var, Y[lo:lo + chunk_rows]))))
+        if progress is not None:
+            progress(min(lo + chunk_rows, X.shape[0]), X.shape[0])
+    scale = (float(model.num_data) / X.shape[0]) if model.num_data is not None else 1.0
+    return math.fsum(sums) * scale - kl

@@ -27,9 +27,9 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <type_traits>
 #include <stdint.h>
-#include <stdlib.h>
 
 #include "tsvgp_hip.h"
 
@@ -1652,6 +1652,23 @@ __global__ void selftest_kernel(const T* a, const T* b, T* c) {
 
 inline int launch_status() { return hipGetLastError() == hipSuccess ? TSVGP_OK : TSVGP_ELAUNCH; }
 
+// Kernels that use more than the default 64 KB of dynamic LDS have to opt in, per kernel and per DEVICE.  The only
+// process-wide state of this library: one "already asked" flag per (kernel, device); setting the attribute twice is
+// harmless, so concurrent first calls need no lock.
+constexpr int MAX_DEVICES = 64;
+struct DynLdsOptIn {
+    std::atomic<unsigned char> done[MAX_DEVICES];
+    int ensure(const void* fn, size_t bytes) {
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0) return TSVGP_ELAUNCH;
+        const bool tracked = dev < MAX_DEVICES;
+        if (tracked && done[dev].load(std::memory_order_acquire)) return TSVGP_OK;
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return TSVGP_ELAUNCH;
+        if (tracked) done[dev].store(1, std::memory_order_release);
+        return TSVGP_OK;
+    }
+};
+
 template <typename T>
 int kernel_fill(int kind, const T* X, const T* Z, const T* inv_ls, T variance, T* K, int64_t N, int M, int D,
                 int64_t ldk, void* stream) {
@@ -1662,10 +1679,9 @@ int kernel_fill(int kind, const T* X, const T* Z, const T* inv_ls, T variance, T
     if (ldk < cols_pad || (ldk % 2) != 0) return TSVGP_EINVAL;
     if (D > 32) return TSVGP_EINVAL;  // input dimensions are padded to a compile-time size (1, 2, 4, 8, 16, 32)
     dim3 grid((unsigned)((rows_pad + FILL_ROWS - 1) / FILL_ROWS), (unsigned)((cols_pad + FILL_COLS - 1) / FILL_COLS));
-    if (const char* cap = getenv("TSVGP_FILL_GRID")) {  // experiment (tools/exp_overlap2.py): fewer, looping workgroups
-        const long c = atol(cap);
-        if (c > 0 && (unsigned)c < grid.x) grid.x = (unsigned)c;
-    }
+#ifdef TSVGP_FILL_GRID_CAP  // experiment build (tools/exp_overlap2.py): fewer, looping workgroups
+    if ((unsigned)(TSVGP_FILL_GRID_CAP) < grid.x) grid.x = (unsigned)(TSVGP_FILL_GRID_CAP);
+#endif
     const int DT = D <= 1 ? 1 : D <= 2 ? 2 : D <= 4 ? 4 : D <= 8 ? 8 : D <= 16 ? 16 : 32;
 #define TSVGP_FILL_LAUNCH(KIND_, DT_)                                                                                 \
     hipLaunchKernelGGL((se_fill_kernel<T, KIND_, DT_>), grid, dim3(NTHREADS), 0, (hipStream_t)stream, X, Z, inv_ls,   \
@@ -1725,14 +1741,9 @@ int moments(const T* A, const T* Tm, const T* gamma, const T* Y, double kdiag, i
     // mean only: the Bernoulli gradients do depend on the variance; gamma [P][Mp] has to fit the LDS
     constexpr size_t MEAN_LDS_MAX = 128 * 1024;
     if (mean_only && (lik_base == TSVGP_LIK_BERNOULLI || var || (size_t)Mp * P * sizeof(T) > MEAN_LDS_MAX)) return TSVGP_EINVAL;
-    if (mean_only) {  // more than the default 64 KB of dynamic LDS has to be asked for (once per type)
-        static bool attr_set = false;
-        if (!attr_set) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mean_lik_kernel<T>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)MEAN_LDS_MAX) != hipSuccess)
-                return TSVGP_ELAUNCH;
-            attr_set = true;
-        }
+    if (mean_only) {
+        static DynLdsOptIn optin;  // one per type T
+        if (optin.ensure(reinterpret_cast<const void*>(&mean_lik_kernel<T>), MEAN_LDS_MAX) != TSVGP_OK) return TSVGP_ELAUNCH;
     }
     lik &= ~TSVGP_LIK_MEANONLY;
     if (lik_base == TSVGP_LIK_NONE) lik = TSVGP_LIK_NONE;
@@ -1837,13 +1848,8 @@ int potrf(double* A, int M, int lda, int batch, int64_t stride, int* info, doubl
     if (inv && (!Xt || !T)) return TSVGP_EINVAL;
     const int nt = M / CH_NB;
     const size_t smem = (size_t)CH_NB * CH_LD * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&potrf_diag_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-            return TSVGP_ELAUNCH;
-        attr_set = true;
-    }
+    static DynLdsOptIn optin;
+    if (optin.ensure(reinterpret_cast<const void*>(&potrf_diag_kernel), smem) != TSVGP_OK) return TSVGP_ELAUNCH;
     hipStream_t st = (hipStream_t)stream;
     const int64_t xstride = (int64_t)M * M;
     if (hipMemsetAsync(info, 0, sizeof(int) * batch, st) != hipSuccess) return TSVGP_ELAUNCH;

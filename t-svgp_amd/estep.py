@@ -24,7 +24,11 @@ from typing import Optional
 import torch
 
 from . import _backend as B
+from .distributed import world_size
 from .kernels import SeparateIndependent
+
+MAX_INPUT_DIM = 32  # the fill kernel pads D to a compile-time size (1, 2, 4, 8, 16, 32)
+MAX_INPUT_DIM_GRAD = 16  # tsvgp_kernel_grad_* (M-step): 1, 2, 4, 8, 16
 
 
 @dataclass
@@ -149,6 +153,9 @@ class EStepEngine:
         """out[Np x Mp] <- K(X, Z) (padding zero) for the stationary kernel ``kind``.  X, Z, inv_ls, out share one dtype."""
         N, D = X.shape
         M = Z.shape[0]
+        if D > MAX_INPUT_DIM:
+            raise ValueError(f"input dimension D = {D} exceeds the HIP fill kernel's limit of {MAX_INPUT_DIM} "
+                             "(include/tsvgp_hip.h: tsvgp_kernel_fill_*)")
         fn = self._fn("tsvgp_kernel_fill", X.dtype)
         with torch.cuda.device(self.device):
             self._launch("tsvgp_se_fill" if N != M or X.data_ptr() != Z.data_ptr() else "tsvgp_se_fill(Kuu)",
@@ -234,6 +241,10 @@ class EStepEngine:
         Z = Z.to(device=dev, dtype=T).contiguous()
         N, D = X.shape
         M = Z.shape[0]
+        if D > MAX_INPUT_DIM_GRAD:
+            raise ValueError(f"input dimension D = {D} exceeds the limit of {MAX_INPUT_DIM_GRAD} of the M-step gradient kernel "
+                             "(include/tsvgp_hip.h: tsvgp_kernel_grad_*); the E-step and the ELBO take D <= "
+                             f"{MAX_INPUT_DIM}")
         Mp = B.round_up(M)
         inv_ls = kernel.inv_lengthscales(D, T, dev)
         rows, Dp = int(self.lib.tsvgp_kernel_grad_rows()), int(self.lib.tsvgp_kernel_grad_dpad(D))
@@ -301,7 +312,7 @@ class EStepEngine:
         ``run``: 3.26 -> 2.6 ms for the pair at N = 1e6, M = 1024 (tools/exp_overlap2.py).  Returns None when there is
         nothing to overlap: separate kernels (one fill per latent), an operand ``run`` would reuse (warm E-steps), a
         stream capture in progress."""
-        if (isinstance(kernel, SeparateIndependent) or self.device.type != "cuda"
+        if (isinstance(kernel, SeparateIndependent) or self.device.type != "cuda" or X.shape[0] == 0
                 or torch.cuda.is_current_stream_capturing()):
             return None
         T, dev = self.dtype, self.device
@@ -370,7 +381,19 @@ class EStepEngine:
         M = Z.shape[0]
         P = moment_Tm.shape[0]
         if N == 0:
-            raise ValueError("empty shard: every rank needs at least one row")
+            # One rank of several may hold no rows (N < world size): it contributes zeros to the all-reduce instead of
+            # raising alone while the other ranks wait in the collective.  A single process with no data is an error.
+            if world_size() == 1:
+                raise ValueError("empty data: natgrad_step / elbo need at least one row")
+            zero = torch.zeros((), dtype=torch.float64, device=dev)
+            st = EStepStats(n_rows=0, ve_sum=zero, nonpos=zero.clone())
+            if sites:
+                st.acc2 = torch.zeros((P, M, M), dtype=torch.float64, device=dev)
+                st.acc1 = torch.zeros((P, M), dtype=torch.float64, device=dev)
+            if want_moments:
+                st.mean = torch.zeros((0, P), dtype=torch.float64, device=dev)
+                st.var = None if mean_only else torch.zeros((0, P), dtype=torch.float64, device=dev)
+            return st
         if X.dim() != 2 or Z.dim() != 2 or Z.shape[1] != D:
             raise ValueError(f"X must be [N, D] and Z [M, D] with equal D, got {tuple(X.shape)} and {tuple(Z.shape)}")
         if lik_id != B.LIK_NONE:

@@ -434,6 +434,18 @@ class t_SVGP(base_SVGP):
         self._check_step(ops, st.nonpos)
         return st.mean, st.var
 
+    def moments_and_gradients(self, data):
+        """The N-sized intermediates of one E-step at the current state, without updating it (tsvgp.py:246-263):
+        mean, var = predict_f(X); g0 = d ve/d mean; g1 = min(d ve/d var, -1e-8).  All [N, P] fp64 on the model device.
+        Not part of the reference's API: what parity checks (tests/, bench.py's ``elbo_match``) read."""
+        X, Y = self._as_device(data[0]), self._as_device(data[1])
+        ops = self._site_operands()
+        st = self._get_engine().run(X, Y, ops["Z"], self.kernel, moment_Tm=ops["D"], moment_mode=ops["moment_mode"],
+                                    gamma=ops["beta"], lik_id=self.likelihood.lik_id, lik_param=self.likelihood.lik_param,
+                                    want_moments=True, want_grads=True)
+        self._check_step(ops, st.nonpos)
+        return st.mean, st.var, st.g0, st.g1
+
     def predict_y(self, Xnew):
         return self.likelihood.predict_mean_and_var(*self.predict_f(Xnew))
 

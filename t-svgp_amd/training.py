@@ -4,7 +4,9 @@ the kernel variance / lengthscales, the Gaussian noise variance and the inducing
 there; the sites are not trainable, src/sites.py:56-63).
 
 GPflow optimises UNCONSTRAINED variables: positive parameters live behind a softplus transform [ext]
-(``gpflow.utilities.positive()``, lower bound 0), the inducing inputs are unconstrained.  ``Adam`` follows
+(``gpflow.utilities.positive()``, lower bound 0; the Gaussian likelihood's variance behind ``positive(lower=1e-6)``, a
+softplus shifted by ``gpflow.likelihoods.Gaussian.DEFAULT_VARIANCE_LOWER_BOUND`` [ext]), the inducing inputs are
+unconstrained.  ``Adam`` follows
 ``tf.optimizers.Adam`` [ext] (beta_1 = 0.9, beta_2 = 0.999, epsilon = 1e-7, bias-corrected step size).
 """
 from __future__ import annotations
@@ -37,20 +39,24 @@ class Adam:
             variables[name] = variables[name] - lr_t * m / (torch.sqrt(v) + self.eps)
 
 
+VARIANCE_LOWER_BOUND = 1e-6  # gpflow.likelihoods.Gaussian: variance = Parameter(..., transform=positive(lower=1e-6)) [ext]
+
+
 def trainable_parameters(model) -> dict:
-    """name -> (Parameter, positive?) for what the reference's M-step trains; the names are those of
-    ``t_SVGP.elbo_and_grads`` ("kernels.<p>.variance" ... with one kernel per latent)."""
+    """name -> (Parameter, lower bound of its shifted-softplus transform, or None when unconstrained) for what the
+    reference's M-step trains; the names are those of ``t_SVGP.elbo_and_grads`` ("kernels.<p>.variance" ... with one
+    kernel per latent)."""
     kern = model.kernel
     if hasattr(kern, "kernels"):  # SeparateIndependent
         out = {}
         for p, k in enumerate(kern.kernels):
-            out[f"kernels.{p}.variance"] = (k.variance, True)
-            out[f"kernels.{p}.lengthscales"] = (k.lengthscales, True)
+            out[f"kernels.{p}.variance"] = (k.variance, 0.0)
+            out[f"kernels.{p}.lengthscales"] = (k.lengthscales, 0.0)
     else:
-        out = {"variance": (kern.variance, True), "lengthscales": (kern.lengthscales, True)}
-    out["Z"] = (model.inducing_variable.Z, False)
+        out = {"variance": (kern.variance, 0.0), "lengthscales": (kern.lengthscales, 0.0)}
+    out["Z"] = (model.inducing_variable.Z, None)
     if hasattr(model.likelihood, "variance"):
-        out["likelihood_variance"] = (model.likelihood.variance, True)
+        out["likelihood_variance"] = (model.likelihood.variance, VARIANCE_LOWER_BOUND)
     return out
 
 
@@ -62,22 +68,22 @@ def m_step(model, data, optimizer: Adam, steps: int = 1):
     for _ in range(steps):
         elbo, grads = model.elbo_and_grads(data)
         u, gu = {}, {}
-        for name, (par, positive) in params.items():
+        for name, (par, lower) in params.items():
             theta = par.value.detach().to(torch.float64)
             g = -grads[name].to(theta.device)  # loss = -ELBO
-            if positive:
-                u[name] = _softplus_inv(theta)
+            if lower is not None:  # theta = lower + softplus(u)
+                u[name] = _softplus_inv(theta - lower)
                 gu[name] = g.reshape(theta.shape) * torch.sigmoid(u[name])  # d theta / d u = sigmoid(u)
             else:
                 u[name], gu[name] = theta, g
         optimizer.step(u, gu)
-        for name, (par, positive) in params.items():
-            par.assign(torch.nn.functional.softplus(u[name]) if positive else u[name])
+        for name, (par, lower) in params.items():
+            par.assign(lower + torch.nn.functional.softplus(u[name]) if lower is not None else u[name])
     return elbo
 
 
 def em_fit(model, data, iterations: int, n_e_steps: int = 8, n_m_steps: int = 20, nat_lr: float = 0.8,
-           adam_lr: float = 0.01, test_data=None, optimizer: Adam = None):
+           adam_lr: float = 0.1, test_data=None, optimizer: Adam = None):
     """The t-SVGP branch of the reference's training loop (experiments/uci_regression.py:132-160; defaults :17-21): per
     iteration ``n_e_steps`` E-steps, the ELBO (and test NLPD) logged, then ``n_m_steps`` M-steps.
     Returns (logf, nlpd)."""

@@ -1,0 +1,81 @@
+"""The benchmark's shape against the oracle: M = 1024 (an 8 x 8 grid of 128-wide tiles, BASELINE.json's metric), D = 8, fp64.
+
+The oracle cannot run N = 1e6, so:
+* the model runs the `ns` workload of bench.py (same generator, same hyperparameters, lr = 0.8) at N of a few thousand
+  rows on every projection route and is compared with the oracle step by step (lambda_1, Lambda_2, ELBO, mean, var, g0, g1);
+* at N = 1e6 the HIP state after two steps is handed to the oracle, which evaluates ``conditional`` +
+  ``variational_expectations`` gradients on a row sample taken across the whole range (every 331st row: all 7813 row
+  panels' worth of launches produced the numbers compared) -- reference src/models/tsvgp.py:97-114, 246-263.
+Tolerances: fp64 max rel err <= 1e-8 on state and moments, |dELBO| / |ELBO| <= 1e-9.
+"""
+import numpy as np
+import pytest
+import torch
+
+import bench
+from oracle import tsvgp_oracle as O
+from tests.helpers import pkg, relerr
+
+pytestmark = pytest.mark.gpu
+
+
+def _ns_problem(N, lik="gaussian"):
+    w = dict(bench.WORKLOADS["ns"], N=N, lik=lik)
+    return bench.make_data(w)
+
+
+def _pair(Z, lik, projection):
+    p = pkg()
+    hip = p.t_SVGP(p.SquaredExponential(1.0, 1.0), p.Gaussian(0.1) if lik == "gaussian" else p.Bernoulli(), Z,
+                   projection=projection)
+    ora = O.t_SVGP(O.SquaredExponential(1.0, 1.0), O.Gaussian(0.1) if lik == "gaussian" else O.Bernoulli(), Z)
+    return hip, ora
+
+
+@pytest.mark.parametrize("lik,projection", [("gaussian", "auto"), ("gaussian", "direct"), ("gaussian", "whitened"),
+                                            ("gaussian", "projected"), ("bernoulli", "auto"), ("bernoulli", "whitened")])
+def test_ns_workload_m1024_matches_oracle(lik, projection):
+    """bench.py's `ns` problem at N = 4500 rows (36 row panels, the last one ragged), M = 1024: two E-steps."""
+    X, Y, Z = _ns_problem(4500, lik)
+    hip, ora = _pair(Z, lik, projection)
+    for _ in range(2):
+        hip.natgrad_step((X, Y), lr=0.8)
+        ora.natgrad_step((X, Y), lr=0.8)
+        assert relerr(hip.lambda_1.numpy(), ora.lambda_1) < 1e-8
+        assert relerr(hip.lambda_2.cpu().numpy(), ora.lambda_2) < 1e-8
+    if projection == "auto":
+        assert hip._routes(1e-9) == ["direct"]  # what bench.py's headline runs (cond(K_uu + 1e-9 I) ~ 5e2)
+    e_h, e_o = float(hip.elbo((X, Y))), float(ora.elbo((X, Y)))
+    assert abs(e_h - e_o) / abs(e_o) < 1e-9
+    mean, var, g0, g1 = hip.moments_and_gradients((X, Y))
+    ora.natgrad_step((X, Y), lr=0.8)  # fills ora.last with the intermediates at the compared state
+    for got, name in ((mean, "mean"), (var, "var"), (g0, "g0"), (g1, "g1")):
+        assert relerr(got.cpu().numpy(), ora.last[name]) < 1e-8, name
+
+
+def test_ns_full_size_row_sample_matches_oracle():
+    """N = 1e6, M = 1024, fp64 (the headline shape): the HIP model's state after two steps goes to the oracle, which
+    recomputes moments and likelihood gradients on every 331st row; ELBO of the sample through both."""
+    N = 1_000_000
+    X, Y, Z = _ns_problem(N)
+    hip, ora = _pair(Z, "gaussian", "auto")
+    Xd, Yd = torch.as_tensor(X, device="cuda:0"), torch.as_tensor(Y, device="cuda:0")
+    for _ in range(2):
+        hip.natgrad_step((Xd, Yd), lr=0.8)
+    ora.sites.lambda_1 = hip.lambda_1.numpy()
+    ora.sites._lambda_2_sqrt = np.tril(hip.lambda_2_sqrt.numpy())
+    mean, var, g0, g1 = hip.moments_and_gradients((Xd, Yd))  # the full-size launch
+    idx = np.arange(0, N, 331)
+    mu_o, var_o = O.predict_f_chunked(ora, X[idx], chunk_rows=1024)
+    g0_o, g1_o = ora.likelihood.variational_expectations_grads(mu_o, var_o, Y[idx])
+    g1_o = np.minimum(g1_o, -1e-8)
+    sel = torch.as_tensor(idx, device="cuda:0")
+    assert relerr(mean[sel].cpu().numpy(), mu_o) < 1e-8
+    assert relerr(var[sel].cpu().numpy(), var_o) < 1e-8
+    assert relerr(g0[sel].cpu().numpy(), g0_o) < 1e-8
+    assert relerr(g1[sel].cpu().numpy(), g1_o) < 1e-8
+    # ELBO on the sample (scaled to N as a minibatch, tsvgp.py:89-94) through both
+    hip.num_data = ora.num_data = N
+    e_h = float(hip.elbo((Xd[sel], Yd[sel])))
+    e_o = float(O.elbo_chunked(ora, (X[idx], Y[idx]), chunk_rows=1024))
+    assert abs(e_h - e_o) / abs(e_o) < 1e-9

@@ -5,8 +5,13 @@ properties of the path.
                         range: the exact property the N-sharded multi-GPU path relies on (fp64: 1e-11 relative).
 * conjugate fixed point -- Gaussian likelihood, lr = 1: one step reaches the optimum, a second step leaves the site
                         parameters and the ELBO unchanged (reference tests/models/test_tsvgp.py:134-145 at N = 1e6).
-* two predictive routes agree -- predict_f (whitened / triangular) == new_predict_f (dense site form), tsvgp.py:215-232.
+* predictions against the oracle -- predict_f / new_predict_f of the N = 1e6 model on a row sample against the oracle's
+                        ``conditional`` (tsvgp.py:97-114) and ``conditional_from_precision_sites`` (util.py:91-185)
+                        evaluated on the HIP model's state.  (predict_f and new_predict_f run the same kernel call here,
+                        so comparing them with each other says nothing.)
+The headline shape (M = 1024, fp64) against the oracle: tests/test_gpu_benchshape.py.
 """
+import numpy as np
 import pytest
 import torch
 
@@ -22,11 +27,13 @@ def _stats(model, X, Y, ops):
                                    whiten_T=ops["whiten_T"], whiten_mode=ops["whiten_mode"], sites=True)
 
 
-@pytest.mark.parametrize("cfg", ["c2_fp64", "c3_fp32"])
+@pytest.mark.parametrize("cfg", ["c2_fp64", "c3_fp32", "ns_fp64"])
 def test_shard_additivity_full_size(cfg):
     p = pkg()
     if cfg == "c2_fp64":
         N, M, D, lik, dt, tol = 1_000_000, 512, 8, "gaussian", torch.float64, 1e-11
+    elif cfg == "ns_fp64":  # the metric's shape: 8 x 8 tiles, 7813 row panels
+        N, M, D, lik, dt, tol = 1_000_000, 1024, 8, "gaussian", torch.float64, 1e-11
     else:
         N, M, D, lik, dt, tol = 1_000_000, 1024, 16, "bernoulli", torch.float32, 2e-4
     X, Y, Z = synthetic(N=N, M=M, D=D, lik=lik, seed=0)
@@ -63,12 +70,19 @@ def test_conjugate_fixed_point_full_size():
     de = abs(float(model.elbo((Xd, Yd))) - e1) / abs(e1)
     print(f"fixed point: d lambda_1 {d1:.2e}, d Lambda_2 {d2:.2e}, d ELBO {de:.2e}")
     assert d1 < 1e-4 and d2 < 1e-8 and de < 1e-8
-    # two predictive routes agree on a row sample
-    Xs = Xd[::997][:1500] + 0.01
+    # predictions on a row sample against the oracle's two predictive forms, evaluated on this model's state
+    from oracle import tsvgp_oracle as O
+
+    ora = O.t_SVGP(O.SquaredExponential(1.0, 1.0), O.Gaussian(0.1), Z)
+    ora.sites.lambda_1 = model.lambda_1.numpy()
+    ora.sites._lambda_2_sqrt = np.tril(model.lambda_2_sqrt.numpy())
+    Xs = X[::997][:1500] + 0.01
     mu_a, var_a = model.predict_f(Xs)
     mu_b, var_b = model.new_predict_f(Xs)
-    assert relerr(mu_a.cpu().numpy(), mu_b.cpu().numpy()) < 1e-9
-    assert relerr(var_a.cpu().numpy(), var_b.cpu().numpy()) < 1e-8
+    mu_o, var_o = ora.predict_f(Xs)  # GPflow conditional on (m, chol S)
+    mu_s, var_s = ora.new_predict_f(Xs)  # conditional_from_precision_sites
+    assert relerr(mu_a.cpu().numpy(), mu_o) < 1e-8 and relerr(var_a.cpu().numpy(), var_o) < 1e-8
+    assert relerr(mu_b.cpu().numpy(), mu_s) < 1e-8 and relerr(var_b.cpu().numpy(), var_s) < 1e-8
 
 
 def test_mstep_gradient_full_size():

@@ -75,7 +75,8 @@ def _moments_ref(A, Tm, gamma, kdiag):
 
 @pytest.mark.parametrize("dtype,tol", DTYPES)
 @pytest.mark.parametrize("lik", ["none", "gaussian", "bernoulli"])
-@pytest.mark.parametrize("N,M,P,mode", [(100, 128, 1, 2), (300, 256, 2, 1), (129, 384, 3, 1)])
+@pytest.mark.parametrize("N,M,P,mode", [(100, 128, 1, 2), (300, 256, 2, 1), (129, 384, 3, 1),
+                                        (600, 1024, 1, 1), (300, 1024, 8, 1)])  # the last two: the benchmark's 8 x 8 tile grid
 def test_moments_and_likelihood_map(engines, dtype, tol, lik, N, M, P, mode):
     eng = engines[dtype]
     B = pkg()._backend
@@ -171,7 +172,8 @@ def test_moments_mean_only(engines, dtype, tol, lik, N, M, P):
 
 
 @pytest.mark.parametrize("dtype,tol", DTYPES)
-@pytest.mark.parametrize("Np,Mp,P,nsplit", [(128, 128, 1, 1), (1024, 256, 2, 3), (640, 384, 1, 7), (4096, 128, 3, 64)])
+@pytest.mark.parametrize("Np,Mp,P,nsplit", [(128, 128, 1, 1), (1024, 256, 2, 3), (640, 384, 1, 7), (4096, 128, 3, 64),
+                                            (1024, 1024, 1, 5), (640, 1024, 8, 3)])  # the benchmark's 36 lower tiles
 def test_site_accum(engines, dtype, tol, Np, Mp, P, nsplit):
     eng = engines[dtype]
     B = pkg()._backend

@@ -549,3 +549,32 @@ def test_auto_graph_with_changing_minibatches():
         ora.natgrad_step((X[:300], Y[:300]), lr=0.3)
         _compare_state(hip, ora, 1e-8)
     assert any(isinstance(e, dict) for e in hip._graphs.values())
+
+
+@pytest.mark.parametrize("separate", [False, True])
+@pytest.mark.parametrize("lik", ["gaussian", "bernoulli"])
+def test_predict_y_and_log_density_match_oracle(lik, separate):
+    """``predict_y`` / ``predict_log_density`` (GPflow GPModel [ext]; the NLPD the reference's drivers log,
+    experiments/uci_regression.py:157, uci_classification.py:139) on held-out points against the oracle, Gaussian and
+    Bernoulli, one shared kernel and one kernel per latent."""
+    p = pkg()
+    P, M, D = 2, 40, 3
+    X, Y, Z = synthetic(N=700, M=M, D=D, P=P, lik=lik, seed=12)
+    Xt, Yt, _ = synthetic(N=150, M=M, D=D, P=P, lik=lik, seed=13)
+    mk = lambda mod: (mod.SeparateIndependent([mod.SquaredExponential(1.0, 0.9), mod.SquaredExponential(0.8, 1.3)])
+                      if separate else mod.SquaredExponential(1.1, 1.2))
+    iv = lambda mod: mod.SharedIndependentInducingVariables(Z) if separate else Z
+    hip = p.t_SVGP(mk(p), p.Gaussian(0.1) if lik == "gaussian" else p.Bernoulli(), iv(p), num_latent_gps=P)
+    ora = O.t_SVGP(mk(O), O.Gaussian(0.1) if lik == "gaussian" else O.Bernoulli(), iv(O), num_latent_gps=P)
+    for _ in range(3):
+        hip.natgrad_step((X, Y), lr=0.8)
+        ora.natgrad_step((X, Y), lr=0.8)
+    ymu_h, yvar_h = hip.predict_y(Xt)
+    ymu_o, yvar_o = ora.predict_y(Xt)
+    assert relerr(ymu_h.cpu().numpy(), ymu_o) < 1e-8 and relerr(yvar_h.cpu().numpy(), yvar_o) < 1e-8
+    ld_h = hip.predict_log_density((Xt, Yt)).cpu().numpy()
+    ld_o = ora.predict_log_density((Xt, Yt))
+    assert ld_h.shape == ld_o.shape == (150,)
+    assert relerr(ld_h, ld_o) < 1e-8
+    nlpd_h, nlpd_o = -float(np.mean(ld_h)), -float(np.mean(ld_o))
+    assert abs(nlpd_h - nlpd_o) < 1e-9 * abs(nlpd_o)

@@ -141,15 +141,17 @@ def test_em_loop_matches_oracle_driven_loop():
                 theta[name] = base
                 grads[name] = g
             u, gu = {}, {}
+            low = {"likelihood_variance": 1e-6}  # gpflow.likelihoods.Gaussian: positive(lower=1e-6) [ext]; others lower 0
             for name in theta:
                 if name == "Z":
                     u[name], gu[name] = torch.as_tensor(theta[name]), torch.as_tensor(-grads[name])
                 else:
-                    u[name] = torch.as_tensor(sp_inv(theta[name]))
-                    gu[name] = torch.as_tensor(-grads[name] / (1.0 + np.exp(-sp_inv(theta[name]))))
+                    un = sp_inv(theta[name] - low.get(name, 0.0))
+                    u[name] = torch.as_tensor(un)
+                    gu[name] = torch.as_tensor(-grads[name] / (1.0 + np.exp(-un)))
             opt.step(u, gu)
             for name in theta:
-                theta[name] = u[name].numpy() if name == "Z" else np.asarray(np.log1p(np.exp(u[name].numpy())))
+                theta[name] = u[name].numpy() if name == "Z" else np.asarray(low.get(name, 0.0) + np.log1p(np.exp(u[name].numpy())))
     assert abs(float(hip.kernel.variance.value) - float(theta["variance"])) < 1e-5
     assert abs(float(hip.kernel.lengthscales.value) - float(theta["lengthscales"])) < 1e-5
     assert abs(float(hip.likelihood.variance.value) - float(theta["likelihood_variance"])) < 1e-5

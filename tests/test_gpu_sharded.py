@@ -56,3 +56,40 @@ def test_two_ranks_on_one_gpu_match_single_process(tmp_path):
     assert relerr(got["g_var"], g1["variance"].cpu().numpy()) < 1e-8
     assert relerr(got["g_ls"], g1["lengthscales"].cpu().numpy()) < 1e-8
     assert relerr(got["g_Z"], g1["Z"].cpu().numpy()) < 1e-7
+
+
+def _worker_empty(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        p = pkg()
+        X, Y, Z = synthetic(N=2, M=2, D=2, seed=3)
+        X, Y = X[:1], Y[:1]  # one row for two ranks: rank 1 holds an empty shard
+        Xs, Ys = p.distributed.shard_rows(X, Y)
+        assert Xs.shape[0] == (1 if rank == 0 else 0)
+        m = p.t_SVGP(p.SquaredExponential(1.0, 1.0), p.Gaussian(0.1), Z, num_data=1, device="cuda:0")
+        Xd, Yd = torch.as_tensor(Xs, device="cuda:0"), torch.as_tensor(Ys, device="cuda:0")
+        m.natgrad_step((Xd, Yd), lr=0.8)
+        e = float(m.elbo((Xd, Yd)))
+        if rank == 0:
+            np.savez(out, l1=m.lambda_1.numpy(), L2=m.lambda_2.cpu().numpy(), elbo=e)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_empty_shard_contributes_zeros(tmp_path):
+    """N < world size: the rank without rows takes part in the all-reduce with zeros instead of raising alone while the
+    others wait (``shard_bounds`` hands it an empty block); a single process with no rows still raises."""
+    out = str(tmp_path / "r0.npz")
+    port = 27500 + (os.getpid() % 2000)
+    mp.spawn(_worker_empty, args=(2, port, out), nprocs=2, join=True)
+    got = np.load(out)
+    X, Y, Z = synthetic(N=2, M=2, D=2, seed=3)
+    ora = O.t_SVGP(O.SquaredExponential(1.0, 1.0), O.Gaussian(0.1), Z, num_data=1)
+    ora.natgrad_step((X[:1], Y[:1]), lr=0.8)
+    assert relerr(got["l1"], ora.lambda_1) < 1e-8 and relerr(got["L2"], ora.lambda_2) < 1e-8
+    assert abs(float(got["elbo"]) - ora.elbo((X[:1], Y[:1]))) < 1e-9 * abs(ora.elbo((X[:1], Y[:1])))
+    p = pkg()
+    m = p.t_SVGP(p.SquaredExponential(1.0, 1.0), p.Gaussian(0.1), Z, device="cuda:0")
+    with pytest.raises(ValueError):
+        m.natgrad_step((X[:0], Y[:0]), lr=0.8)

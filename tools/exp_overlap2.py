@@ -1,4 +1,5 @@
-"""Experiment: the K(X,Z) fill as FEW looping workgroups (TSVGP_FILL_GRID) on a side stream, overlapped with the real
+"""Experiment (historic: the runtime switch TSVGP_FILL_GRID it drove is now the compile-time macro TSVGP_FILL_GRID_CAP; build one
+library per cap with -DTSVGP_FILL_GRID_CAP=<n> and point TSVGP_HIP_LIB at it): the K(X,Z) fill as FEW looping workgroups on a side stream, overlapped with the real
 M x M prelude of the E-step (t_SVGP._site_operands: K_uu fill, GEMMs, batched Cholesky + inverse) on the main stream.
 A saturating grid starves whatever the other queue holds (tools/exp_overlap.py); a grid that is resident at once leaves
 wave slots and LDS on every CU.   usage: python tools/exp_overlap2.py [grid caps ...]"""
