@@ -67,11 +67,11 @@ def make_data(w, seed=0):
     return X, Y, X[: w["M"]].copy()
 
 
-def kernel_flops(w, rows):
+def kernel_flops(w, rows, batched=True, trmm_batch=1):
     """Algorithmic flops per launch of each MFMA kernel for `rows` data rows (triangular/symmetric counts, 2 per FMA)."""
-    M, P = w["M"], (1 if w.get("separate") else w["P"])  # separate kernels: one launch per latent
+    M, P = w["M"], (1 if (w.get("separate") and not batched) else w["P"])  # per-latent path: one launch per latent
     return {
-        "tsvgp_trmm": rows * M * (M + 1),  # B = Kfu L^-T, lower-triangular k-range
+        "tsvgp_trmm": rows * M * (M + 1) * trmm_batch,  # B = Kfu U^-T, triangular k-range (x latents per launch)
         "tsvgp_moments": rows * M * (M + 1) * P + 2 * rows * M * P,  # |F^T b|^2 (upper) + mean GEMV
         "tsvgp_site_accum": rows * M * (M + 1) * P + 2 * rows * M * P,  # lower half of sum g1 b b^T + sum g0 b
     }
@@ -397,7 +397,8 @@ def main():
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        flops = kernel_flops(w, rows)
+        flops = kernel_flops(w, rows, batched=getattr(eng, "last_batched", False) or not w.get("separate"),
+                             trmm_batch=getattr(eng, "last_trmm_batch", 1) if w.get("separate") else 1)
         byts = kernel_bytes(w, rows, esize)
         kern_ms = {k: v[1] for k, v in prof.items()}
         mfma = {k: kern_ms[k] for k in flops if k in kern_ms}

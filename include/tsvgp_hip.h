@@ -9,7 +9,8 @@
  *
  * Conventions
  *   - extern "C", plain pointers and sizes; no torch / C++ types.
- *   - All pointers are DEVICE pointers (caller-allocated, caller-owned); `stream` is a
+ *   - All pointers are DEVICE pointers (caller-allocated, caller-owned) unless the parameter name ends in `_host`
+ *     (small arrays of per-latent scalars, read during the call and passed on as kernel arguments); `stream` is a
  *     hipStream_t passed as void* (NULL = default stream).  No allocation and no
  *     synchronisation inside: safe to capture into a hipGraph.  The only process-wide
  *     state is one "dynamic-LDS opt-in done" flag per (kernel, device) for the two
@@ -37,6 +38,8 @@ extern "C" {
 #define TSVGP_ELAUNCH 2
 
 #define TSVGP_TILE 128 /* padding granule of N and M */
+#define TSVGP_MAX_BATCH 32 /* latent GPs per launch of the *_batched entry points (their per-latent scalars travel as
+                              kernel arguments); callers with more latents issue several calls */
 
 /* likelihood selectors for tsvgp_moments_* */
 #define TSVGP_LIK_NONE 0      /* moments only (predict_f) */
@@ -88,6 +91,19 @@ int tsvgp_kernel_fill_f64(int kind, const double *X, const double *Z, const doub
 int tsvgp_kernel_fill_f32(int kind, const float *X, const float *Z, const float *inv_ls, float variance, float *K,
                           int64_t N, int M, int D, int64_t ldk, void *stream);
 
+/* (1c) The fill for P latent GPs with one kernel each on shared inputs and shared inducing points
+ *     (gpflow SeparateIndependent + SharedIndependentInducingVariables, reference docs/notebooks/heteroskedastic.py:62-76;
+ *     Kuf [P, M, N] at src/models/tsvgp.py:269 for BASELINE configs[4]) in ONE launch:
+ *        K[p][n, m] = variance[p] * k(r_p),   r_p^2 = sum_d ((x_nd - z_md) * inv_ls[p*D + d])^2,   latent p at K + p*strideK.
+ *     inv_ls [P x D] is a device array; variance_host [P] is a HOST array (the scalars travel as kernel arguments, exactly
+ *     as `variance` does above).  1 <= P <= TSVGP_MAX_BATCH; strideK >= round_up(N,128) * ldk, even. */
+int tsvgp_kernel_fill_batched_f64(int kind, const double *X, const double *Z, const double *inv_ls,
+                                  const double *variance_host, double *K, int64_t strideK, int64_t N, int M, int D,
+                                  int64_t ldk, int P, void *stream);
+int tsvgp_kernel_fill_batched_f32(int kind, const float *X, const float *Z, const float *inv_ls,
+                                  const float *variance_host, float *K, int64_t strideK, int64_t N, int M, int D,
+                                  int64_t ldk, int P, void *stream);
+
 /* (2) Blocked triangular solve with an N-sized right-hand side, in inverted-factor form:
  *        C[n, i] = sum_{j in range(i)} A[n, j] * Tm[i, j],   range = j<=i | j>=i | all j   (mode)
  *     With Tm = inv(chol(Kuu + jitter I)) and mode LOWER this is B = Kfu * L^-T, i.e. the forward substitution
@@ -96,6 +112,17 @@ int tsvgp_kernel_fill_f32(int kind, const float *X, const float *Z, const float 
  *     A, C [Np x Mp] row-major (lda/ldc = Mp), Tm [Mp x Mp] row-major, zero outside its triangle/valid block. */
 int tsvgp_trmm_f64(const double *A, const double *Tm, double *C, int64_t Np, int Mp, int mode, void *stream);
 int tsvgp_trmm_f32(const float *A, const float *Tm, float *C, int64_t Np, int Mp, int mode, void *stream);
+
+/* (2b) The same solve batched over the latent dimension (the rank-3 A = cholesky_solve(chol(Kuu [P,M,M]),
+ *     Kuf [P,M,N]) of reference src/models/tsvgp.py:270-277 for one kernel per latent): latent b < batch reads
+ *     A + b*strideA (strideA = 0: one operand shared by all latents) and Tm + b*strideT, writes C + b*strideC, one launch.
+ *     In place (C == A with strideC == strideA) is allowed for TSVGP_TRI_UPPER only: a workgroup owns its 128-row panel,
+ *     takes the output column tiles in increasing order, and tile `it` reads only columns >= 128*it before it overwrites
+ *     columns [128*it, 128*it + 128).  batch <= 65535; strideC >= Np*Mp when batch > 1. */
+int tsvgp_trmm_batched_f64(const double *A, int64_t strideA, const double *Tm, int64_t strideT, double *C,
+                           int64_t strideC, int64_t Np, int Mp, int mode, int batch, void *stream);
+int tsvgp_trmm_batched_f32(const float *A, int64_t strideA, const float *Tm, int64_t strideT, float *C, int64_t strideC,
+                           int64_t Np, int Mp, int mode, int batch, void *stream);
 
 /* (3)+(4) Fused predictive moments and likelihood-gradient map.
  *     For every row n < N and latent p < P:
@@ -117,6 +144,19 @@ int tsvgp_moments_f32(const float *A, const float *Tm, const float *gamma, const
                       double lik_param, float *mean, float *var, float *g0, float *g1, double *ve_partial,
                       int32_t *nonpos_partial, int64_t N, int64_t Np, int Mp, int P, int mode, void *stream);
 
+/* (3b) The moments for P latents with one kernel each: latent p has its own operand A + p*strideA ([Np x Mp] each; strideA = 0
+ *     is the shared operand of tsvgp_moments_*) and its own prior variance kdiag_host[p] (HOST array of P doubles, passed
+ *     as kernel arguments).  1 <= P <= TSVGP_MAX_BATCH.  Everything else as tsvgp_moments_*; one launch, each workgroup
+ *     takes its 128-row panel through the P latents in turn. */
+int tsvgp_moments_batched_f64(const double *A, int64_t strideA, const double *Tm, const double *gamma, const double *Y,
+                              const double *kdiag_host, int lik, double lik_param, double *mean, double *var, double *g0,
+                              double *g1, double *ve_partial, int32_t *nonpos_partial, int64_t N, int64_t Np, int Mp,
+                              int P, int mode, void *stream);
+int tsvgp_moments_batched_f32(const float *A, int64_t strideA, const float *Tm, const float *gamma, const float *Y,
+                              const double *kdiag_host, int lik, double lik_param, float *mean, float *var, float *g0,
+                              float *g1, double *ve_partial, int32_t *nonpos_partial, int64_t N, int64_t Np, int Mp,
+                              int P, int mode, void *stream);
+
 /* (5) Site accumulation (the two einsums of reference src/models/tsvgp.py:278-281 in whitened coordinates):
  *        acc2[p][i][j] = sum_n g1[n,p] * B[n,i] * B[n,j]        (full symmetric [P x Mp x Mp], fp64)
  *        acc1[p][i]    = sum_n g0[n,p] * B[n,i]                 ([P x Mp], fp64)
@@ -129,6 +169,12 @@ int tsvgp_site_accum_f64(const double *B, const double *g0, const double *g1, do
                          int64_t Np, int Mp, int P, int nsplit, void *stream);
 int tsvgp_site_accum_f32(const float *B, const float *g0, const float *g1, double *acc2, double *acc1, void *work,
                          int64_t Np, int Mp, int P, int nsplit, void *stream);
+/* (5b) The same sums with one operand per latent (the rank-3 A of reference src/models/tsvgp.py:271-281): latent p reads
+ *     B + p*strideB ([Np x Mp] each; strideB = 0 is tsvgp_site_accum_*).  One launch over all P latents. */
+int tsvgp_site_accum_batched_f64(const double *B, int64_t strideB, const double *g0, const double *g1, double *acc2,
+                                 double *acc1, void *work, int64_t Np, int Mp, int P, int nsplit, void *stream);
+int tsvgp_site_accum_batched_f32(const float *B, int64_t strideB, const float *g0, const float *g1, double *acc2,
+                                 double *acc1, void *work, int64_t Np, int Mp, int P, int nsplit, void *stream);
 
 /* (6) Batched lower Cholesky of the M x M site matrices, in place:  A[b] = L[b] L[b]^T, L written to the lower triangle
  *     of the 128x128 diagonal blocks and below (the strictly upper part of the diagonal blocks is zeroed; blocks above

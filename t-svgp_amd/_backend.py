@@ -19,6 +19,7 @@ HEADER_PATH = os.path.join(_ROOT, "include", "tsvgp_hip.h")
 SOURCES = [os.path.join(CSRC, "tsvgp_kernels.hip")]
 
 TILE = 128
+MAX_BATCH = 32  # TSVGP_MAX_BATCH: latents per launch of the *_batched entry points
 LIK_NONE, LIK_GAUSSIAN, LIK_BERNOULLI = 0, 1, 2
 LIK_NOCROP = 0x100
 LIK_MEANONLY = 0x200
@@ -63,6 +64,10 @@ _PROTOTYPES = {
     "tsvgp_se_fill_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int, c_int, c_int64, c_void_p]),
     "tsvgp_kernel_fill_f64": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_double, c_void_p, c_int64, c_int, c_int, c_int64, c_void_p]),
     "tsvgp_kernel_fill_f32": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int, c_int, c_int64, c_void_p]),
+    "tsvgp_kernel_fill_batched_f64": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int,
+                                              c_int64, c_int, c_void_p]),
+    "tsvgp_kernel_fill_batched_f32": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int,
+                                              c_int64, c_int, c_void_p]),
     "tsvgp_kernel_grad_rows": (c_int, []),
     "tsvgp_kernel_grad_dpad": (c_int, [c_int]),
     "tsvgp_kernel_grad_f64": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_double, c_void_p, c_int64, c_void_p, c_void_p, c_int,
@@ -71,6 +76,14 @@ _PROTOTYPES = {
                                       c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "tsvgp_trmm_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "tsvgp_trmm_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "tsvgp_trmm_batched_f64": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_void_p]),
+    "tsvgp_trmm_batched_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_void_p]),
+    "tsvgp_moments_batched_f64": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_double, c_void_p, c_void_p,
+                                          c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_void_p]),
+    "tsvgp_moments_batched_f32": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_double, c_void_p, c_void_p,
+                                          c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_void_p]),
+    "tsvgp_site_accum_batched_f64": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
+    "tsvgp_site_accum_batched_f32": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     "tsvgp_moments_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_int, c_double, c_void_p, c_void_p,
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_void_p]),
     "tsvgp_moments_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_int, c_double, c_void_p, c_void_p,

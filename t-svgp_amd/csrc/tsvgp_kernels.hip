@@ -293,13 +293,23 @@ __device__ __forceinline__ T kernel_profile(T s) {
 #ifndef TSVGP_FILL_MAXWAVES
 #define TSVGP_FILL_MAXWAVES 3
 #endif
+// Latent batch (grid.z): latent p has its own lengthscales inv_ls[p * D ..], variance var.v[p] and output K + p * strideK;
+// X and Z are shared (SharedIndependentInducingVariables + SeparateIndependent, reference docs/notebooks/heteroskedastic.py:62-76).
+template <typename T>
+struct FillBatch {
+    T v[TSVGP_MAX_BATCH];
+};
+
 template <typename T, int KIND, int DT>
 __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, TSVGP_FILL_MAXWAVES))) void se_fill_kernel(
-    const T* __restrict__ X, const T* __restrict__ Z, const T* __restrict__ inv_ls, T variance, T* __restrict__ K,
-    int64_t N, int M, int D, int64_t ldk, int64_t rows_pad, int cols_pad) {
+    const T* __restrict__ X, const T* __restrict__ Z, const T* __restrict__ inv_ls, FillBatch<T> var, T* __restrict__ K,
+    int64_t strideK, int64_t N, int M, int D, int64_t ldk, int64_t rows_pad, int cols_pad) {
     __shared__ __attribute__((aligned(16))) T Xs[FILL_ROWS][DT];  // pre-scaled by inv_ls
     typedef typename Mfma<T>::pair_t pair_t;
 
+    const T variance = var.v[blockIdx.z];
+    inv_ls += (size_t)blockIdx.z * D;
+    K += (size_t)blockIdx.z * strideK;
     const int t = threadIdx.x;
     const int m = blockIdx.y * FILL_COLS + 2 * t;  // this thread's column pair
     const bool v0 = (m < M), v1 = (m + 1 < M), active = (m < cols_pad);
@@ -501,9 +511,13 @@ struct PanelArgs {
     T* g1;           // [Np x P] or null
     double* ve_partial;
     int32_t* nonpos_partial;
-    double kdiag, lik_param;
+    double lik_param;
     int64_t N, Np;
+    int64_t strideA;  // elements between the operands of consecutive latents (0: one operand shared by all latents)
+    int64_t strideC, strideT;  // STORE, latent batch on grid.y
     int Mp, P, mode, lik;
+    int kdiag_uniform;              // MOMENTS: kdiag[0] holds for every latent (one shared kernel; any P)
+    double kdiag[TSVGP_MAX_BATCH];  // MOMENTS: k(x, x) = kernel variance of latent p (one kernel per latent: they differ)
 };
 
 // FUSE (MOMENTS, triangular modes): the mean GEMV rides on the column tile whose k-range covers every chunk of the
@@ -529,14 +543,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void panel_kernel(PanelArgs<T> a) {
     const int Mp = a.Mp;
     const int ntile = Mp / TILE, nchunk = Mp / KC;
 
-    const T* Arow = a.A + (n0 + srow) * (int64_t)Mp + skh * H;
     T* const lds_wr = &lds[0][0][srow * RS + skh * H];
     constexpr int BUF_STRIDE = 2 * TILE * RS, OP_STRIDE = TILE * RS;
     double ve_acc = 0.0;
     int nonpos = 0;
+    // STORE: one latent per grid.y slice (operands A, Tm and the output C each advance by their latent stride);
+    // MOMENTS: the workgroup takes its row panel through all P latents in turn (their outputs interleave in [n * P + p])
+    const int pb = (MODE == MODE_STORE) ? (int)blockIdx.y : 0;
 
     for (int p = 0; p < a.P; ++p) {
-        const T* Tp = a.Tm + (size_t)p * Mp * Mp;
+        const T* Tp = (MODE == MODE_STORE) ? a.Tm + (size_t)pb * a.strideT : a.Tm + (size_t)p * Mp * Mp;
+        const T* Arow = a.A + (size_t)(MODE == MODE_STORE ? pb : p) * a.strideA + (n0 + srow) * (int64_t)Mp + skh * H;
         // Row sums of squares: after every column tile the 8 per-register partials (2 row blocks x 4 registers) are
         // summed over the 16 lanes that share (lane>>4) and lane lr keeps the one with index lr & 7.
         double rs_mine = 0.0;
@@ -698,7 +715,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void panel_kernel(PanelArgs<T> a) {
 #endif
 
             if constexpr (MODE == MODE_STORE) {
-                T* Cb = a.C + n0 * (int64_t)Mp + it * TILE + (lane & 15);
+                T* Cb = a.C + (size_t)pb * a.strideC + n0 * (int64_t)Mp + it * TILE + (lane & 15);
 #pragma unroll
                 for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -752,7 +769,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void panel_kernel(PanelArgs<T> a) {
                 const bool live = n < a.N;
                 const double q = rowq[srow];
                 const double mu = (double)mpart;
-                const double v = a.kdiag - q;
+                const double v = a.kdiag[a.kdiag_uniform ? 0 : p] - q;
                 double g0 = 0.0, g1 = 0.0, ve = 0.0;
                 if ((a.lik & 0xFF) == TSVGP_LIK_BERNOULLI) {
                     // the quadrature is the long pole of this epilogue (20 erf / exp / log in fp64 per row): the two
@@ -830,9 +847,9 @@ __global__ __launch_bounds__(NTHREADS) void mean_lik_kernel(PanelArgs<T> a) {
     __syncthreads();
     const int64_t nw = (int64_t)blockIdx.x * TILE + w * (TILE / 4);
     for (int r = 0; r < TILE / 4; r += 2) {
-        const T* r0 = a.A + (nw + r) * (int64_t)Mp;
-        const T* r1 = r0 + Mp;
-        for (int p = 0; p < P; ++p) {  // P > 1 re-reads the two rows from cache
+        for (int p = 0; p < P; ++p) {  // shared operand (strideA = 0): P > 1 re-reads the two rows from cache
+            const T* r0 = a.A + (size_t)p * a.strideA + (nw + r) * (int64_t)Mp;
+            const T* r1 = r0 + Mp;
             const T* gp = gs + p * Mp;
             T s0 = T(0), s1 = T(0);
 #pragma unroll 4
@@ -883,6 +900,7 @@ struct SyrkArgs {
     T* part2;     // [P][slabs_per_p][128*128], slab(tri, s) = (tri - it) * ns_off + it * ns_diag + s
     T* part1;     // [P][ns_diag][Mp]
     int64_t Np;
+    int64_t strideB;  // elements between the operands of consecutive latents (0: shared)
     int Mp, P, nt, ns_off, ns_diag;
     int64_t chunks_off, chunks_diag;  // N-slice lengths in units of KC rows
 };
@@ -921,8 +939,8 @@ __device__ __forceinline__ void syrk_body(const SyrkArgs<T>& a, T (*lds)[2][KC *
 
     // staging role: k-row of the chunk and four 16-byte (fp64) / 8-byte (fp32) pieces spread over the 128 columns
     const int krow = t >> 4, cseg = t & 15;
-    const T* Bi = a.B + (int64_t)krow * Mp + it * TILE + cseg * 2;
-    const T* Bj = a.B + (int64_t)krow * Mp + jt * TILE + cseg * 2;
+    const T* Bi = a.B + (size_t)p * a.strideB + (int64_t)krow * Mp + it * TILE + cseg * 2;
+    const T* Bj = a.B + (size_t)p * a.strideB + (int64_t)krow * Mp + jt * TILE + cseg * 2;
 
     acc_t acc[2][8];
 #pragma unroll
@@ -1669,23 +1687,30 @@ struct DynLdsOptIn {
     }
 };
 
+// P latents in one launch: inv_ls [P x D] (device), variance [P] (HOST: the scalars travel as kernel arguments, like the
+// single-latent entry point's `variance`), K + p * strideK.
 template <typename T>
-int kernel_fill(int kind, const T* X, const T* Z, const T* inv_ls, T variance, T* K, int64_t N, int M, int D,
-                int64_t ldk, void* stream) {
-    if (!X || !Z || !inv_ls || !K || N <= 0 || M <= 0 || D <= 0 || (kind != TSVGP_KERNEL_SE && kind != TSVGP_KERNEL_MATERN32 && kind != TSVGP_KERNEL_MATERN52))
+int kernel_fill(int kind, const T* X, const T* Z, const T* inv_ls, const T* variance, T* K, int64_t strideK, int64_t N,
+                int M, int D, int64_t ldk, int P, void* stream) {
+    if (!X || !Z || !inv_ls || !variance || !K || N <= 0 || M <= 0 || D <= 0 || P <= 0 || P > TSVGP_MAX_BATCH ||
+        (kind != TSVGP_KERNEL_SE && kind != TSVGP_KERNEL_MATERN32 && kind != TSVGP_KERNEL_MATERN52))
         return TSVGP_EINVAL;
     const int64_t rows_pad = (N + TILE - 1) / TILE * TILE;
     const int cols_pad = (M + TILE - 1) / TILE * TILE;
     if (ldk < cols_pad || (ldk % 2) != 0) return TSVGP_EINVAL;
+    if (P > 1 && (strideK < rows_pad * ldk || (strideK % 2) != 0)) return TSVGP_EINVAL;
     if (D > 32) return TSVGP_EINVAL;  // input dimensions are padded to a compile-time size (1, 2, 4, 8, 16, 32)
-    dim3 grid((unsigned)((rows_pad + FILL_ROWS - 1) / FILL_ROWS), (unsigned)((cols_pad + FILL_COLS - 1) / FILL_COLS));
+    FillBatch<T> var{};
+    for (int q = 0; q < P; ++q) var.v[q] = variance[q];
+    dim3 grid((unsigned)((rows_pad + FILL_ROWS - 1) / FILL_ROWS), (unsigned)((cols_pad + FILL_COLS - 1) / FILL_COLS),
+              (unsigned)P);
 #ifdef TSVGP_FILL_GRID_CAP  // experiment build (tools/exp_overlap2.py): fewer, looping workgroups
     if ((unsigned)(TSVGP_FILL_GRID_CAP) < grid.x) grid.x = (unsigned)(TSVGP_FILL_GRID_CAP);
 #endif
     const int DT = D <= 1 ? 1 : D <= 2 ? 2 : D <= 4 ? 4 : D <= 8 ? 8 : D <= 16 ? 16 : 32;
 #define TSVGP_FILL_LAUNCH(KIND_, DT_)                                                                                 \
     hipLaunchKernelGGL((se_fill_kernel<T, KIND_, DT_>), grid, dim3(NTHREADS), 0, (hipStream_t)stream, X, Z, inv_ls,   \
-                       variance, K, N, M, D, ldk, rows_pad, cols_pad)
+                       var, K, strideK, N, M, D, ldk, rows_pad, cols_pad)
 #define TSVGP_FILL_DT(KIND_)                          \
     switch (DT) {                                     \
         case 1: TSVGP_FILL_LAUNCH(KIND_, 1); break;   \
@@ -1705,10 +1730,18 @@ int kernel_fill(int kind, const T* X, const T* Z, const T* inv_ls, T variance, T
     return launch_status();
 }
 
+// `batch` latents in one launch (grid.y): latent b reads A + b * strideA (0: one shared operand) and Tm + b * strideT and
+// writes C + b * strideC.  In place (C == A, strideC == strideA) is allowed for TSVGP_TRI_UPPER only: a workgroup owns
+// its 128-row panel and takes the output column tiles in increasing order, tile `it` reads the columns >= 128 * it and
+// then overwrites the columns [128 * it, 128 * it + 128), which no later tile reads.
 template <typename T>
-int trmm(const T* A, const T* Tm, T* C, int64_t Np, int Mp, int mode, void* stream) {
-    if (!A || !Tm || !C || Np <= 0 || Mp <= 0 || (Np % TILE) || (Mp % TILE) || mode < 0 || mode > 2)
+int trmm(const T* A, int64_t strideA, const T* Tm, int64_t strideT, T* C, int64_t strideC, int64_t Np, int Mp, int mode,
+         int batch, void* stream) {
+    if (!A || !Tm || !C || Np <= 0 || Mp <= 0 || (Np % TILE) || (Mp % TILE) || mode < 0 || mode > 2 || batch <= 0 ||
+        batch > 65535 || strideA < 0 || strideT < 0 || strideC < 0)
         return TSVGP_EINVAL;
+    if (batch > 1 && strideC < Np * (int64_t)Mp) return TSVGP_EINVAL;  // outputs of different latents must not overlap
+    if ((const void*)A == (const void*)C && (mode != TSVGP_TRI_UPPER || strideA != strideC)) return TSVGP_EINVAL;
     PanelArgs<T> a{};
     a.A = A;
     a.Tm = Tm;
@@ -1718,7 +1751,10 @@ int trmm(const T* A, const T* Tm, T* C, int64_t Np, int Mp, int mode, void* stre
     a.Mp = Mp;
     a.P = 1;
     a.mode = mode;
-    const dim3 grid((unsigned)(Np / TILE)), block(NTHREADS);
+    a.strideA = strideA;
+    a.strideT = strideT;
+    a.strideC = strideC;
+    const dim3 grid((unsigned)(Np / TILE), (unsigned)batch), block(NTHREADS);
     if (mode == TSVGP_TRI_LOWER)
         hipLaunchKernelGGL((panel_kernel<T, MODE_STORE, TSVGP_TRI_LOWER>), grid, block, 0, (hipStream_t)stream, a);
     else if (mode == TSVGP_TRI_UPPER)
@@ -1728,12 +1764,16 @@ int trmm(const T* A, const T* Tm, T* C, int64_t Np, int Mp, int mode, void* stre
     return launch_status();
 }
 
+// kdiag: HOST array of P values (one kernel variance per latent), or of ONE value with kdiag_uniform (a shared kernel, any P).
 template <typename T>
-int moments(const T* A, const T* Tm, const T* gamma, const T* Y, double kdiag, int lik, double lik_param, T* mean,
-            T* var, T* g0, T* g1, double* ve_partial, int32_t* nonpos_partial, int64_t N, int64_t Np, int Mp, int P,
-            int mode, void* stream) {
+int moments(const T* A, int64_t strideA, const T* Tm, const T* gamma, const T* Y, const double* kdiag, bool kdiag_uniform,
+            int lik, double lik_param, T* mean, T* var, T* g0, T* g1, double* ve_partial, int32_t* nonpos_partial,
+            int64_t N, int64_t Np, int Mp, int P, int mode, void* stream) {
     const bool mean_only = (lik & TSVGP_LIK_MEANONLY) != 0;
-    if (!A || !gamma || N <= 0 || Np < N || (Np % TILE) || Mp <= 0 || (Mp % TILE) || P <= 0) return TSVGP_EINVAL;
+    if (!A || !gamma || !kdiag || N <= 0 || Np < N || (Np % TILE) || Mp <= 0 || (Mp % TILE) || P <= 0 || strideA < 0)
+        return TSVGP_EINVAL;
+    if (!kdiag_uniform && P > TSVGP_MAX_BATCH) return TSVGP_EINVAL;
+    if (strideA != 0 && strideA < Np * (int64_t)Mp) return TSVGP_EINVAL;
     if (!mean_only && (!Tm || mode < 0 || mode > 2)) return TSVGP_EINVAL;
     if (lik & ~(0xFF | TSVGP_LIK_NOCROP | TSVGP_LIK_MEANONLY)) return TSVGP_EINVAL;
     const int lik_base = lik & 0xFF;
@@ -1760,7 +1800,9 @@ int moments(const T* A, const T* Tm, const T* gamma, const T* Y, double kdiag, i
     a.g1 = g1;
     a.ve_partial = ve_partial;
     a.nonpos_partial = nonpos_partial;
-    a.kdiag = kdiag;
+    a.kdiag_uniform = kdiag_uniform ? 1 : 0;
+    for (int q = 0; q < (kdiag_uniform ? 1 : P); ++q) a.kdiag[q] = kdiag[q];
+    a.strideA = strideA;
     a.lik_param = lik_param;
     a.N = N;
     a.Np = Np;
@@ -1797,10 +1839,10 @@ int64_t site_accum_work_bytes(int Mp, int P, int nsplit) {
 }
 
 template <typename T>
-int site_accum(const T* B, const T* g0, const T* g1, double* acc2, double* acc1, void* work, int64_t Np, int Mp, int P,
-               int nsplit, void* stream) {
+int site_accum(const T* B, int64_t strideB, const T* g0, const T* g1, double* acc2, double* acc1, void* work, int64_t Np,
+               int Mp, int P, int nsplit, void* stream) {
     if (!B || !g0 || !g1 || !acc2 || !acc1 || !work || Np <= 0 || (Np % TILE) || Mp <= 0 || (Mp % TILE) || P <= 0 ||
-        nsplit <= 0)
+        nsplit <= 0 || strideB < 0 || (strideB != 0 && strideB < Np * (int64_t)Mp))
         return TSVGP_EINVAL;
     const int nt = Mp / TILE, ntri = nt * (nt + 1) / 2, n_off = ntri - nt;
     const int64_t total_chunks = Np / KC;
@@ -1809,6 +1851,7 @@ int site_accum(const T* B, const T* g0, const T* g1, double* acc2, double* acc1,
     a.g0 = g0;
     a.g1 = g1;
     a.Np = Np;
+    a.strideB = strideB;
     a.Mp = Mp;
     a.P = P;
     a.nt = nt;
@@ -1932,39 +1975,71 @@ int tsvgp_site_accum_slots_f32(void) { return site_accum_slots<float>(); }
 
 int tsvgp_se_fill_f64(const double* X, const double* Z, const double* inv_ls, double variance, double* K, int64_t N,
                       int M, int D, int64_t ldk, void* stream) {
-    return kernel_fill<double>(TSVGP_KERNEL_SE, X, Z, inv_ls, variance, K, N, M, D, ldk, stream);
+    return kernel_fill<double>(TSVGP_KERNEL_SE, X, Z, inv_ls, &variance, K, 0, N, M, D, ldk, 1, stream);
 }
 int tsvgp_se_fill_f32(const float* X, const float* Z, const float* inv_ls, float variance, float* K, int64_t N, int M,
                       int D, int64_t ldk, void* stream) {
-    return kernel_fill<float>(TSVGP_KERNEL_SE, X, Z, inv_ls, variance, K, N, M, D, ldk, stream);
+    return kernel_fill<float>(TSVGP_KERNEL_SE, X, Z, inv_ls, &variance, K, 0, N, M, D, ldk, 1, stream);
 }
 int tsvgp_kernel_fill_f64(int kind, const double* X, const double* Z, const double* inv_ls, double variance, double* K,
                           int64_t N, int M, int D, int64_t ldk, void* stream) {
-    return kernel_fill<double>(kind, X, Z, inv_ls, variance, K, N, M, D, ldk, stream);
+    return kernel_fill<double>(kind, X, Z, inv_ls, &variance, K, 0, N, M, D, ldk, 1, stream);
 }
 int tsvgp_kernel_fill_f32(int kind, const float* X, const float* Z, const float* inv_ls, float variance, float* K,
                           int64_t N, int M, int D, int64_t ldk, void* stream) {
-    return kernel_fill<float>(kind, X, Z, inv_ls, variance, K, N, M, D, ldk, stream);
+    return kernel_fill<float>(kind, X, Z, inv_ls, &variance, K, 0, N, M, D, ldk, 1, stream);
+}
+int tsvgp_kernel_fill_batched_f64(int kind, const double* X, const double* Z, const double* inv_ls,
+                                  const double* variance_host, double* K, int64_t strideK, int64_t N, int M, int D,
+                                  int64_t ldk, int P, void* stream) {
+    return kernel_fill<double>(kind, X, Z, inv_ls, variance_host, K, strideK, N, M, D, ldk, P, stream);
+}
+int tsvgp_kernel_fill_batched_f32(int kind, const float* X, const float* Z, const float* inv_ls,
+                                  const float* variance_host, float* K, int64_t strideK, int64_t N, int M, int D,
+                                  int64_t ldk, int P, void* stream) {
+    return kernel_fill<float>(kind, X, Z, inv_ls, variance_host, K, strideK, N, M, D, ldk, P, stream);
 }
 
 int tsvgp_trmm_f64(const double* A, const double* Tm, double* C, int64_t Np, int Mp, int mode, void* stream) {
-    return trmm<double>(A, Tm, C, Np, Mp, mode, stream);
+    return trmm<double>(A, 0, Tm, 0, C, 0, Np, Mp, mode, 1, stream);
 }
 int tsvgp_trmm_f32(const float* A, const float* Tm, float* C, int64_t Np, int Mp, int mode, void* stream) {
-    return trmm<float>(A, Tm, C, Np, Mp, mode, stream);
+    return trmm<float>(A, 0, Tm, 0, C, 0, Np, Mp, mode, 1, stream);
+}
+int tsvgp_trmm_batched_f64(const double* A, int64_t strideA, const double* Tm, int64_t strideT, double* C,
+                           int64_t strideC, int64_t Np, int Mp, int mode, int batch, void* stream) {
+    return trmm<double>(A, strideA, Tm, strideT, C, strideC, Np, Mp, mode, batch, stream);
+}
+int tsvgp_trmm_batched_f32(const float* A, int64_t strideA, const float* Tm, int64_t strideT, float* C, int64_t strideC,
+                           int64_t Np, int Mp, int mode, int batch, void* stream) {
+    return trmm<float>(A, strideA, Tm, strideT, C, strideC, Np, Mp, mode, batch, stream);
 }
 
 int tsvgp_moments_f64(const double* A, const double* Tm, const double* gamma, const double* Y, double kdiag, int lik,
                       double lik_param, double* mean, double* var, double* g0, double* g1, double* ve_partial,
                       int32_t* nonpos_partial, int64_t N, int64_t Np, int Mp, int P, int mode, void* stream) {
-    return moments<double>(A, Tm, gamma, Y, kdiag, lik, lik_param, mean, var, g0, g1, ve_partial, nonpos_partial, N,
-                           Np, Mp, P, mode, stream);
+    return moments<double>(A, 0, Tm, gamma, Y, &kdiag, true, lik, lik_param, mean, var, g0, g1, ve_partial,
+                           nonpos_partial, N, Np, Mp, P, mode, stream);
+}
+int tsvgp_moments_batched_f64(const double* A, int64_t strideA, const double* Tm, const double* gamma, const double* Y,
+                              const double* kdiag_host, int lik, double lik_param, double* mean, double* var, double* g0,
+                              double* g1, double* ve_partial, int32_t* nonpos_partial, int64_t N, int64_t Np, int Mp,
+                              int P, int mode, void* stream) {
+    return moments<double>(A, strideA, Tm, gamma, Y, kdiag_host, false, lik, lik_param, mean, var, g0, g1, ve_partial,
+                           nonpos_partial, N, Np, Mp, P, mode, stream);
+}
+int tsvgp_moments_batched_f32(const float* A, int64_t strideA, const float* Tm, const float* gamma, const float* Y,
+                              const double* kdiag_host, int lik, double lik_param, float* mean, float* var, float* g0,
+                              float* g1, double* ve_partial, int32_t* nonpos_partial, int64_t N, int64_t Np, int Mp,
+                              int P, int mode, void* stream) {
+    return moments<float>(A, strideA, Tm, gamma, Y, kdiag_host, false, lik, lik_param, mean, var, g0, g1, ve_partial,
+                          nonpos_partial, N, Np, Mp, P, mode, stream);
 }
 int tsvgp_moments_f32(const float* A, const float* Tm, const float* gamma, const float* Y, double kdiag, int lik,
                       double lik_param, float* mean, float* var, float* g0, float* g1, double* ve_partial,
                       int32_t* nonpos_partial, int64_t N, int64_t Np, int Mp, int P, int mode, void* stream) {
-    return moments<float>(A, Tm, gamma, Y, kdiag, lik, lik_param, mean, var, g0, g1, ve_partial, nonpos_partial, N, Np,
-                          Mp, P, mode, stream);
+    return moments<float>(A, 0, Tm, gamma, Y, &kdiag, true, lik, lik_param, mean, var, g0, g1, ve_partial,
+                          nonpos_partial, N, Np, Mp, P, mode, stream);
 }
 
 int64_t tsvgp_site_accum_work_bytes_f64(int Mp, int P, int nsplit) {
@@ -1975,11 +2050,19 @@ int64_t tsvgp_site_accum_work_bytes_f32(int Mp, int P, int nsplit) {
 }
 int tsvgp_site_accum_f64(const double* B, const double* g0, const double* g1, double* acc2, double* acc1, void* work,
                          int64_t Np, int Mp, int P, int nsplit, void* stream) {
-    return site_accum<double>(B, g0, g1, acc2, acc1, work, Np, Mp, P, nsplit, stream);
+    return site_accum<double>(B, 0, g0, g1, acc2, acc1, work, Np, Mp, P, nsplit, stream);
+}
+int tsvgp_site_accum_batched_f64(const double* B, int64_t strideB, const double* g0, const double* g1, double* acc2,
+                                 double* acc1, void* work, int64_t Np, int Mp, int P, int nsplit, void* stream) {
+    return site_accum<double>(B, strideB, g0, g1, acc2, acc1, work, Np, Mp, P, nsplit, stream);
+}
+int tsvgp_site_accum_batched_f32(const float* B, int64_t strideB, const float* g0, const float* g1, double* acc2,
+                                 double* acc1, void* work, int64_t Np, int Mp, int P, int nsplit, void* stream) {
+    return site_accum<float>(B, strideB, g0, g1, acc2, acc1, work, Np, Mp, P, nsplit, stream);
 }
 int tsvgp_site_accum_f32(const float* B, const float* g0, const float* g1, double* acc2, double* acc1, void* work,
                          int64_t Np, int Mp, int P, int nsplit, void* stream) {
-    return site_accum<float>(B, g0, g1, acc2, acc1, work, Np, Mp, P, nsplit, stream);
+    return site_accum<float>(B, 0, g0, g1, acc2, acc1, work, Np, Mp, P, nsplit, stream);
 }
 
 int tsvgp_potrf_f64(double* A, int M, int lda, int batch, int64_t stride, int* info, double* work, void* stream) {

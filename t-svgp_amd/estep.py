@@ -18,6 +18,7 @@ Kernel sequence of ``run(..., sites=True)`` by projection route (models/tsvgp.py
 """
 from __future__ import annotations
 
+import ctypes
 from dataclasses import dataclass
 from typing import Optional
 
@@ -68,6 +69,8 @@ class EStepEngine:
         self.syrk_oversubscribe = 8
         self._b_tag = None  # identifies the contents of the cached whitened buffer B
         self._side = None  # side stream of start_fill
+        self.last_batched = False  # the last pass over separate kernels ran as batched launches
+        self.last_trmm_batch = 1  # latents per whitening launch of that pass
         self.profile = None  # set to a dict to record (start, stop) HIP events per kernel launch on the launch stream
 
     # ------------------------------------------------------------------ helpers
@@ -273,14 +276,171 @@ class EStepEngine:
                     "tsvgp_selftest_mfma")
         return a, b, c
 
-    def _run_separate(self, X, Y, Z, kernel, *, moment_Tm, gamma, whiten_T, project_T, want_grads, **kw) -> EStepStats:
-        """Separate per-latent kernels (K_uu [P, M, M]): one fill + moments + accumulation pass per latent, through the
-        same single-latent kernels and ONE K(X, Z) buffer (P of them would be 8.2 GB each at N = 1e6, M = 1024)."""
+    # ------------------------------------------------------------------ one kernel per latent, batched over the latents
+    batch_separate = True  # False: always one pass per latent through a single K(X, Z) buffer (the round-1 path)
+    batch_mem_fraction = 0.8  # of the device memory still free: what the [P, Np, Mp] operand of a batched pass may take
+
+    @staticmethod
+    def _per_latent(t, p):
+        """Entry p of a per-latent operand given as None, a list, a [P, M, M] tensor or one shared [M, M] tensor."""
+        if t is None:
+            return None
+        if isinstance(t, (list, tuple)):
+            return t[p]
+        return t[p] if t.dim() == 3 else t
+
+    def _batch_plan(self, N, M, kernel, P, whiten_T, whiten_mode, project_T, moments_on_kfu):
+        """Can the pass over P separately-parameterised latents run as batched launches (tsvgp_*_batched_*)?  Needs one
+        kernel family, at most MAX_BATCH latents, no "projected" latent (its second product is not in place), the
+        whitening in upper form (in place) and room for the [P, Np, Mp] operand.  Returns the list of whitened latents
+        or None for the per-latent path."""
+        if not self.batch_separate or P < 2 or P > B.MAX_BATCH or moments_on_kfu:
+            return None
+        if len({k.kind for k in kernel.kernels}) != 1:
+            return None
+        if any(self._per_latent(project_T, p) is not None for p in range(P)):
+            return None
+        whitened = [p for p in range(P) if self._per_latent(whiten_T, p) is not None]
+        if whitened and whiten_mode != B.TRI_UPPER:
+            return None
+        Np, Mp = B.round_up(N), B.round_up(M)
+        need = P * Np * Mp * torch.empty((), dtype=self.dtype).element_size()
+        have = self._buf.get("KfuP")
+        if have is None or tuple(have.shape) != (P, Np, Mp) or have.dtype != self.dtype:
+            free, _ = torch.cuda.mem_get_info(self.device)
+            free += torch.cuda.memory_reserved(self.device) - torch.cuda.memory_allocated(self.device)
+            if have is not None:
+                free += have.numel() * have.element_size()
+            if need > self.batch_mem_fraction * free:
+                return None
+        return whitened
+
+    def _fill_batched(self, X, Z, kernel, KfuP):
+        """K(X, Z) of every latent's kernel into KfuP [P, Np, Mp] with one launch per MAX_BATCH latents."""
+        T, dev = self.dtype, self.device
+        N, D = X.shape
+        M = Z.shape[0]
+        if D > MAX_INPUT_DIM:
+            raise ValueError(f"input dimension D = {D} exceeds the HIP fill kernel's limit of {MAX_INPUT_DIM}")
+        P = len(kernel.kernels)
+        inv_ls = torch.stack([k.inv_lengthscales(D, T, dev) for k in kernel.kernels]).contiguous()  # [P, D]
+        ctype = ctypes.c_double if T == torch.float64 else ctypes.c_float
+        fn = self._fn("tsvgp_kernel_fill_batched", T)
+        stride = KfuP.shape[1] * KfuP.shape[2]
+        with torch.cuda.device(dev):
+            for p0 in range(0, P, B.MAX_BATCH):
+                n = min(B.MAX_BATCH, P - p0)
+                var = (ctype * n)(*[k.variance.item() for k in kernel.kernels[p0:p0 + n]])
+                self._launch("tsvgp_se_fill", lambda: fn(kernel.kernels[0].kind, X.data_ptr(), Z.data_ptr(),
+                                                         inv_ls[p0].data_ptr(), var, KfuP[p0].data_ptr(), stride, N, M, D,
+                                                         KfuP.shape[2], n, self._stream()))
+        return KfuP
+
+    def _run_batched(self, X, Y, Z, kernel, whitened, *, moment_Tm, moment_mode, gamma, lik_id, lik_param, whiten_T,
+                     sites, want_moments, want_grads, mean_only, prefill=None) -> EStepStats:
+        """One pass for P latents with one kernel each as batched launches: fill [P, Np, Mp] -> in-place whitening of the
+        latents that ask for it -> moments -> site sums (4 launches; BASELINE configs[4])."""
+        T, dev = self.dtype, self.device
+        X = X.to(device=dev, dtype=T).contiguous()
+        Z = Z.to(device=dev, dtype=T).contiguous()
+        N, M, P = X.shape[0], Z.shape[0], moment_Tm.shape[0]
+        Np, Mp = B.round_up(N), B.round_up(M)
+        need_g = lik_id != B.LIK_NONE
+        if need_g:
+            Y = Y.to(device=dev, dtype=T).contiguous()
+        self._b_tag = None
+        self._buf.pop("Kfu", None)  # the single-latent operand buffers are not needed beside the batched one
+        self._buf.pop("B", None)
+        KfuP = self._get("KfuP", (P, Np, Mp), T)
+        stride = Np * Mp
+        if prefill is not None:
+            if prefill.get("KfuP") is not KfuP:
+                raise RuntimeError("prefill ticket does not belong to this pass")
+            torch.cuda.current_stream(dev).wait_event(prefill["event"])
+        else:
+            if self._side is not None:
+                torch.cuda.current_stream(dev).wait_stream(self._side)
+            self._fill_batched(X, Z, kernel, KfuP)
+        # whitening in place, one launch per run of consecutive whitened latents: B_p = K_p U9_p^-T (upper form)
+        runs, start = [], None
+        for p in range(P + 1):
+            on = p < P and p in whitened
+            if on and start is None:
+                start = p
+            if not on and start is not None:
+                runs.append((start, p))
+                start = None
+        fn_trmm = self._fn("tsvgp_trmm_batched")
+        self.last_trmm_batch = max([hi - lo for lo, hi in runs], default=1)
+        for lo, hi in runs:
+            Wt = torch.stack([self._per_latent(whiten_T, p) for p in range(lo, hi)])
+            Wp = self._pad_square(Wt, Mp, f"pad_LinvP{hi - lo}")
+            with torch.cuda.device(dev):
+                self._launch("tsvgp_trmm", lambda: fn_trmm(KfuP[lo].data_ptr(), stride, Wp.data_ptr(), Mp * Mp,
+                                                           KfuP[lo].data_ptr(), stride, Np, Mp, B.TRI_UPPER, hi - lo,
+                                                           self._stream()))
+        Tm = self._pad_square(moment_Tm, Mp, "pad_Tm")
+        gam = torch.zeros((Mp, P), dtype=T, device=dev)
+        gam[:M] = gamma
+        nblk = Np // B.TILE
+        ve_partial = self._get("ve_partial", (nblk,), torch.float64)
+        nonpos_partial = self._get("nonpos_partial", (nblk,), torch.int32)
+        g0 = self._get("g0", (Np, P), T) if need_g else None
+        g1 = self._get("g1", (Np, P), T) if need_g else None
+        mean = torch.empty((N, P), dtype=T, device=dev) if want_moments else None
+        var = torch.empty((N, P), dtype=T, device=dev) if (want_moments and not mean_only) else None
+        lik_flags = (lik_id | B.LIK_MEANONLY) if mean_only else lik_id
+        kdiag = (ctypes.c_double * P)(*[k.variance.item() for k in kernel.kernels])
+        with torch.cuda.device(dev):
+            self._launch("tsvgp_moments", lambda: self._fn("tsvgp_moments_batched")(
+                KfuP.data_ptr(), stride, Tm.data_ptr(), gam.data_ptr(), _ptr(Y) if need_g else None, kdiag, lik_flags,
+                float(lik_param), _ptr(mean), _ptr(var), _ptr(g0), _ptr(g1), ve_partial.data_ptr(),
+                nonpos_partial.data_ptr(), N, Np, Mp, P, moment_mode, self._stream()))
+        stats = EStepStats(n_rows=N, ve_sum=ve_partial.sum(), nonpos=nonpos_partial.sum().to(torch.float64))
+        if want_moments:
+            stats.mean, stats.var = mean.to(torch.float64), (None if var is None else var.to(torch.float64))
+        if want_grads and need_g:
+            stats.g0, stats.g1 = g0[:N].to(torch.float64), g1[:N].to(torch.float64)
+        if sites:
+            nsplit = self.nsplit_override or self.choose_nsplit(Mp, P)
+            nsplit = max(1, min(nsplit, Np // 16))
+            nbytes = int(self._fn("tsvgp_site_accum_work_bytes")(Mp, P, nsplit))
+            work = self._get("work", (nbytes,), torch.uint8)
+            acc2 = torch.empty((P, Mp, Mp), dtype=torch.float64, device=dev)
+            acc1 = torch.empty((P, Mp), dtype=torch.float64, device=dev)
+            with torch.cuda.device(dev):
+                self._launch("tsvgp_site_accum", lambda: self._fn("tsvgp_site_accum_batched")(
+                    KfuP.data_ptr(), stride, g0.data_ptr(), g1.data_ptr(), acc2.data_ptr(), acc1.data_ptr(),
+                    work.data_ptr(), Np, Mp, P, nsplit, self._stream()))
+            stats.acc2 = acc2[:, :M, :M]
+            stats.acc1 = acc1[:, :M]
+        self.last_batched = True
+        return stats
+
+    def _run_separate(self, X, Y, Z, kernel, *, moment_Tm, gamma, whiten_T, project_T, want_grads, prefill=None,
+                      **kw) -> EStepStats:
+        """Separate per-latent kernels (K_uu [P, M, M]).  Batched launches over the latents when ``_batch_plan`` allows
+        (one [P, Np, Mp] operand: 8.2 GB per latent at N = 1e6, M = 1024, fp64 -- 66 GB of the 288 GB at P = 8);
+        otherwise one fill + moments + accumulation pass per latent through the single-latent kernels and ONE K(X, Z)
+        buffer."""
         P = moment_Tm.shape[0]
         if len(kernel.kernels) != P:
             raise ValueError(f"{len(kernel.kernels)} kernels for {P} latent GPs")
         if Y is not None and (Y.dim() != 2 or Y.shape[1] != P):
             raise ValueError(f"Y must be [N, P] = [{X.shape[0]}, {P}], got {tuple(Y.shape)}")
+        if X.shape[0] > 0:
+            if prefill is not None and "KfuP" in prefill:  # the batched fill is already under way (start_fill)
+                whitened = [p for p in range(P) if self._per_latent(whiten_T, p) is not None]
+            else:
+                whitened = self._batch_plan(X.shape[0], Z.shape[0], kernel, P, whiten_T,
+                                            kw.get("whiten_mode", B.TRI_UPPER), project_T, kw.get("moments_on_kfu", False))
+            if whitened is not None:
+                return self._run_batched(X, Y, Z, kernel, whitened, moment_Tm=moment_Tm, moment_mode=kw["moment_mode"],
+                                         gamma=gamma, lik_id=kw.get("lik_id", B.LIK_NONE), lik_param=kw.get("lik_param", 0.0),
+                                         whiten_T=whiten_T, sites=kw.get("sites", False),
+                                         want_moments=kw.get("want_moments", False), want_grads=want_grads,
+                                         mean_only=kw.get("mean_only", False), prefill=prefill)
+        self.last_batched = False
         parts = []
         for p, kp in enumerate(kernel.kernels):
             if isinstance(whiten_T, (list, tuple)):  # per-latent routes: None = this latent works on K_fu directly
@@ -305,20 +465,44 @@ class EStepEngine:
         return out
 
     # ------------------------------------------------------------------ K(X, Z) fill beside the M x M prelude
-    def start_fill(self, X, Z, kernel, b_tag=None, want="Kfu"):
+    def start_fill(self, X, Z, kernel, b_tag=None, want="Kfu", routes=None):
         """Starts the K(X, Z) fill of the next ``run`` on a side stream and returns a ticket for ``run(prefill=...)``.
         The fill needs only X, Z and the kernel parameters, so it can run beside the latency-bound M x M prelude
         (factorisations of one workgroup each, small GEMMs) that the main stream executes between this call and
         ``run``: 3.26 -> 2.6 ms for the pair at N = 1e6, M = 1024 (tools/exp_overlap2.py).  Returns None when there is
-        nothing to overlap: separate kernels (one fill per latent), an operand ``run`` would reuse (warm E-steps), a
-        stream capture in progress."""
-        if (isinstance(kernel, SeparateIndependent) or self.device.type != "cuda" or X.shape[0] == 0
-                or torch.cuda.is_current_stream_capturing()):
+        nothing to overlap: separate kernels on the per-latent path (one fill per latent), an operand ``run`` would reuse
+        (warm E-steps), a stream capture in progress.  ``routes``: the projection route of every latent (separate kernels:
+        the batched pass, whose fill this starts, needs all of them direct or whitened)."""
+        if self.device.type != "cuda" or X.shape[0] == 0 or torch.cuda.is_current_stream_capturing():
             return None
         T, dev = self.dtype, self.device
         N, D = X.shape
         M = Z.shape[0]
         Np, Mp = B.round_up(N), B.round_up(M)
+        if isinstance(kernel, SeparateIndependent):
+            P = len(kernel.kernels)
+            if routes is None or any(r == "projected" for r in routes):
+                return None
+            if self._batch_plan(N, M, kernel, P, None, B.TRI_UPPER, None, False) is None:
+                return None
+            main = torch.cuda.current_stream(dev)
+            if self._side is None:
+                self._side = torch.cuda.Stream(dev)
+            side = self._side
+            Xc = X.to(device=dev, dtype=T).contiguous()
+            Zc = Z.to(device=dev, dtype=T).contiguous()
+            self._b_tag = None
+            self._buf.pop("Kfu", None)
+            self._buf.pop("B", None)
+            KfuP = self._get("KfuP", (P, Np, Mp), T)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                self._fill_batched(Xc, Zc, kernel, KfuP)
+                done = torch.cuda.Event()
+                done.record(side)
+            for t in (Xc, Zc, KfuP):
+                t.record_stream(side)
+            return dict(event=done, KfuP=KfuP)
         if (b_tag is not None and self._b_tag == (want, b_tag) and self._buf.get(want) is not None
                 and tuple(self._buf[want].shape) == (Np, Mp)):
             return None
@@ -371,7 +555,8 @@ class EStepEngine:
             return self._run_separate(X, Y, Z, kernel, moment_Tm=moment_Tm, moment_mode=moment_mode, gamma=gamma,
                                       lik_id=lik_id, lik_param=lik_param, whiten_T=whiten_T, whiten_mode=whiten_mode,
                                       project_T=project_T, sites=sites, want_moments=want_moments, want_grads=want_grads,
-                                      mean_only=mean_only, moments_on_kfu=moments_on_kfu, project_mode=project_mode)
+                                      mean_only=mean_only, moments_on_kfu=moments_on_kfu, project_mode=project_mode,
+                                      prefill=prefill)
         if mean_only and (lik_id & 0xFF) not in (B.LIK_NONE, B.LIK_GAUSSIAN):
             raise ValueError("mean_only needs a likelihood whose gradients do not depend on the predictive variance")
         T, dev = self.dtype, self.device

@@ -622,7 +622,7 @@ class t_SVGP(base_SVGP):
         pre = None
         if self.overlap_fill and hasattr(eng, "start_fill"):
             pre = eng.start_fill(X, self._Z(), self.kernel, b_tag=warm_key,
-                                 want="Kfu" if all(r == "direct" for r in routes) else "B")
+                                 want="Kfu" if all(r == "direct" for r in routes) else "B", routes=routes)
         ops = self._site_operands(whiten_jitter=jitter, warm_key=warm_key, routes=routes)
         st = eng.run(X, Y, ops["Z"], self.kernel, moment_Tm=ops["moment_Tm"], prefill=pre,
                      moment_mode=ops["moment_mode"], gamma=ops["gamma"],

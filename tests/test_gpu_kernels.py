@@ -275,3 +275,127 @@ def test_matern_fill(engines, dtype, tol, name, kind):
         K = out.double().cpu().numpy()
         assert relerr(K[:A.shape[0], :M], ker.K(A, Z)) < tol * 10
         assert np.all(K[A.shape[0]:, :] == 0) and np.all(K[:, M:] == 0)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# latent-batched entry points (BASELINE configs[4]): one launch over P latents with one kernel each
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype,tol", DTYPES)
+def test_kernel_fill_batched(engines, dtype, tol):
+    import ctypes
+
+    eng = engines[dtype]
+    B = pkg()._backend
+    rng = np.random.RandomState(11)
+    N, M, D, P = 300, 200, 5, 3
+    X, Z = rng.randn(N, D), rng.randn(M, D)
+    ls = 0.7 + rng.rand(P, D)
+    var = [1.3, 0.6, 2.0]
+    Np, Mp = B.round_up(N), B.round_up(M)
+    t = lambda a: torch.as_tensor(a, dtype=dtype, device="cuda:0").contiguous()
+    out = torch.full((P, Np, Mp), float("nan"), dtype=dtype, device="cuda:0")
+    ctype = ctypes.c_double if dtype == torch.float64 else ctypes.c_float
+    Xt, Zt, il = t(X), t(Z), t(1.0 / ls)
+    B.check(eng._fn("tsvgp_kernel_fill_batched")(B.KERNEL_SE, Xt.data_ptr(), Zt.data_ptr(), il.data_ptr(), (ctype * P)(*var),
+                                                 out.data_ptr(), Np * Mp, N, M, D, Mp, P, eng._stream()), "fill batched")
+    K = out.double().cpu().numpy()
+    for p in range(P):
+        ref = O.SquaredExponential(variance=var[p], lengthscales=ls[p]).K(X, Z)
+        assert relerr(K[p, :N, :M], ref) < tol * 10
+        assert np.all(K[p, N:, :] == 0) and np.all(K[p, :, M:] == 0)
+    # rejected: overlapping latent slices, too many latents
+    fn = eng._fn("tsvgp_kernel_fill_batched")
+    assert fn(B.KERNEL_SE, Xt.data_ptr(), Zt.data_ptr(), il.data_ptr(), (ctype * P)(*var), out.data_ptr(), Np * Mp - 2, N, M, D,
+              Mp, P, eng._stream()) == 1
+    assert fn(B.KERNEL_SE, Xt.data_ptr(), Zt.data_ptr(), il.data_ptr(), (ctype * P)(*var), out.data_ptr(), Np * Mp, N, M, D,
+              Mp, B.MAX_BATCH + 1, eng._stream()) == 1
+
+
+@pytest.mark.parametrize("dtype,tol", DTYPES)
+@pytest.mark.parametrize("mode,inplace", [(0, False), (1, False), (1, True), (2, False)])
+def test_trmm_batched(engines, dtype, tol, mode, inplace):
+    """tsvgp_trmm_batched_*: per-latent operands and factors, a shared operand (strideA = 0), and the in-place upper form."""
+    eng = engines[dtype]
+    B = pkg()._backend
+    rng = np.random.RandomState(12)
+    Np, Mp, P = 384, 256, 3
+    A = rng.randn(P, Np, Mp)
+    mask = {0: np.tril(np.ones((Mp, Mp))), 1: np.triu(np.ones((Mp, Mp))), 2: np.ones((Mp, Mp))}[mode]
+    Tm = rng.randn(P, Mp, Mp) * mask
+    t = lambda a: torch.as_tensor(a, dtype=dtype, device="cuda:0").contiguous()
+    At, Tt = t(A), t(Tm)
+    ref = np.einsum("pnj,pij->pni", At.double().cpu().numpy(), Tt.double().cpu().numpy())
+    fn = eng._fn("tsvgp_trmm_batched")
+    if inplace:
+        C = At.clone()
+        B.check(fn(C.data_ptr(), Np * Mp, Tt.data_ptr(), Mp * Mp, C.data_ptr(), Np * Mp, Np, Mp, mode, P, eng._stream()), "trmm")
+    else:
+        C = torch.full((P, Np, Mp), float("nan"), dtype=dtype, device="cuda:0")
+        B.check(fn(At.data_ptr(), Np * Mp, Tt.data_ptr(), Mp * Mp, C.data_ptr(), Np * Mp, Np, Mp, mode, P, eng._stream()), "trmm")
+    assert relerr(C.cpu().numpy(), ref) < tol * 20
+    # one shared operand for all latents
+    C2 = torch.empty((P, Np, Mp), dtype=dtype, device="cuda:0")
+    B.check(fn(At[1].data_ptr(), 0, Tt.data_ptr(), Mp * Mp, C2.data_ptr(), Np * Mp, Np, Mp, mode, P, eng._stream()), "trmm")
+    ref2 = np.einsum("nj,pij->pni", At[1].double().cpu().numpy(), Tt.double().cpu().numpy())
+    assert relerr(C2.cpu().numpy(), ref2) < tol * 20
+    # in place is refused for the lower and dense forms (a later tile would read what an earlier one overwrote)
+    if mode != 1:
+        assert fn(At.data_ptr(), Np * Mp, Tt.data_ptr(), Mp * Mp, At.data_ptr(), Np * Mp, Np, Mp, mode, P, eng._stream()) == 1
+
+
+@pytest.mark.parametrize("dtype,tol", DTYPES)
+@pytest.mark.parametrize("lik", ["gaussian", "bernoulli"])
+def test_moments_and_site_accum_batched(engines, dtype, tol, lik):
+    """One operand and one prior variance per latent: tsvgp_moments_batched_* + tsvgp_site_accum_batched_* against NumPy /
+    the oracle's likelihood maps."""
+    import ctypes
+
+    eng = engines[dtype]
+    B = pkg()._backend
+    rng = np.random.RandomState(13)
+    N, M, P = 333, 256, 3
+    Np = B.round_up(N)
+    A = np.zeros((P, Np, M))
+    A[:, :N] = rng.randn(P, N, M) / np.sqrt(M)
+    Tm = np.triu(rng.randn(P, M, M) * 0.5)
+    gamma = rng.randn(M, P)
+    kd = [2.5, 3.0, 2.2]
+    Y = (rng.rand(N, P) > 0.5).astype(float) if lik == "bernoulli" else rng.randn(N, P)
+    t = lambda a: torch.as_tensor(a, dtype=dtype, device="cuda:0").contiguous()
+    At, Tmt, gt, Yt = t(A), t(Tm), t(gamma), t(Y)
+    mean = torch.empty((N, P), dtype=dtype, device="cuda:0")
+    var = torch.empty((N, P), dtype=dtype, device="cuda:0")
+    g0 = torch.full((Np, P), float("nan"), dtype=dtype, device="cuda:0")
+    g1 = torch.full((Np, P), float("nan"), dtype=dtype, device="cuda:0")
+    vep = torch.zeros(Np // 128, dtype=torch.float64, device="cuda:0")
+    npp = torch.zeros(Np // 128, dtype=torch.int32, device="cuda:0")
+    lik_id = {"gaussian": 1, "bernoulli": 2}[lik]
+    B.check(eng._fn("tsvgp_moments_batched")(At.data_ptr(), Np * M, Tmt.data_ptr(), gt.data_ptr(), Yt.data_ptr(),
+                                             (ctypes.c_double * P)(*kd), lik_id, 0.3, mean.data_ptr(), var.data_ptr(),
+                                             g0.data_ptr(), g1.data_ptr(), vep.data_ptr(), npp.data_ptr(), N, Np, M, P, 1,
+                                             eng._stream()), "moments batched")
+    Ad, Td, gd = At.double().cpu().numpy(), Tmt.double().cpu().numpy(), gt.double().cpu().numpy()
+    C = np.einsum("pnj,pij->pni", Ad[:, :N], Td)
+    vref = (np.asarray(kd)[:, None] - np.sum(C * C, axis=-1)).T
+    mref = np.einsum("pnj,jp->np", Ad[:, :N], gd)
+    assert relerr(mean.cpu().numpy(), mref) < tol * 20
+    assert np.max(np.abs(var.double().cpu().numpy() - vref)) < tol * 20 * max(kd)
+    assert int(npp.sum()) == int(np.sum(vref <= 0)) == 0
+    olik = O.Gaussian(variance=0.3) if lik == "gaussian" else O.Bernoulli()
+    mu_k, var_k = mean.double().cpu().numpy(), var.double().cpu().numpy()
+    r0, r1 = olik.variational_expectations_grads(mu_k, var_k, Y)
+    r1 = np.minimum(r1, -1e-8)
+    ltol = 1e-10 if dtype == torch.float64 else 1e-5
+    np.testing.assert_allclose(g0.double().cpu().numpy()[:N], r0, rtol=ltol, atol=ltol)
+    np.testing.assert_allclose(g1.double().cpu().numpy()[:N], r1, rtol=ltol, atol=ltol)
+    assert np.all(g0.cpu().numpy()[N:] == 0) and np.all(g1.cpu().numpy()[N:] == 0)
+    # site sums over the per-latent operands
+    nsplit = 3
+    work = torch.empty(int(eng._fn("tsvgp_site_accum_work_bytes")(M, P, nsplit)), dtype=torch.uint8, device="cuda:0")
+    acc2 = torch.full((P, M, M), float("nan"), dtype=torch.float64, device="cuda:0")
+    acc1 = torch.full((P, M), float("nan"), dtype=torch.float64, device="cuda:0")
+    B.check(eng._fn("tsvgp_site_accum_batched")(At.data_ptr(), Np * M, g0.data_ptr(), g1.data_ptr(), acc2.data_ptr(),
+                                                acc1.data_ptr(), work.data_ptr(), Np, M, P, nsplit, eng._stream()), "site_accum")
+    g0d, g1d = g0.double().cpu().numpy(), g1.double().cpu().numpy()
+    assert relerr(acc2.cpu().numpy(), np.einsum("pnm,pno,np->pmo", Ad, Ad, g1d)) < tol * 50
+    assert relerr(acc1.cpu().numpy(), np.einsum("pnm,np->pm", Ad, g0d)) < tol * 50

@@ -578,3 +578,33 @@ def test_predict_y_and_log_density_match_oracle(lik, separate):
     assert relerr(ld_h, ld_o) < 1e-8
     nlpd_h, nlpd_o = -float(np.mean(ld_h)), -float(np.mean(ld_o))
     assert abs(nlpd_h - nlpd_o) < 1e-9 * abs(nlpd_o)
+
+
+@pytest.mark.parametrize("batched", [True, False])
+def test_p8_separate_kernels_match_oracle(batched):
+    """BASELINE configs[4] at small N: P = 8 latents, one SE kernel per latent with l_p = linspace(0.8, 1.5, 8) on shared
+    inducing points, M = 192.  `batched`: the latent-batched launches (fill / in-place whitening / moments / site sums,
+    one each: tsvgp_*_batched_*) against the one-pass-per-latent path; both against the oracle.  Long lengthscales are
+    whitened, short ones direct ("auto" decides per latent), so the batched whitening runs on a sub-range of the latents."""
+    p = pkg()
+    P, M, D = 8, 192, 8
+    X, Y, Z = synthetic(N=1500, M=M, D=D, P=P, lik="gaussian", seed=5)
+    ls = np.linspace(0.8, 1.5, P)
+    hip = p.t_SVGP(p.SeparateIndependent([p.SquaredExponential(1.0, float(l)) for l in ls]), p.Gaussian(0.1),
+                   p.SharedIndependentInducingVariables(Z), num_latent_gps=P)
+    ora = O.t_SVGP(O.SeparateIndependent([O.SquaredExponential(1.0, float(l)) for l in ls]), O.Gaussian(0.1),
+                   O.SharedIndependentInducingVariables(Z), num_latent_gps=P)
+    eng = hip._get_engine()
+    eng.batch_separate = batched
+    routes = hip._routes(1e-9)
+    assert "direct" in routes and "whitened" in routes
+    for _ in range(3):
+        hip.natgrad_step((X, Y), lr=0.8)
+        ora.natgrad_step((X, Y), lr=0.8)
+        _compare_state(hip, ora, 1e-8)
+    assert eng.last_batched == batched
+    e_h, e_o = float(hip.elbo((X, Y))), float(ora.elbo((X, Y)))
+    assert abs(e_h - e_o) / abs(e_o) < 1e-9
+    mu_h, var_h = hip.predict_f(X[:200] + 0.05)
+    mu_o, var_o = ora.predict_f(X[:200] + 0.05)
+    assert relerr(mu_h.cpu().numpy(), mu_o) < 1e-8 and relerr(var_h.cpu().numpy(), var_o) < 1e-8
