@@ -357,7 +357,7 @@ def test_moments_and_site_accum_batched(engines, dtype, tol, lik):
     Np = B.round_up(N)
     A = np.zeros((P, Np, M))
     A[:, :N] = rng.randn(P, N, M) / np.sqrt(M)
-    Tm = np.triu(rng.randn(P, M, M) * 0.5)
+    Tm = np.triu(rng.randn(P, M, M) * 0.1)  # q = |Tm a|^2 ~ 1.3 < kdiag: positive variances
     gamma = rng.randn(M, P)
     kd = [2.5, 3.0, 2.2]
     Y = (rng.rand(N, P) > 0.5).astype(float) if lik == "bernoulli" else rng.randn(N, P)

@@ -596,8 +596,11 @@ def test_p8_separate_kernels_match_oracle(batched):
                    O.SharedIndependentInducingVariables(Z), num_latent_gps=P)
     eng = hip._get_engine()
     eng.batch_separate = batched
+    hip._routes(1e-9)
+    conds = sorted(hip._cond_cache[1])
+    hip.DIRECT_MAX_COND = {torch.float64: 0.5 * (conds[2] + conds[3])}  # this model only: the five longest lengthscales whiten
     routes = hip._routes(1e-9)
-    assert "direct" in routes and "whitened" in routes
+    assert routes == ["direct"] * 3 + ["whitened"] * 5
     for _ in range(3):
         hip.natgrad_step((X, Y), lr=0.8)
         ora.natgrad_step((X, Y), lr=0.8)
