@@ -77,9 +77,10 @@ def kernel_flops(w, rows, batched=True, trmm_batch=1):
     }
 
 
-def kernel_bytes(w, rows, esize):
+def kernel_bytes(w, rows, esize, batched=False):
     """Algorithmic HBM bytes per launch of the fill kernel (the only HBM-bound kernel): write Kfu once, read X once."""
-    return {"tsvgp_se_fill": rows * w["M"] * esize + rows * w["D"] * esize}
+    P = w["P"] if (w.get("separate") and batched) else 1  # the batched fill writes every latent's K(X, Z) in one launch
+    return {"tsvgp_se_fill": P * rows * w["M"] * esize + rows * w["D"] * esize}
 
 
 def make_kernel(mod, w):
@@ -399,7 +400,7 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         flops = kernel_flops(w, rows, batched=getattr(eng, "last_batched", False) or not w.get("separate"),
                              trmm_batch=getattr(eng, "last_trmm_batch", 1) if w.get("separate") else 1)
-        byts = kernel_bytes(w, rows, esize)
+        byts = kernel_bytes(w, rows, esize, batched=getattr(eng, "last_batched", False))
         kern_ms = {k: v[1] for k, v in prof.items()}
         mfma = {k: kern_ms[k] for k in flops if k in kern_ms}
         dom = max(mfma, key=mfma.get) if mfma else None

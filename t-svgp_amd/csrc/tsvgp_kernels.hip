@@ -353,7 +353,11 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, TSV
                 out[0] = (rowok && v0) ? variance * kernel_profile<KIND>(s0) : T(0);
                 out[1] = (rowok && v1) ? variance * kernel_profile<KIND>(s1) : T(0);
 #endif
+#ifdef TSVGP_FILL_NT  // experiment: streaming (non-temporal) stores
+                __builtin_nontemporal_store(out, reinterpret_cast<pair_t*>(K + n * ldk + m));
+#else
                 *reinterpret_cast<pair_t*>(K + n * ldk + m) = out;
+#endif
             }
         }
         if (rb + gridDim.x < nrb) __syncthreads();  // Xs is rewritten by the next row block
@@ -538,6 +542,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void panel_kernel(PanelArgs<T> a) {
 
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+#ifdef TSVGP_DIAG_PANEL  // diagnostic build (tools/diag_panel.py): when and where every workgroup ran
+    const unsigned long long diag_t0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long diag_c0 = __builtin_amdgcn_s_memtime();
+#endif
+#ifdef TSVGP_EXP_SLOTPRIO  // experiment: the second resident workgroup of a CU (second dispatch half-round) at wave priority 1
+    if ((blockIdx.x >> 8) & 1) __builtin_amdgcn_s_setprio(TSVGP_EXP_SLOTPRIO);
+#endif
+#ifdef TSVGP_EXP_STAGGER  // experiment: delay the second resident workgroup of a CU by a fraction of a chunk
+    if ((blockIdx.x >> 8) & 1) {
+        for (int i = 0; i < TSVGP_EXP_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
     const int srow = t >> 1, skh = t & 1;  // staging role: row of the tile, which half of the k-chunk
     const int64_t n0 = (int64_t)blockIdx.x * TILE;
     const int Mp = a.Mp;
@@ -790,7 +806,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void panel_kernel(PanelArgs<T> a) {
                 if (skh == 0) {
                     if (live) {
                         if (!(v > 0.0)) nonpos += 1;
+#ifndef TSVGP_DIAG_PANEL
                         if (a.mean) a.mean[n * a.P + p] = (T)mu;
+#endif
                         if (a.var) a.var[n * a.P + p] = (T)v;
                         ve_acc += ve;
                     }
@@ -822,6 +840,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void panel_kernel(PanelArgs<T> a) {
             if (a.nonpos_partial) a.nonpos_partial[blockIdx.x] = redi[0] + redi[1] + redi[2] + redi[3];
         }
     }
+#ifdef TSVGP_DIAG_PANEL
+    // stamps go to a buffer of their own (passed in place of `mean`, which this build never writes: see the guard below)
+    if (t == 0 && a.mean) {
+        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(a.mean) + (size_t)blockIdx.x * 4;
+        dbg[0] = diag_t0;
+        dbg[1] = __builtin_amdgcn_s_memrealtime();
+        dbg[2] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)) |          // HW_REG_HW_ID
+                 ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)) << 32);  // HW_REG_XCC_ID
+        dbg[3] = __builtin_amdgcn_s_memtime() - diag_c0;  // shader cycles of this workgroup
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------

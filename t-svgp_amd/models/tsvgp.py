@@ -42,6 +42,7 @@ from ..kernels import SeparateIndependent, latent_kernels
 from ..sites import DenseSites
 from ..util import (
     cholesky_deferred,
+    cond2_estimate,
     gradient_transformation_mean_var_to_expectation,
     info_sum,
     kl_from_dense_site,
@@ -230,7 +231,7 @@ class t_SVGP(base_SVGP):
                      for k in latent_kernels(self.kernel, self.num_latent_gps))
 
     # Route gates on cond(K_uu + jitter I), per latent GP.  direct: K^-1 (sum g k k^T) K^-1 cancels two factors of K, so its
-    # error grows faster than cond.  Measured against the oracle at the benchmark's M = 1024, D = 8 (tools/route_gate.py,
+    # error grows faster than cond.  Measured against the CPU restatement of the reference at the benchmark's M = 1024, D = 8 (tools/route_gate.py,
     # profiles/r02_route_gate_m1024.txt; max rel err of lambda_1 / Lambda_2 after two steps): 5e-13 at cond 5e2, 2e-11 at
     # 4e3, 4e-11 at 1e4, 2e-10 at 2e4, 8e-10 at 5e4, 1.1e-8 at 2.5e5, 1.5e-7 at 1.8e6 -- it reaches 1e-9, a tenth of the
     # stated 1e-8, near cond 6e4: that is the fp64 gate (round 1 had 1e3, set from M <= 64 fixtures).  fp32: cond <= 30
@@ -243,17 +244,18 @@ class t_SVGP(base_SVGP):
 
     def _routes(self, jitter) -> list:
         """The projection route of every latent GP (one decision for all latents under a shared kernel): "direct",
-        "whitened" or "projected".  In "auto" mode the 2-norm condition number of K_uu + jitter I is computed (symmetric
-        eigenvalues, M x M, one host read) only when the kernel parameters, Z or the jitter changed."""
+        "whitened" or "projected".  In "auto" mode the 2-norm condition number of K_uu + jitter I is estimated
+        (``util.cond2_estimate``: one factorisation + power iterations, M x M, one host read) only when the kernel
+        parameters, Z or the jitter changed."""
         P = self.num_latent_gps
         if self.projection != "auto":
             return [self.projection] * P
         key = (self._kernel_versions(), id(self.inducing_variable.Z), self.inducing_variable.Z.version, float(jitter))
         if self._cond_cache is None or self._cond_cache[0] != key:
-            Kzz = self._get_engine().kuu(self._Z(), self.kernel)  # [M, M] or [P, M, M]
-            ev = torch.linalg.eigvalsh(Kzz + jitter * torch.eye(Kzz.shape[-1], dtype=Kzz.dtype, device=Kzz.device))
-            lo, hi = ev[..., 0], ev[..., -1]
-            cond = torch.where(lo > 0, hi / lo, torch.full_like(lo, float("inf"))).reshape(-1)
+            eng = self._get_engine()
+            Kzz = eng.kuu(self._Z(), self.kernel)  # [M, M] or [P, M, M]
+            Kzz.diagonal(dim1=-2, dim2=-1).add_(jitter)
+            cond = cond2_estimate(Kzz, getattr(eng, "cholesky", None)).reshape(-1)
             cond = D_.broadcast_from_rank0(cond.contiguous()).tolist()  # one decision for all ranks
             self._cond_cache = (key, cond if len(cond) == P else cond * P, {})
         dmax, wmax = self.DIRECT_MAX_COND[self.compute_dtype], self.WHITENED_MAX_COND[self.compute_dtype]

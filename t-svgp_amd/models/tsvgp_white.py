@@ -37,7 +37,7 @@ from .. import distributed as D_
 from ..base import default_jitter, to_tensor
 from ..kernels import SeparateIndependent
 from ..sites import DenseSites
-from ..util import cholesky_deferred, info_sum, rev_cholesky
+from ..util import cholesky_deferred, cond2_estimate, info_sum, rev_cholesky
 from .tsvgp import base_SVGP
 
 
@@ -170,14 +170,15 @@ class t_SVGP_white(base_SVGP):
     ROBUST_MIN_COND = 1.0e6  # beyond this the factorisations run by substitution (EStepEngine.cholesky(robust=True))
 
     def _cond_k6(self) -> float:
-        """cond(K_uu + default_jitter I): one symmetric eigenvalue problem per change of the kernel parameters or Z,
-        taken from rank 0."""
+        """cond(K_uu + default_jitter I), estimated (``util.cond2_estimate``) once per change of the kernel parameters or
+        Z, taken from rank 0."""
         k, Zp = self.kernel, self.inducing_variable.Z
         key = (id(k), k.variance.version, k.lengthscales.version, id(Zp), Zp.version)
         if self._cond_cache is None or self._cond_cache[0] != key:
-            Kzz = self._get_engine().kuu(self._Z(), k)
-            ev = torch.linalg.eigvalsh(Kzz + default_jitter() * torch.eye(Kzz.shape[-1], dtype=Kzz.dtype, device=Kzz.device))
-            cond = torch.where(ev[0] > 0, ev[-1] / ev[0], torch.full_like(ev[0], float("inf"))).reshape(1)
+            eng = self._get_engine()
+            Kzz = eng.kuu(self._Z(), k)
+            Kzz.diagonal(dim1=-2, dim2=-1).add_(default_jitter())
+            cond = cond2_estimate(Kzz, getattr(eng, "cholesky", None)).reshape(1)
             self._cond_cache = (key, float(D_.broadcast_from_rank0(cond.contiguous())))
             self._direct_failed = False
         return self._cond_cache[1]

@@ -54,6 +54,35 @@ def rev_cholesky(a: torch.Tensor, infos: list, potrf=None, inverse: bool = False
     return torch.flip(res, (-2, -1))
 
 
+def cond2_estimate(A: torch.Tensor, potrf=None, iters: int = 32) -> torch.Tensor:
+    """Estimate of the 2-norm condition number of the symmetric positive definite A [..., M, M] (one value per matrix,
+    device tensor, no host synchronisation): lambda_max by power iteration on A, 1 / lambda_min by power iteration on
+    A^-1 = X^T X with X the inverse Cholesky factor (one factorisation; ``potrf`` as in ``cholesky_deferred``).  Both
+    Rayleigh quotients approach their eigenvalue from inside the spectrum, so the estimate is a LOWER bound of cond_2,
+    within a few percent after 32 steps on kernel matrices (their small eigenvalues decay geometrically or sit on the
+    jitter); ``inf`` where the factorisation fails.  Replaces a symmetric eigendecomposition (22 ms at M = 1024 through
+    rocSOLVER) by ~2 ms of GEMVs in the route gate of the models."""
+    A = A if A.dim() == 3 else A[None]
+    infos = []
+    _, X = cholesky_deferred(A.clone(), infos, potrf, inverse=True, overwrite=True)
+    M = A.shape[-1]
+    g = torch.Generator(device="cpu").manual_seed(1234)
+    v0 = torch.randn(M, 2, generator=g, dtype=torch.float64).to(A.device)
+    v = v0.expand(A.shape[0], M, 2).clone()  # two start vectors per matrix: the larger quotient is kept
+    w = v.clone()
+    for _ in range(iters):
+        v = A @ v
+        v = v / torch.linalg.vector_norm(v, dim=-2, keepdim=True)
+        w = X.transpose(-1, -2) @ (X @ w)
+        w = w / torch.linalg.vector_norm(w, dim=-2, keepdim=True)
+    lam_max = torch.sum(v * (A @ v), dim=-2).amax(dim=-1)
+    Xw = X @ w
+    inv_min = torch.sum(Xw * Xw, dim=-2).amax(dim=-1)
+    cond = lam_max * inv_min
+    bad = (infos[0].reshape(-1) != 0) | ~torch.isfinite(cond)
+    return torch.where(bad, torch.full_like(cond, float("inf")), cond)
+
+
 def _check_site_shapes(K, lambda_1, lambda_2_sqrt, who):
     if K.dim() < 2 or K.shape[-1] != K.shape[-2]:
         raise ValueError(f"{who}: K must be [..., M, M]")
