@@ -182,7 +182,14 @@ int tsvgp_site_accum_batched_f32(const float *B, int64_t strideB, const float *g
  *     src/util.py:377-388.  M must be a multiple of 128 (pad with an identity block), lda >= M, matrix b starts at
  *     A + b*stride.  info[b] = 0, or the 1-based index of the first non-positive pivot (LAPACK potrf convention).
  *     work: batch * 128 * 128 doubles. */
-int tsvgp_potrf_f64(double *A, int M, int lda, int batch, int64_t stride, int32_t *info, double *work, void *stream);
+#define TSVGP_POTRF_SUBST 1 /* flags: solve the panels below each diagonal block by substitution against L_kk (16-wide
+                               sub-blocks by forward substitution, the rest by MFMA updates, as LAPACK's blocked trsm)
+                               instead of multiplying by inv(L_kk): ~0.15 ms slower at M = 1024, but as robust as a
+                               LAPACK factorisation on numerically barely definite matrices (cond ~ 1e14), where the
+                               inverse-based panels lose cond(L_kk) digits of the trailing matrix.  The callers set it
+                               when cond(K_uu + jitter I) is beyond 1e7. */
+int tsvgp_potrf_f64(double *A, int M, int lda, int batch, int64_t stride, int32_t *info, double *work, int flags,
+                    void *stream);
 
 /* (6b) The same factorisation plus the inverse factor: X[b] = inv(L[b]) (lower triangular, exact zeros above) and
  *     Xt[b] = X[b]^T, both [batch x M x M] row-major (leading dimension M).  The inverted diagonal blocks the panel
@@ -191,7 +198,7 @@ int tsvgp_potrf_f64(double *A, int M, int lda, int batch, int64_t stride, int32_
  *     (reference src/util.py:168-175, src/models/tsvgp.py:270-271): the callers apply X by GEMM.
  *     T: scratch, batch * M * M doubles.  Other arguments as tsvgp_potrf_f64. */
 int tsvgp_potrf_inv_f64(double *A, int M, int lda, int batch, int64_t stride, int32_t *info, double *work, double *X,
-                        double *Xt, double *T, void *stream);
+                        double *Xt, double *T, int flags, void *stream);
 
 /* (8) Kernel-parameter gradient contraction for the M-step (d ELBO / d theta with the sites fixed: reference
  *     experiments/uci_regression.py:159-160, pinned by tests/models/test_tsvgp.py:168-188; TensorFlow autodiff there).

@@ -25,6 +25,7 @@ LIK_NOCROP = 0x100
 LIK_MEANONLY = 0x200
 KERNEL_SE, KERNEL_MATERN32, KERNEL_MATERN52 = 0, 2, 3
 TRI_LOWER, TRI_UPPER, TRI_DENSE = 0, 1, 2
+POTRF_SUBST = 1  # TSVGP_POTRF_SUBST
 
 _lib = None
 
@@ -92,9 +93,9 @@ _PROTOTYPES = {
     "tsvgp_site_accum_work_bytes_f32": (c_int64, [c_int, c_int, c_int]),
     "tsvgp_site_accum_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     "tsvgp_site_accum_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
-    "tsvgp_potrf_f64": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p]),
+    "tsvgp_potrf_f64": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_void_p, c_int, c_void_p]),
     "tsvgp_potrf_inv_f64": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                    c_void_p]),
+                                    c_int, c_void_p]),
     "tsvgp_selftest_mfma_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "tsvgp_selftest_mfma_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
 }

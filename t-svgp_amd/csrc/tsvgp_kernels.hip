@@ -1590,6 +1590,83 @@ __global__ __launch_bounds__(NTHREADS) void chol_tile_kernel(double* __restrict_
         }
 }
 
+// Panel solve by SUBSTITUTION (TSVGP_POTRF_SUBST): X L_kk^T = A_ik for the rows below the diagonal block, without the
+// inverse of L_kk.  chol_tile_kernel<0> multiplies by inv(L_kk), which costs a factor cond(L_kk) of accuracy in the
+// trailing matrix: harmless for the site matrices of a well-conditioned K_uu, but a numerically barely definite matrix
+// (cond ~ 1e14, lambda_min ~ 30 eps lambda_max: the new Lambda_2 on a K_uu with cond 1e10) then loses its definiteness
+// at the first pivot of the next block where a LAPACK-style factorisation goes through.  Here, as in LAPACK's blocked
+// trsm, only 16 x 16 diagonal sub-blocks are solved against directly (one lane per row, forward substitution, IEEE
+// division) and the rest of the row block is updated with MFMA tiles:
+//   for s in sub-blocks:  X[:, s] = A[:, s] L_ss^-T ;  A[:, >s] -= X[:, s] L[>s, s]^T
+// One workgroup per PS_ROWS rows of the panel; the rows and the current 16-wide column block of L_kk live in LDS.
+constexpr int PS_ROWS = 64;
+constexpr int PS_LD = CH_SB + 1;
+__global__ __launch_bounds__(NTHREADS) void chol_panel_subst_kernel(double* __restrict__ Amat, int lda, int64_t stride, int k) {
+    static_assert(CH_SB == 16, "sub-block width of the substitution panel");
+    __builtin_amdgcn_s_setprio(TSVGP_CHOL_PRIO);
+    __shared__ double Pn[PS_ROWS][CH_LD];
+    __shared__ double Lc[CH_NB][PS_LD];
+    __shared__ double dinv[CH_SB];
+    const int t = threadIdx.x, lane = t & 63, li = lane & 15, lk = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    double* Ab = Amat + (size_t)blockIdx.y * stride;
+    const size_t row0 = (size_t)(k + 1) * CH_NB + (size_t)blockIdx.x * PS_ROWS, col0 = (size_t)k * CH_NB;
+    for (int idx = t; idx < PS_ROWS * CH_NB / 2; idx += NTHREADS) {
+        const int r = idx >> 6, c = (idx & 63) * 2;
+        const v2d v = *reinterpret_cast<const v2d*>(Ab + (row0 + r) * lda + col0 + c);
+        Pn[r][c] = v[0];
+        Pn[r][c + 1] = v[1];
+    }
+    for (int s0 = 0; s0 < CH_NB; s0 += CH_SB) {
+        const int nr = CH_NB - s0;  // rows of L_kk from the sub-block down
+        __syncthreads();           // the previous update has read Lc; the first pass: Pn is complete
+        for (int idx = t; idx < nr * CH_SB; idx += NTHREADS) {
+            const int r = idx >> 4, c = idx & 15;
+            Lc[r][c] = Ab[(col0 + s0 + r) * lda + col0 + s0 + c];
+        }
+        __syncthreads();
+        if (t < CH_SB) dinv[t] = 1.0 / Lc[t][t];
+        __syncthreads();
+        if (t < PS_ROWS) {  // one lane per row: x_c = (a_c - sum_{j<c} x_j L_ss[c][j]) / L_ss[c][c]
+            double a[CH_SB];
+#pragma unroll
+            for (int c = 0; c < CH_SB; ++c) a[c] = Pn[t][s0 + c];
+#pragma unroll
+            for (int c = 0; c < CH_SB; ++c) {
+                double v[4] = {a[c], 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int j = 0; j < c; ++j) v[j & 3] = fma(-a[j], Lc[c][j], v[j & 3]);
+                a[c] = ((v[0] + v[1]) + (v[2] + v[3])) * dinv[c];
+            }
+#pragma unroll
+            for (int c = 0; c < CH_SB; ++c) Pn[t][s0 + c] = a[c];
+        }
+        __syncthreads();
+        // A[:, s0 + 16 + 16 cb ..] -= X[:, s0 .. s0 + 16] * L[s0 + 16 + 16 cb .., s0 .. s0 + 16]^T on 16 x 16 MFMA tiles
+        const int ncb = (nr - CH_SB) / 16, ntile = (PS_ROWS / 16) * ncb;
+        for (int ti = w; ti < ntile; ti += NTHREADS / 64) {
+            const int rb = ti / ncb, cb = ti - rb * ncb;
+            const int c0 = s0 + CH_SB + 16 * cb;
+            v4d acc;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = Pn[16 * rb + lk + 4 * r][c0 + li];
+#pragma unroll
+            for (int kk = 0; kk < CH_SB / 4; ++kk)
+                acc = Mfma<double>::run(-Pn[16 * rb + li][s0 + 4 * kk + lk], Lc[CH_SB + 16 * cb + li][4 * kk + lk], acc);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Pn[16 * rb + lk + 4 * r][c0 + li] = acc[r];
+        }
+    }
+    __syncthreads();
+    for (int idx = t; idx < PS_ROWS * CH_NB / 2; idx += NTHREADS) {
+        const int r = idx >> 6, c = (idx & 63) * 2;
+        v2d v;
+        v[0] = Pn[r][c];
+        v[1] = Pn[r][c + 1];
+        *reinterpret_cast<v2d*>(Ab + (row0 + r) * lda + col0 + c) = v;
+    }
+}
+
 // inv(L) from the inverted diagonal blocks by the 2x2 recursion, one level per launch pair:
 //   [[L00, 0], [L10, L11]]^-1 = [[X00, 0], [-X11 L10 X00, X11]]      (blocks of n rows; the second may be shorter)
 // with X (lower, row-major) and Xt = X^T kept side by side so that every product is of the form A * B^T with both
@@ -1913,10 +1990,11 @@ int site_accum_slots() {
     return cus * nb;
 }
 
-int potrf(double* A, int M, int lda, int batch, int64_t stride, int* info, double* work, void* stream,
+int potrf(double* A, int M, int lda, int batch, int64_t stride, int* info, double* work, int flags, void* stream,
           double* X = nullptr, double* Xt = nullptr, double* T = nullptr) {
-    if (!A || !info || !work || M <= 0 || (M % CH_NB) || lda < M || batch <= 0) return TSVGP_EINVAL;
-    const bool inv = X != nullptr;
+    if (!A || !info || !work || M <= 0 || (M % CH_NB) || lda < M || batch <= 0 || (flags & ~TSVGP_POTRF_SUBST))
+        return TSVGP_EINVAL;
+    const bool inv = X != nullptr, subst = (flags & TSVGP_POTRF_SUBST) != 0;
     if (inv && (!Xt || !T)) return TSVGP_EINVAL;
     const int nt = M / CH_NB;
     const size_t smem = (size_t)CH_NB * CH_LD * sizeof(double);
@@ -1932,12 +2010,16 @@ int potrf(double* A, int M, int lda, int batch, int64_t stride, int* info, doubl
     const int wpb = NTHREADS / 64;
     for (int k = 0; k < nt; ++k) {
         hipLaunchKernelGGL(potrf_diag_kernel, dim3(batch), dim3(CH_THREADS), smem, st, A, lda, stride, k, work, info,
-                           (inv || k + 1 < nt) ? 1 : 0, X, Xt, M, xstride);
+                           (inv || (k + 1 < nt && !subst)) ? 1 : 0, X, Xt, M, xstride);
         const int below = nt - k - 1;
         if (below > 0) {
             const int nb32 = below * (CH_NB / CH_WT), ntile = nb32 * (nb32 + 1) / 2;
-            hipLaunchKernelGGL(chol_tile_kernel<0>, dim3(nb32, batch), dim3(NTHREADS), 0, st, A, lda, stride, k, nt,
-                               work);
+            if (subst)
+                hipLaunchKernelGGL(chol_panel_subst_kernel, dim3(below * (CH_NB / PS_ROWS), batch), dim3(NTHREADS), 0, st, A,
+                                   lda, stride, k);
+            else
+                hipLaunchKernelGGL(chol_tile_kernel<0>, dim3(nb32, batch), dim3(NTHREADS), 0, st, A, lda, stride, k, nt,
+                                   work);
             hipLaunchKernelGGL(chol_tile_kernel<1>, dim3((ntile + wpb - 1) / wpb, batch), dim3(NTHREADS), 0, st, A,
                                lda, stride, k, nt, work);
         }
@@ -2094,13 +2176,14 @@ int tsvgp_site_accum_f32(const float* B, const float* g0, const float* g1, doubl
     return site_accum<float>(B, 0, g0, g1, acc2, acc1, work, Np, Mp, P, nsplit, stream);
 }
 
-int tsvgp_potrf_f64(double* A, int M, int lda, int batch, int64_t stride, int* info, double* work, void* stream) {
-    return potrf(A, M, lda, batch, stride, info, work, stream);
+int tsvgp_potrf_f64(double* A, int M, int lda, int batch, int64_t stride, int* info, double* work, int flags,
+                    void* stream) {
+    return potrf(A, M, lda, batch, stride, info, work, flags, stream);
 }
 int tsvgp_potrf_inv_f64(double* A, int M, int lda, int batch, int64_t stride, int* info, double* work, double* X,
-                        double* Xt, double* T, void* stream) {
+                        double* Xt, double* T, int flags, void* stream) {
     if (!X || !Xt || !T) return TSVGP_EINVAL;
-    return potrf(A, M, lda, batch, stride, info, work, stream, X, Xt, T);
+    return potrf(A, M, lda, batch, stride, info, work, flags, stream, X, Xt, T);
 }
 
 int tsvgp_kernel_grad_rows(void) { return KG_ROWS; }

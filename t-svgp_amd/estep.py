@@ -183,18 +183,13 @@ class EStepEngine:
         A [.., M, M] fp64 (lower triangle referenced) -> (L [.., M, M] with zeros above the diagonal, info [batch] int32);
         with ``inverse`` also inv(L) (``tsvgp_potrf_inv_f64``), lower triangular with exact zeros above.
         ``overwrite``: A is a temporary of the caller and may be factored in place (no copy when M is a multiple of 128).
-        ``robust``: factor by substitution (rocSOLVER potrf + a triangular solve for the inverse) instead: the blocked
-        kernel solves its panels by multiplying with the INVERTED diagonal block, which costs it a factor cond(L_kk) of
-        accuracy in the trailing matrix -- irrelevant for the matrices of a well-conditioned K_uu (and 4x faster), but a
-        numerically barely definite matrix (cond ~ 1e14, lambda_min ~ 30 eps lambda_max) then fails where LAPACK-style
-        factorisations go through.  The callers ask for it on the "projected" route, whose matrices are of that kind."""
+        ``robust``: solve the panels below each diagonal block by substitution (TSVGP_POTRF_SUBST) instead of multiplying
+        with the INVERTED diagonal block, which costs a factor cond(L_kk) of accuracy in the trailing matrix -- irrelevant
+        for the matrices of a well-conditioned K_uu (and ~0.15 ms faster), but a numerically barely definite matrix
+        (cond ~ 1e14, lambda_min ~ 30 eps lambda_max) then fails where LAPACK-style factorisations go through.  The
+        callers ask for it on the "projected" route, whose matrices are of that kind."""
         A = A.to(device=self.device, dtype=torch.float64)
-        if robust:
-            L, info = torch.linalg.cholesky_ex(A, upper=False, check_errors=False)
-            if not inverse:
-                return L, info
-            eye = torch.eye(A.shape[-1], dtype=torch.float64, device=self.device)
-            return L, info, torch.linalg.solve_triangular(L, eye.expand_as(L), upper=False)
+        flags = B.POTRF_SUBST if robust else 0
         M = A.shape[-1]
         batch_shape = A.shape[:-2]
         Mp = B.round_up(M)
@@ -218,10 +213,10 @@ class EStepEngine:
                 T = self._get("potrf_T", (nb, Mp, Mp), torch.float64)
                 self._launch("tsvgp_potrf", lambda: self.lib.tsvgp_potrf_inv_f64(
                     W.data_ptr(), Mp, Mp, nb, Mp * Mp, info.data_ptr(), work.data_ptr(), X[0].data_ptr(), X[1].data_ptr(),
-                    T.data_ptr(), self._stream()))
+                    T.data_ptr(), flags, self._stream()))
             else:
                 self._launch("tsvgp_potrf", lambda: self.lib.tsvgp_potrf_f64(
-                    W.data_ptr(), Mp, Mp, nb, Mp * Mp, info.data_ptr(), work.data_ptr(), self._stream()))
+                    W.data_ptr(), Mp, Mp, nb, Mp * Mp, info.data_ptr(), work.data_ptr(), flags, self._stream()))
         L = torch.tril(W[:, :M, :M]).reshape(out_shape)
         if inverse:
             return L, info, X[0, :, :M, :M].reshape(out_shape)

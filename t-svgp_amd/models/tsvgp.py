@@ -292,7 +292,8 @@ class t_SVGP(base_SVGP):
         potrf = getattr(eng, "cholesky", None)  # HIP blocked Cholesky (tsvgp_potrf_f64)
         if potrf is not None and routes is not None and any(r == "projected" for r in routes):
             # cond(K_uu + jitter I) beyond 1e7: K9 and the new Lambda_2 are barely definite in fp64 there, and the
-            # factorisation that follows the reference's success / failure is the one by substitution (EStepEngine.cholesky)
+            # factorisation that follows the reference's success / failure is the one with substitution panels
+            # (TSVGP_POTRF_SUBST through EStepEngine.cholesky(robust=True))
             potrf = functools.partial(potrf, robust=True)
         # W = I + L^T K6 L (util.py:171-172, formed without chol(K6)).  The factorisations of W and K_uu + jitter I are
         # independent and both latency bound (one workgroup per diagonal block): do them in ONE batched call, whose
@@ -665,8 +666,7 @@ class t_SVGP(base_SVGP):
             return False
         eng = self._get_engine()
         if (D_.world_size() > 1 or self.cache_whitened or eng.profile is not None
-                or isinstance(self.kernel, SeparateIndependent)
-                or any(r == "projected" for r in routes)):  # its rocSOLVER factorisations cannot be captured
+                or isinstance(self.kernel, SeparateIndependent)):
             return False
         lik_v = tuple(p.version for p in vars(self.likelihood).values() if hasattr(p, "version"))
         key = (X.data_ptr(), Y.data_ptr(), tuple(X.shape), tuple(Y.shape), X.dtype, Y.dtype, self._kernel_versions(),

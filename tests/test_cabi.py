@@ -34,7 +34,7 @@ def test_argument_validation_needs_no_gpu():
     assert lib.tsvgp_trmm_f32(None, None, None, 100, 128, 0, None) == 1
     assert lib.tsvgp_moments_f64(None, None, None, None, 1.0, 0, 0.0, None, None, None, None, None, None, 1, 128, 128, 1, 0, None) == 1
     assert lib.tsvgp_site_accum_f64(None, None, None, None, None, None, 128, 128, 1, 1, None) == 1
-    assert lib.tsvgp_potrf_f64(None, 128, 128, 1, 0, None, None, None) == 1
+    assert lib.tsvgp_potrf_f64(None, 128, 128, 1, 0, None, None, 0, None) == 1
     assert lib.tsvgp_site_accum_work_bytes_f64(1024, 1, 15) == (28 * 15 + 8 * 11) * 128 * 128 * 8 + 11 * 1024 * 8
     assert lib.tsvgp_site_accum_work_bytes_f32(1000, 1, 15) == -1
 
@@ -62,7 +62,7 @@ def test_product_path_fails_loudly_without_gpu():
 
 def lib_validation_extra():
     lib = pkg()._backend.lib()
-    ok = lib.tsvgp_potrf_inv_f64(None, 128, 128, 1, 0, None, None, None, None, None, None) == 1
+    ok = lib.tsvgp_potrf_inv_f64(None, 128, 128, 1, 0, None, None, None, None, None, 0, None) == 1
     ok &= lib.tsvgp_kernel_fill_f64(7, None, None, None, 1.0, None, 10, 4, 2, 128, None) == 1
     ok &= lib.tsvgp_kernel_grad_f64(0, None, None, None, 1.0, None, 128, None, None, 1, None, 1, 10, 4, 2, None, None, None, None) == 1
     ok &= lib.tsvgp_kernel_grad_rows() == 1024 and lib.tsvgp_kernel_grad_dpad(5) == 8

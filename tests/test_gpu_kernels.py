@@ -218,14 +218,16 @@ def test_invalid_arguments_are_rejected(engines):
     assert lib.tsvgp_site_accum_work_bytes_f64(100, 1, 1) == -1
 
 
+@pytest.mark.parametrize("robust", [False, True])
 @pytest.mark.parametrize("M,batch", [(128, 1), (256, 3), (1024, 1), (200, 2), (33, 1)])
-def test_potrf(engines, M, batch):
-    """Blocked Cholesky (tsvgp_potrf_f64) vs LAPACK; non-positive-definite input reports info like potrf."""
+def test_potrf(engines, M, batch, robust):
+    """Blocked Cholesky (tsvgp_potrf_f64) vs LAPACK, with the panels solved by the inverted diagonal block (default) and
+    by substitution (TSVGP_POTRF_SUBST); non-positive-definite input reports info like potrf."""
     eng = engines[torch.float64]
     rng = np.random.RandomState(5)
     A = rng.randn(batch, M, M)
     A = A @ np.swapaxes(A, -1, -2) / M + 0.5 * np.eye(M)
-    L, info = eng.cholesky(torch.as_tensor(A, device="cuda:0"))
+    L, info = eng.cholesky(torch.as_tensor(A, device="cuda:0"), robust=robust)
     torch.cuda.synchronize()
     assert int(info.abs().sum()) == 0
     ref = np.linalg.cholesky(A)
@@ -233,8 +235,29 @@ def test_potrf(engines, M, batch):
     assert np.array_equal(np.triu(L.cpu().numpy(), 1), np.zeros_like(A))
     bad = A.copy()
     bad[0, M // 2, M // 2] = -1.0
-    _, info = eng.cholesky(torch.as_tensor(bad, device="cuda:0"))
+    _, info = eng.cholesky(torch.as_tensor(bad, device="cuda:0"), robust=robust)
     assert int(info[0]) == M // 2 + 1  # 1-based index of the first non-positive pivot
+
+
+@pytest.mark.parametrize("M", [256, 640])
+def test_potrf_substitution_panels_on_a_barely_definite_matrix(engines, M):
+    """cond ~ 1e14 with lambda_min a few tens of eps * lambda_max (the new Lambda_2 on an ill-conditioned K_uu): wherever
+    LAPACK's factorisation goes through, the one with substitution panels does too, with a backward error at rounding
+    level, and so does its inverse factor."""
+    eng = engines[torch.float64]
+    rng = np.random.RandomState(8)
+    Q, _ = np.linalg.qr(rng.randn(M, M))
+    lam = np.logspace(0, -14.2, M)
+    A = (Q * lam) @ Q.T
+    A = 0.5 * (A + A.T)
+    ref = np.linalg.cholesky(A)  # LAPACK goes through (raises otherwise)
+    L, info, Linv = eng.cholesky(torch.as_tensor(A, device="cuda:0"), inverse=True, robust=True)
+    assert int(info.abs().sum()) == 0
+    Ln = L.cpu().numpy()
+    assert np.max(np.abs(Ln @ Ln.T - A)) < 50 * np.finfo(float).eps * np.max(np.abs(A))
+    assert np.max(np.abs(Ln - ref)) < 1e-6 * np.max(np.abs(ref))  # the factor itself is only determined to ~cond * eps
+    X = Linv.cpu().numpy()
+    assert np.max(np.abs(X @ Ln - np.eye(M))) < 1e-6
 
 
 @pytest.mark.parametrize("M,batch", [(128, 1), (256, 3), (1024, 1), (640, 2), (1536, 1), (200, 2), (33, 1)])
@@ -245,7 +268,7 @@ def test_potrf_inverse(engines, M, batch):
     rng = np.random.RandomState(6)
     A = rng.randn(batch, M, M)
     A = A @ np.swapaxes(A, -1, -2) / M + 0.5 * np.eye(M)
-    L, info, Linv = eng.cholesky(torch.as_tensor(A, device="cuda:0"), inverse=True)
+    L, info, Linv = eng.cholesky(torch.as_tensor(A, device="cuda:0"), inverse=True, robust=(M % 3 == 0))
     torch.cuda.synchronize()
     assert int(info.abs().sum()) == 0
     ref = np.linalg.cholesky(A)

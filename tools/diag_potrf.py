@@ -14,7 +14,7 @@ vp = ctypes.c_void_p
 # the stamped build overwrites the head of inv(L_00) in `work` with its stamps, so the factor itself is wrong here
 for _ in range(3):
     W = A.clone()
-    assert lib.tsvgp_potrf_f64(vp(W.data_ptr()), M, M, 1, ctypes.c_int64(M * M), vp(info.data_ptr()), vp(work.data_ptr()), None) == 0
+    assert lib.tsvgp_potrf_f64(vp(W.data_ptr()), M, M, 1, ctypes.c_int64(M * M), vp(info.data_ptr()), vp(work.data_ptr()), 0, None) == 0
 torch.cuda.synchronize()
 st = work[:40].view(torch.int64).cpu().numpy()
 n = int(st[0]); st = st[1:1 + n]
