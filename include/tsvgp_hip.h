@@ -200,6 +200,36 @@ int tsvgp_potrf_f64(double *A, int M, int lda, int batch, int64_t stride, int32_
 int tsvgp_potrf_inv_f64(double *A, int M, int lda, int batch, int64_t stride, int32_t *info, double *work, double *X,
                         double *Xt, double *T, int flags, void *stream);
 
+/* (7) Triangle extraction for the factors above, fused with a scale and (optionally) the index reversal of the upper-form
+ *     factorisation A = U U^T (U = J C J with C the lower factor of J A J, J the exchange matrix):
+ *        dst[b][i][j] = keep ? scale * src[b][si][sj] : 0   on the leading M x M block,
+ *        flip = 0: (si, sj) = (i, j), keep = i >= j;   flip = 1: (si, sj) = (M-1-i, M-1-j), keep = i <= j;
+ *        flip = 2: (si, sj) = (M-1-i, M-1-j), keep everything (J A J, the input of the upper-form factorisation).
+ *     Replaces tf.linalg.band_part / the triangular() transform of reference src/sites.py:63 and the leading minus of
+ *     src/models/tsvgp.py:300 (scale = -1) in one pass.  src [batch x * x lds], dst [batch x * x ldd] (strides in elements). */
+int tsvgp_tri_copy_f64(const double *src, int lds, int64_t sstride, double *dst, int ldd, int64_t dstride, int M, int batch,
+                       double scale, int flip, void *stream);
+
+/* (7b) The matrix of the final factorisation of one E-step (reference src/models/tsvgp.py:286-300), in one pass:
+ *        G1s    = (G1 + G1^T) / 2
+ *        target = c_ll * LLt + c_g * s * G1s + jitter * I,     s = num_data / rows[0]  (1 when num_data <= 0)
+ *     with LLt = L L^T of the old site factor, c_ll = 1 - lr, c_g = -2 lr:  -2 [(1-lr) lambda_2 + lr s G1] + jitter I.
+ *     `rows` is a device scalar (the all-reduced row count of the step), so the minibatch scale of :286-291 needs no host
+ *     read.  All matrices [P x M x M] contiguous. */
+int tsvgp_site_target_f64(const double *G1, const double *LLt, double *target, double *G1s, int M, int P, double c_ll,
+                          double c_g, double jitter, const double *rows, double num_data, void *stream);
+
+/* (7c) Status word of one step: flags[0] = sum |info_a| (prelude factorisations), flags[1] = nonpos[0] (count of
+ *     non-positive predictive variances, the assert_positive of :113; NULL = 0), flags[2] = sum |info_b| (the final
+ *     factorisation, :300).  One device->host read of these three doubles ends a step. */
+int tsvgp_step_status_f64(const int32_t *info_a, int na, const int32_t *info_b, int nb, const double *nonpos, double *flags,
+                          void *stream);
+
+/* (7d) Lower triangle of P symmetric M x M accumulators <-> packed [P x M (M + 1) / 2] (row by row): the payload of the
+ *     all-reduce of the dual accumulators (half of P M^2).  Unpack writes both triangles. */
+int tsvgp_sym_pack_f64(const double *A, int lda, int64_t stride, int M, int P, double *packed, void *stream);
+int tsvgp_sym_unpack_f64(const double *packed, double *A, int lda, int64_t stride, int M, int P, void *stream);
+
 /* (8) Kernel-parameter gradient contraction for the M-step (d ELBO / d theta with the sites fixed: reference
  *     experiments/uci_regression.py:159-160, pinned by tests/models/test_tsvgp.py:168-188; TensorFlow autodiff there).
  *     For one latent GP, with V[n,m] = g0[n] beta[m] - 2 g1[n] U[n,m] (U = K_fu Q from tsvgp_trmm, Q = D^T D):

@@ -96,6 +96,12 @@ _PROTOTYPES = {
     "tsvgp_potrf_f64": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_void_p, c_int, c_void_p]),
     "tsvgp_potrf_inv_f64": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_int, c_void_p]),
+    "tsvgp_tri_copy_f64": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int, c_int64, c_int, c_int, c_double, c_int, c_void_p]),
+    "tsvgp_site_target_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_double, c_double, c_double, c_void_p,
+                                      c_double, c_void_p]),
+    "tsvgp_step_status_f64": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "tsvgp_sym_pack_f64": (c_int, [c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p]),
+    "tsvgp_sym_unpack_f64": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p]),
     "tsvgp_selftest_mfma_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "tsvgp_selftest_mfma_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
 }

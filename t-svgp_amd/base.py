@@ -99,6 +99,14 @@ class Parameter:
             self._host, self._host_version = host, self.version
         return self
 
+    def assign_owned(self, new: torch.Tensor):
+        """``assign`` for a freshly computed tensor that nobody else holds: adopted as is (no copy)."""
+        if tuple(new.shape) != tuple(self._value.shape) or new.dtype != self._value.dtype or new.device != self._value.device:
+            return self.assign(new)
+        self._value = new
+        self.version += 1
+        return self
+
     def numpy(self) -> np.ndarray:
         return self._value.detach().cpu().numpy()
 

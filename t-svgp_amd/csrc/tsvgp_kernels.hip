@@ -1761,6 +1761,100 @@ __global__ __launch_bounds__(NTHREADS) void trtri_level_kernel(const double* __r
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Small fused M x M helpers of the replicated prelude / epilogue (each replaces a chain of ~5 us elementwise launches).
+// ---------------------------------------------------------------------------------------------------------------
+// 16-byte zero fill (hipMemsetAsync takes 23-31 us for the 8 MB inverse-factor buffers; this takes the time of the stores)
+__global__ __launch_bounds__(NTHREADS) void zero_fill_kernel(v2d* __restrict__ p, size_t n2) {
+    for (size_t i = (size_t)blockIdx.x * NTHREADS + threadIdx.x; i < n2; i += (size_t)gridDim.x * NTHREADS) p[i] = v2d{0.0, 0.0};
+}
+inline void zero_fill(void* p, size_t bytes, hipStream_t st) {  // bytes a multiple of 16, p 16-byte aligned
+    const size_t n2 = bytes / 16;
+    if (n2 == 0) return;
+    const unsigned grid = (unsigned)((n2 + NTHREADS - 1) / NTHREADS < 2048 ? (n2 + NTHREADS - 1) / NTHREADS : 2048);
+    hipLaunchKernelGGL(zero_fill_kernel, dim3(grid), dim3(NTHREADS), 0, st, reinterpret_cast<v2d*>(p), n2);
+}
+
+// dst[b][i][j] = keep(i, j) ? scale * src[b][si][sj] : 0 on the leading M x M block.
+//   flip == 0: (si, sj) = (i, j),                 keep = (i >= j)   -- the lower factor out of the factorisation buffer
+//   flip == 1: (si, sj) = (M - 1 - i, M - 1 - j), keep = (i <= j)   -- U = J C J, the upper-form factor (util.rev_cholesky)
+//   flip == 2: (si, sj) = (M - 1 - i, M - 1 - j), keep everything   -- J A J, the input of that factorisation
+__global__ __launch_bounds__(NTHREADS) void tri_copy_kernel(const double* __restrict__ src, int lds_, int64_t sstride,
+                                                            double* __restrict__ dst, int ldd, int64_t dstride, int M,
+                                                            double scale, int flip) {
+    const int b = blockIdx.z, i = blockIdx.y;
+    const int j = blockIdx.x * NTHREADS + threadIdx.x;
+    if (j >= M) return;
+    const bool keep = flip == 2 ? true : flip ? (i <= j) : (i >= j);
+    double v = 0.0;
+    if (keep) {
+        const int si = flip ? M - 1 - i : i, sj = flip ? M - 1 - j : j;
+        v = scale * src[(size_t)b * sstride + (size_t)si * lds_ + sj];
+    }
+    dst[(size_t)b * dstride + (size_t)i * ldd + j] = v;
+}
+
+// target[p][i][j] = c_ll * LLt[p][i][j] + c_g * s * G1s[i][j] + jitter * (i == j),  G1s = (G1 + G1^T) / 2 (also written out),
+// s = num_data / rows (rows: a device scalar, the all-reduced row count) or 1 when num_data <= 0.
+// The matrix of the final factorisation of one E-step, reference src/models/tsvgp.py:286-300:
+//   -2 [(1 - lr) lambda_2 + lr scale G1] + jitter I  with lambda_2 = -1/2 L L^T  ->  c_ll = 1 - lr, c_g = -2 lr.
+__global__ __launch_bounds__(NTHREADS) void site_target_kernel(const double* __restrict__ G1, const double* __restrict__ LLt,
+                                                               double* __restrict__ target, double* __restrict__ G1s, int M,
+                                                               double c_ll, double c_g, double jitter,
+                                                               const double* __restrict__ rows, double num_data) {
+    __shared__ double tile[32][33];
+    const size_t base = (size_t)blockIdx.z * M * M;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+    for (int r = ty; r < 32; r += 8) {  // the transposed tile G1[j0.., i0..]
+        const int jj = j0 + r, ii = i0 + tx;
+        tile[r][tx] = (jj < M && ii < M) ? G1[base + (size_t)jj * M + ii] : 0.0;
+    }
+    __syncthreads();
+    const double s = num_data > 0.0 ? num_data / rows[0] : 1.0;
+    for (int r = ty; r < 32; r += 8) {
+        const int i = i0 + r, j = j0 + tx;
+        if (i < M && j < M) {
+            const size_t o = base + (size_t)i * M + j;
+            const double g = 0.5 * (G1[o] + tile[tx][r]);
+            G1s[o] = g;
+            target[o] = c_ll * LLt[o] + c_g * s * g + (i == j ? jitter : 0.0);
+        }
+    }
+}
+
+// flags[0] = sum |info_a|, flags[1] = nonpos (as is, NaN included), flags[2] = sum |info_b|   (t_SVGP._status_flags)
+__global__ void step_status_kernel(const int* __restrict__ info_a, int na, const int* __restrict__ info_b, int nb,
+                                   const double* __restrict__ nonpos, double* __restrict__ flags) {
+    if (threadIdx.x == 0) {
+        double a = 0.0, b = 0.0;
+        for (int i = 0; i < na; ++i) a += fabs((double)info_a[i]);
+        for (int i = 0; i < nb; ++i) b += fabs((double)info_b[i]);
+        flags[0] = a;
+        flags[1] = nonpos ? nonpos[0] : 0.0;
+        flags[2] = b;
+    }
+}
+
+// Lower triangle of the symmetric accumulators, row by row, [P][M (M + 1) / 2]: what the all-reduce of the dual
+// accumulators ships (half of P M^2); unpack mirrors it back.
+__global__ __launch_bounds__(NTHREADS) void sym_pack_kernel(const double* __restrict__ A, int lda, int64_t stride, int M,
+                                                            double* __restrict__ out, int unpack) {
+    const int i = blockIdx.y, p = blockIdx.z;
+    const int j = blockIdx.x * NTHREADS + threadIdx.x;
+    if (j > i) return;
+    const size_t tri = (size_t)M * (M + 1) / 2;
+    double* o = out + (size_t)p * tri + (size_t)i * (i + 1) / 2 + j;
+    double* a = const_cast<double*>(A) + (size_t)p * stride;
+    if (!unpack) {
+        *o = a[(size_t)i * lda + j];
+    } else {
+        const double v = *o;
+        a[(size_t)i * lda + j] = v;
+        a[(size_t)j * lda + i] = v;
+    }
+}
+
 // single-wave MFMA map self-test
 template <typename T>
 __global__ void selftest_kernel(const T* a, const T* b, T* c) {
@@ -2004,8 +2098,9 @@ int potrf(double* A, int M, int lda, int batch, int64_t stride, int* info, doubl
     const int64_t xstride = (int64_t)M * M;
     if (hipMemsetAsync(info, 0, sizeof(int) * batch, st) != hipSuccess) return TSVGP_ELAUNCH;
     if (inv) {  // the blocks the recursion does not write stay zero
-        if (hipMemsetAsync(X, 0, sizeof(double) * xstride * batch, st) != hipSuccess) return TSVGP_ELAUNCH;
-        if (hipMemsetAsync(Xt, 0, sizeof(double) * xstride * batch, st) != hipSuccess) return TSVGP_ELAUNCH;
+        if ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Xt)) & 15) return TSVGP_EINVAL;
+        zero_fill(X, sizeof(double) * xstride * batch, st);
+        zero_fill(Xt, sizeof(double) * xstride * batch, st);
     }
     const int wpb = NTHREADS / 64;
     for (int k = 0; k < nt; ++k) {
@@ -2184,6 +2279,42 @@ int tsvgp_potrf_inv_f64(double* A, int M, int lda, int batch, int64_t stride, in
                         double* Xt, double* T, int flags, void* stream) {
     if (!X || !Xt || !T) return TSVGP_EINVAL;
     return potrf(A, M, lda, batch, stride, info, work, flags, stream, X, Xt, T);
+}
+
+int tsvgp_tri_copy_f64(const double* src, int lds, int64_t sstride, double* dst, int ldd, int64_t dstride, int M, int batch,
+                       double scale, int flip, void* stream) {
+    if (!src || !dst || M <= 0 || lds < M || ldd < M || batch <= 0 || batch > 65535 || M > 65535 || flip < 0 || flip > 2)
+        return TSVGP_EINVAL;
+    hipLaunchKernelGGL(tri_copy_kernel, dim3((M + NTHREADS - 1) / NTHREADS, M, batch), dim3(NTHREADS), 0, (hipStream_t)stream,
+                       src, lds, sstride, dst, ldd, dstride, M, scale, flip);
+    return launch_status();
+}
+
+int tsvgp_site_target_f64(const double* G1, const double* LLt, double* target, double* G1s, int M, int P, double c_ll,
+                          double c_g, double jitter, const double* rows, double num_data, void* stream) {
+    if (!G1 || !LLt || !target || !G1s || M <= 0 || P <= 0 || P > 65535 || (num_data > 0.0 && !rows)) return TSVGP_EINVAL;
+    const unsigned nb = (unsigned)((M + 31) / 32);
+    hipLaunchKernelGGL(site_target_kernel, dim3(nb, nb, (unsigned)P), dim3(NTHREADS), 0, (hipStream_t)stream, G1, LLt, target,
+                       G1s, M, c_ll, c_g, jitter, rows, num_data);
+    return launch_status();
+}
+int tsvgp_step_status_f64(const int32_t* info_a, int na, const int32_t* info_b, int nb, const double* nonpos, double* flags,
+                          void* stream) {
+    if (!flags || na < 0 || nb < 0 || (na > 0 && !info_a) || (nb > 0 && !info_b)) return TSVGP_EINVAL;
+    hipLaunchKernelGGL(step_status_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, info_a, na, info_b, nb, nonpos, flags);
+    return launch_status();
+}
+int tsvgp_sym_pack_f64(const double* A, int lda, int64_t stride, int M, int P, double* packed, void* stream) {
+    if (!A || !packed || M <= 0 || lda < M || P <= 0 || P > 65535 || M > 65535) return TSVGP_EINVAL;
+    hipLaunchKernelGGL(sym_pack_kernel, dim3((M + NTHREADS - 1) / NTHREADS, M, P), dim3(NTHREADS), 0, (hipStream_t)stream, A,
+                       lda, stride, M, packed, 0);
+    return launch_status();
+}
+int tsvgp_sym_unpack_f64(const double* packed, double* A, int lda, int64_t stride, int M, int P, void* stream) {
+    if (!A || !packed || M <= 0 || lda < M || P <= 0 || P > 65535 || M > 65535) return TSVGP_EINVAL;
+    hipLaunchKernelGGL(sym_pack_kernel, dim3((M + NTHREADS - 1) / NTHREADS, M, P), dim3(NTHREADS), 0, (hipStream_t)stream, A,
+                       lda, stride, M, const_cast<double*>(packed), 1);
+    return launch_status();
 }
 
 int tsvgp_kernel_grad_rows(void) { return KG_ROWS; }

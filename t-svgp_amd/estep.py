@@ -178,7 +178,18 @@ class EStepEngine:
         self.se_fill(Z, Z, inv_ls, kernel.variance.item(), out, kernel.kind)
         return out[:M, :M].contiguous()
 
-    def cholesky(self, A: torch.Tensor, inverse: bool = False, overwrite: bool = False, robust: bool = False):
+    def tri_copy(self, src: torch.Tensor, M: int, scale: float = 1.0, flip: int = 0) -> torch.Tensor:
+        """[nb, M, M] contiguous <- triangle / index reversal of the leading M x M block of src [nb, R, C]
+        (``tsvgp_tri_copy_f64``: flip 0 = lower triangle, 1 = reversed indices, upper triangle, 2 = reversed, everything)."""
+        nb, R, C = src.shape
+        out = torch.empty((nb, M, M), dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            B.check(self.lib.tsvgp_tri_copy_f64(src.data_ptr(), src.stride(1), src.stride(0), out.data_ptr(), M, M * M, M, nb,
+                                                float(scale), int(flip), self._stream()), "tsvgp_tri_copy")
+        return out
+
+    def cholesky(self, A: torch.Tensor, inverse: bool = False, overwrite: bool = False, robust: bool = False,
+                 scale: float = 1.0, upper_form: bool = False):
         """Batched lower Cholesky on the GPU through ``tsvgp_potrf_f64`` (no host synchronisation).
         A [.., M, M] fp64 (lower triangle referenced) -> (L [.., M, M] with zeros above the diagonal, info [batch] int32);
         with ``inverse`` also inv(L) (``tsvgp_potrf_inv_f64``), lower triangular with exact zeros above.
@@ -187,7 +198,10 @@ class EStepEngine:
         with the INVERTED diagonal block, which costs a factor cond(L_kk) of accuracy in the trailing matrix -- irrelevant
         for the matrices of a well-conditioned K_uu (and ~0.15 ms faster), but a numerically barely definite matrix
         (cond ~ 1e14, lambda_min ~ 30 eps lambda_max) then fails where LAPACK-style factorisations go through.  The
-        callers ask for it on the "projected" route, whose matrices are of that kind."""
+        callers ask for it on the "projected" route, whose matrices are of that kind.
+        ``scale``: the factor is returned times this (the leading minus of tsvgp.py:300 rides on the triangle copy).
+        ``upper_form``: A = U U^T with U upper triangular -- the input is read with reversed indices, factored, and the
+        factor (and inverse) written back reversed (``util.rev_cholesky`` without its four flip passes)."""
         A = A.to(device=self.device, dtype=torch.float64)
         flags = B.POTRF_SUBST if robust else 0
         M = A.shape[-1]
@@ -196,7 +210,14 @@ class EStepEngine:
         nb = 1
         for d in batch_shape:
             nb *= int(d)
-        if Mp == M:  # no padding: one copy (or none) instead of a zero fill plus a copy
+        if upper_form:
+            W = self.tri_copy(A.reshape(nb, M, M), M, 1.0, 2)  # J A J (a fresh buffer of ours)
+            if Mp != M:
+                Wp = torch.zeros((nb, Mp, Mp), dtype=torch.float64, device=self.device)
+                Wp[:, :M, :M] = W
+                Wp.diagonal(dim1=-2, dim2=-1)[:, M:] = 1.0
+                W = Wp
+        elif Mp == M:  # no padding: one copy (or none) instead of a zero fill plus a copy
             W = A.reshape(nb, M, M)
             if not (overwrite and W.is_contiguous() and W.data_ptr() == A.data_ptr()):
                 W = W.clone(memory_format=torch.contiguous_format)
@@ -217,10 +238,56 @@ class EStepEngine:
             else:
                 self._launch("tsvgp_potrf", lambda: self.lib.tsvgp_potrf_f64(
                     W.data_ptr(), Mp, Mp, nb, Mp * Mp, info.data_ptr(), work.data_ptr(), flags, self._stream()))
-        L = torch.tril(W[:, :M, :M]).reshape(out_shape)
+        L = self.tri_copy(W, M, scale, 1 if upper_form else 0).reshape(out_shape)
         if inverse:
-            return L, info, X[0, :, :M, :M].reshape(out_shape)
+            if upper_form:
+                Xi = self.tri_copy(X[0], M, 1.0, 1).reshape(out_shape)
+            else:
+                Xi = X[0, :, :M, :M].reshape(out_shape)
+            return L, info, Xi
         return L, info
+
+    # ------------------------------------------------------------------ fused M x M helpers of the epilogue
+    def site_target(self, G1, LLt, c_ll, c_g, jitter, rows, num_data):
+        """(target, G1s) of ``tsvgp_site_target_f64``: G1s = (G1 + G1^T) / 2, target = c_ll LLt + c_g s G1s + jitter I with
+        s = num_data / rows (rows: device scalar) or 1 when num_data is None.  [P, M, M] fp64."""
+        G1, LLt = G1.contiguous(), LLt.contiguous()
+        P, M = G1.shape[0], G1.shape[-1]
+        target, G1s = torch.empty_like(G1), torch.empty_like(G1)
+        with torch.cuda.device(self.device):
+            B.check(self.lib.tsvgp_site_target_f64(G1.data_ptr(), LLt.data_ptr(), target.data_ptr(), G1s.data_ptr(), M, P,
+                                                   float(c_ll), float(c_g), float(jitter),
+                                                   rows.data_ptr() if num_data is not None else None,
+                                                   float(num_data) if num_data is not None else 0.0, self._stream()),
+                    "tsvgp_site_target")
+        return target, G1s
+
+    def step_status(self, infos_a, infos_b, nonpos):
+        """[3] fp64 device tensor (sum |info| of the prelude factorisations, nonpos, sum |info| of the final one)."""
+        cat = lambda ts: None if len(ts) == 0 else (ts[0] if len(ts) == 1 else torch.cat(list(ts))).contiguous()
+        a, b = cat(infos_a), cat(infos_b)
+        nonpos = nonpos.reshape(1).to(torch.float64)
+        flags = torch.empty(3, dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            B.check(self.lib.tsvgp_step_status_f64(_ptr(a), 0 if a is None else a.numel(), _ptr(b), 0 if b is None else b.numel(),
+                                                   nonpos.data_ptr(), flags.data_ptr(), self._stream()), "tsvgp_step_status")
+        return flags
+
+    def sym_pack(self, acc2: torch.Tensor, out: torch.Tensor):
+        """Lower triangles of acc2 [P, M, M] (any row / matrix stride) -> out [P * M (M + 1) / 2] (``tsvgp_sym_pack_f64``)."""
+        P, M = acc2.shape[0], acc2.shape[-1]
+        assert acc2.stride(2) == 1
+        with torch.cuda.device(self.device):
+            B.check(self.lib.tsvgp_sym_pack_f64(acc2.data_ptr(), acc2.stride(1), acc2.stride(0), M, P, out.data_ptr(),
+                                                self._stream()), "tsvgp_sym_pack")
+        return out
+
+    def sym_unpack(self, packed: torch.Tensor, P: int, M: int) -> torch.Tensor:
+        out = torch.empty((P, M, M), dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            B.check(self.lib.tsvgp_sym_unpack_f64(packed.data_ptr(), out.data_ptr(), M, M * M, M, P, self._stream()),
+                    "tsvgp_sym_unpack")
+        return out
 
     def trmm(self, A: torch.Tensor, Tm: torch.Tensor, C: torch.Tensor, mode: int):
         Np, Mp = A.shape

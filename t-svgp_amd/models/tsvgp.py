@@ -338,6 +338,12 @@ class t_SVGP(base_SVGP):
             return ops
         ops["U9"], ops["Uinv9"] = U9, Uinv9  # K_uu + jitter I = U9 U9^T, tsvgp.py:268-270
         ops["moments_on_kfu"], ops["project_mode"] = False, B.TRI_LOWER
+        # what the epilogue needs of (theta, Z, the OLD sites) is formed here, where it runs beside the K(X, Z) fill:
+        # L L^T (tsvgp.py:293), predict_f(Z)'s mean K_uu beta (:249-254) and, for the direct route, K9^-1 = U9^-T U9^-1
+        ops["LLt"] = L @ L.transpose(-1, -2)
+        ops["meanZ"] = _kmv(Kzz, beta)
+        if routes is not None and "direct" in routes and Uinv9 is not None:
+            ops["K9inv"] = Uinv9.transpose(-1, -2) @ Uinv9
         if lower9:
             # a = K9^-1 k by two triangular products with the lower factor: b = L9^-1 k, a = L9^-T b; the moments act on
             # K(X, Z) with D and beta, so nothing on their side depends on the factor of K9
@@ -371,7 +377,11 @@ class t_SVGP(base_SVGP):
         return ops
 
     def _status_flags(self, ops, nonpos, extra_infos=()) -> torch.Tensor:
-        """Device tensor [3]: failed prelude factorisations, count of non-positive variances, failed final one."""
+        """Device tensor [3]: failed prelude factorisations, count of non-positive variances, failed final one
+        (one kernel, ``tsvgp_step_status_f64``)."""
+        eng = self._get_engine()
+        if hasattr(eng, "step_status") and nonpos.is_cuda:
+            return eng.step_status(ops["infos"], list(extra_infos), nonpos)
         zero = torch.zeros(1, dtype=torch.float64, device=self.device)
         final = info_sum(extra_infos) if len(extra_infos) else zero
         return torch.cat([info_sum(ops["infos"]), nonpos.reshape(1).to(torch.float64), final])
@@ -472,10 +482,8 @@ class t_SVGP(base_SVGP):
         st = self._get_engine().run(self._as_device(X), self._as_device(Y), ops["Z"], self.kernel,
                                     moment_Tm=ops["D"], moment_mode=ops["moment_mode"], gamma=ops["beta"],
                                     lik_id=self.likelihood.lik_id, lik_param=self.likelihood.lik_param)
-        packed = D_.pack_stats(st, with_sites=False)
-        if self._reduce():
-            D_.all_reduce_sum(packed)
-        _, _, ve_sum, nonpos, rows = D_.unpack_stats(packed, self.num_latent_gps, self.num_inducing, False)
+        _, _, ve_sum, nonpos, rows, _ = D_.reduce_stats(st, self.num_latent_gps, self.num_inducing, False, self._reduce(),
+                                                        self._get_engine())
         self._check_step(ops, nonpos)
         scale = (float(self.num_data) / rows) if self.num_data is not None else 1.0
         return ve_sum * scale - kl
@@ -537,13 +545,8 @@ class t_SVGP(base_SVGP):
             st = EStepStats(n_rows=parts[0].n_rows, ve_sum=sum(s_.ve_sum for s_ in parts),
                             nonpos=sum(s_.nonpos for s_ in parts))
             st.acc2, st.acc1 = torch.cat([s_.acc2 for s_ in parts], dim=0), torch.cat([s_.acc1 for s_ in parts], dim=0)
-        extra = [dvar, dls.reshape(-1), dZ.reshape(-1), sum_g1, res.reshape(1)]
-        packed = torch.cat([D_.pack_stats(st, with_sites=True)] + extra)
-        if self._reduce():
-            D_.all_reduce_sum(packed)
-        base = P * M * M + P * M + 3
-        acc2, acc1, ve_sum, nonpos, rows = D_.unpack_stats(packed[:base], P, M, True)
-        tail = packed[base:]
+        extra = torch.cat([dvar, dls.reshape(-1), dZ.reshape(-1), sum_g1, res.reshape(1)])
+        acc2, acc1, ve_sum, nonpos, rows, tail = D_.reduce_stats(st, P, M, True, self._reduce(), eng, extra=extra)
         o = 0
         dvar, o = tail[o:o + nk], o + nk
         dls, o = tail[o:o + nk * Dn].reshape(nk, Dn), o + nk * Dn
@@ -728,20 +731,18 @@ class t_SVGP(base_SVGP):
         """All-reduce of the packed accumulators (RCCL) + the replicated M x M epilogue (tsvgp.py:278-303).
         Returns the status flags (device tensor, see ``_status_flags``)."""
         P, M = self.num_latent_gps, self.num_inducing
-        packed = D_.pack_stats(st, with_sites=True)
-        if self._reduce():
-            D_.all_reduce_sum(packed)
-        acc2, acc1, _, nonpos, rows = D_.unpack_stats(packed, P, M, True)
+        eng = self._get_engine()
+        acc2, acc1, _, nonpos, rows, _ = D_.reduce_stats(st, P, M, True, self._reduce(), eng)
 
-        Uinv9, Kzz, beta = ops["Uinv9"], ops["Kzz"], ops["beta"]
+        Uinv9 = ops["Uinv9"]
         Uinv9t = Uinv9.transpose(-1, -2) if Uinv9 is not None else None  # None: projected route on the lower factor
         routes = ops["routes"]
         forms = {}
         if "direct" in routes:
             # direct projection: acc2 = sum g1 k k^T, acc1 = sum g0 k  ->  G1 = K9^-1 acc2 K9^-1, G0 = K9^-1 acc1
-            # (K9^-1 = U9^-T U9^-1 applied as GEMMs; torch.cholesky_solve is not an option: it returned wrong values for
-            # small batched right-hand sides on this ROCm build -- tools/check_cholesky_solve.py)
-            K9inv = Uinv9t @ Uinv9
+            # (K9^-1 = U9^-T U9^-1 from the prelude, applied as GEMMs; torch.cholesky_solve is not an option: it returned
+            # wrong values for small batched right-hand sides on this ROCm build -- tools/check_cholesky_solve.py)
+            K9inv = ops["K9inv"]
             forms["direct"] = (K9inv @ acc2 @ K9inv, _kmv(K9inv, acc1.transpose(-1, -2)))
         if "whitened" in routes:
             # G1 = U9^-T acc2 U9^-1,  G0 = U9^-T acc1   (tsvgp.py:279-280 in whitened coordinates)
@@ -754,26 +755,28 @@ class t_SVGP(base_SVGP):
         else:  # mixed routes (separate kernels): every latent keeps the form its sums were taken in
             G1 = torch.stack([forms[r][0][p] for p, r in enumerate(routes)])
             G0 = torch.stack([forms[r][1][:, p] for p, r in enumerate(routes)], dim=1)
-        G1 = 0.5 * (G1 + G1.transpose(-1, -2))
-        meanZ = _kmv(Kzz, beta)  # predict_f(Z) mean, tsvgp.py:249-254 (per latent kernel for separate kernels)
-        grad_mu = gradient_transformation_mean_var_to_expectation(meanZ, [G0, G1])  # tsvgp.py:284
-
-        # tsvgp.py:286-291; `rows` = global number of rows, a device scalar (no synchronisation)
-        scale = (float(self.num_data) / rows) if self.num_data is not None else 1.0
+        # tsvgp.py:286-300 in one pass (tsvgp_site_target_f64): with lambda_2 = -1/2 L L^T the matrix to factor is
+        #   -2 [(1 - lr) lambda_2 + lr scale G1] + jitter I = (1 - lr) L L^T - 2 lr scale G1 + jitter I;
+        # L L^T of the old factor comes from the prelude, `rows` (the global number of rows) is a device scalar: the
+        # minibatch scale of :286-291 needs no synchronisation
+        if hasattr(eng, "site_target") and G1.is_cuda:
+            target, G1 = eng.site_target(G1, ops["LLt"], 1.0 - lr, -2.0 * lr, jitter, rows, self.num_data)
+            scale = (float(self.num_data) / rows) if self.num_data is not None else 1.0
+        else:
+            G1 = 0.5 * (G1 + G1.transpose(-1, -2))
+            scale = (float(self.num_data) / rows) if self.num_data is not None else 1.0
+            target = (1.0 - lr) * ops["LLt"] + (-2.0 * lr * scale) * G1
+            target.diagonal(dim1=-2, dim2=-1).add_(jitter)
+        grad_mu = gradient_transformation_mean_var_to_expectation(ops["meanZ"], [G0, G1])  # tsvgp.py:284
         lambda_1 = (1 - lr) * self.lambda_1.value + lr * scale * grad_mu[0]  # tsvgp.py:296
-        # tsvgp.py:293-300 in one pass: with lambda_2 = -1/2 L L^T the matrix to factor is
-        #   -2 [(1 - lr) lambda_2 + lr scale G1] + jitter I = (1 - lr) L L^T - 2 lr scale G1 + jitter I,
-        # and the old L L^T rides on a GEMM whose "C" operand is the scaled gradient
-        L_old = self.lambda_2_sqrt.value
-        target = torch.baddbmm(grad_mu[1] * (-2.0 * lr * scale), L_old, L_old.transpose(-1, -2), alpha=1.0 - lr)
-        target.diagonal(dim1=-2, dim2=-1).add_(jitter)
         final_info = []
-        lambda_2_sqrt = -cholesky_deferred(target, final_info, ops["potrf"], overwrite=True)  # tsvgp.py:300
+        # tsvgp.py:300; the leading minus rides on the factorisation's triangle copy, which also leaves exact zeros above
+        lambda_2_sqrt = cholesky_deferred(target, final_info, ops["potrf"], overwrite=True, scale=-1.0)
         if inplace:
             self.lambda_1.value.copy_(lambda_1)
-            self.lambda_2_sqrt.value.copy_(torch.tril(lambda_2_sqrt))
+            self.lambda_2_sqrt.value.copy_(lambda_2_sqrt)
         else:
-            self.lambda_1.assign(lambda_1)  # tsvgp.py:302
-            self.sites.assign_lambda_2_sqrt(lambda_2_sqrt)  # tsvgp.py:303
+            self.lambda_1.assign_owned(lambda_1)  # tsvgp.py:302
+            self.sites.assign_lambda_2_sqrt(lambda_2_sqrt, lower_and_owned=True)  # tsvgp.py:303
         # tsvgp.py:304 recomputes the posterior and discards it: dead work, not reproduced.
         return self._status_flags(ops, nonpos, final_info)

@@ -254,10 +254,8 @@ class t_SVGP_white(base_SVGP):
         def go(direct):
             ops = self._operands(direct=direct)
             st = self._run(X, Y, ops, self.likelihood.lik_id | B.LIK_NOCROP)
-            packed = D_.pack_stats(st, with_sites=False)
-            if self._reduce():
-                D_.all_reduce_sum(packed)
-            _, _, ve_sum, nonpos, rows = D_.unpack_stats(packed, self.num_latent_gps, self.num_inducing, False)
+            _, _, ve_sum, nonpos, rows, _ = D_.reduce_stats(st, self.num_latent_gps, self.num_inducing, False,
+                                                              self._reduce(), self._get_engine())
             self._check(ops, nonpos)
             scale = (float(self.num_data) / rows) if self.num_data is not None else 1.0
             return ve_sum * scale - kl
@@ -273,10 +271,8 @@ class t_SVGP_white(base_SVGP):
         ops = self._operands(jitter=jitter, direct=direct)
         # tsvgp_white.py:188-191: no crop of d ve / d var in this class
         st = self._run(X, Y, ops, self.likelihood.lik_id | B.LIK_NOCROP, sites=True)
-        packed = D_.pack_stats(st, with_sites=True)
-        if self._reduce():
-            D_.all_reduce_sum(packed)
-        acc2, acc1, _, nonpos, rows = D_.unpack_stats(packed, self.num_latent_gps, self.num_inducing, True)
+        acc2, acc1, _, nonpos, rows, _ = D_.reduce_stats(st, self.num_latent_gps, self.num_inducing, True, self._reduce(),
+                                                         self._get_engine())
         U6, Uinv6, K9inv, Id = ops["U6"], ops["Uinv6"], ops["K9inv"], ops["Id"]
         if ops["direct"]:  # the sums were taken over k itself
             S2, s1, gamma_k = acc2, acc1.transpose(-1, -2), ops["gamma"]

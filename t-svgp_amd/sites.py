@@ -55,8 +55,13 @@ class DenseSites(Sites):
             raise ValueError("sites are stored as a Cholesky factor")
         self._lambda_2.assign(value)
 
-    def assign_lambda_2_sqrt(self, value):
-        """triangular() transform: only the lower triangle is kept (reference src/sites.py:63)."""
+    def assign_lambda_2_sqrt(self, value, lower_and_owned: bool = False):
+        """triangular() transform: only the lower triangle is kept (reference src/sites.py:63).
+        ``lower_and_owned``: ``value`` is a fresh tensor with exact zeros above the diagonal (a factor straight out of the
+        factorisation): adopted without the triangle pass and the copy."""
         if not self.factor:
             raise ValueError("sites are stored as a full lambda_2")
-        self._lambda_2_sqrt.assign(torch.tril(to_tensor(value, device=self._lambda_2_sqrt.device)))
+        if lower_and_owned and isinstance(value, torch.Tensor):
+            self._lambda_2_sqrt.assign_owned(value)
+        else:
+            self._lambda_2_sqrt.assign(torch.tril(to_tensor(value, device=self._lambda_2_sqrt.device)))

@@ -20,14 +20,16 @@ def cholesky(a: torch.Tensor) -> torch.Tensor:
     return L
 
 
-def cholesky_deferred(a: torch.Tensor, infos: list, potrf=None, inverse: bool = False, overwrite: bool = False):
+def cholesky_deferred(a: torch.Tensor, infos: list, potrf=None, inverse: bool = False, overwrite: bool = False,
+                      scale: float = 1.0):
     """Cholesky without a host synchronisation: the LAPACK-style ``info`` tensor is appended to ``infos`` and
     checked later in one device->host read (see ``t_SVGP._check_step``).  ``potrf`` is the engine's HIP
     factorisation (``EStepEngine.cholesky``); without it torch's is used.  With ``inverse`` returns (L, inv(L)).
-    ``overwrite``: ``a`` is a temporary that the factorisation may destroy."""
+    ``overwrite``: ``a`` is a temporary that the factorisation may destroy.  ``scale``: the factor is returned times
+    this (not the inverse)."""
     Linv = None
     if potrf is not None:
-        res = potrf(a, inverse=inverse, overwrite=overwrite)
+        res = potrf(a, inverse=inverse, overwrite=overwrite, scale=scale)
         L, info = res[0], res[1]
         Linv = res[2] if inverse else None
     else:
@@ -35,6 +37,8 @@ def cholesky_deferred(a: torch.Tensor, infos: list, potrf=None, inverse: bool = 
         if inverse:
             Id = torch.eye(a.shape[-1], dtype=a.dtype, device=a.device)
             Linv = torch.linalg.solve_triangular(L, Id, upper=False)
+        if scale != 1.0:
+            L = L * scale
     infos.append(info.reshape(-1).to(torch.int32))  # raw: reduced once per call by ``info_sum``
     return (L, Linv) if inverse else L
 
@@ -47,8 +51,13 @@ def info_sum(infos) -> torch.Tensor:
 def rev_cholesky(a: torch.Tensor, infos: list, potrf=None, inverse: bool = False):
     """Upper-form Cholesky a = U U^T, U upper triangular: the lower factor of the index-reversed matrix, reversed back
     (J a J = C C^T  =>  a = (J C J)(J C J)^T, and U^-1 = J C^-1 J).  Status handling as in ``cholesky_deferred``.
-    With ``inverse`` returns (U, inv(U))."""
-    res = cholesky_deferred(torch.flip(a, (-2, -1)), infos, potrf, inverse, overwrite=True)  # the flipped copy is ours
+    With ``inverse`` returns (U, inv(U)).  The engine's factorisation takes the reversal into its own copy passes
+    (``EStepEngine.cholesky(upper_form=True)``: no separate flip kernels)."""
+    if potrf is not None:
+        res = potrf(a, inverse=inverse, upper_form=True)
+        infos.append(res[1].reshape(-1).to(torch.int32))
+        return (res[0], res[2]) if inverse else res[0]
+    res = cholesky_deferred(torch.flip(a, (-2, -1)), infos, None, inverse, overwrite=True)  # the flipped copy is ours
     if inverse:
         return torch.flip(res[0], (-2, -1)), torch.flip(res[1], (-2, -1))
     return torch.flip(res, (-2, -1))
