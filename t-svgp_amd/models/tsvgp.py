@@ -41,6 +41,7 @@ from ..inducing_variables import inducingpoint_wrapper
 from ..kernels import SeparateIndependent, latent_kernels
 from ..sites import DenseSites
 from ..util import (
+    bmv,
     cholesky_deferred,
     cond2_estimate,
     gradient_transformation_mean_var_to_expectation,
@@ -53,12 +54,12 @@ from ..util import (
 
 def _kmv(K: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
     """K v per latent: K [M, M] (shared kernel) or [P, M, M] (separate kernels), v [M, P] -> [M, P]."""
-    return K @ v if K.dim() == 2 else torch.einsum("pmk,kp->mp", K, v)
+    return bmv(K, v)
 
 
 def _ktmv(K: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
     """K^T v per latent (shapes as ``_kmv``)."""
-    return K.transpose(-1, -2) @ v if K.dim() == 2 else torch.einsum("pkm,kp->mp", K, v)
+    return bmv(K, v, transpose=True)
 
 
 class base_SVGP(abc.ABC):
@@ -329,8 +330,8 @@ class t_SVGP(base_SVGP):
         else:
             U9, Uinv9 = None, None
         Dm = (Uinv_W @ L.transpose(-1, -2)).triu()  # D = U_W^-1 L^T, [P, M, M], upper triangular
-        DKl = torch.einsum("pmk,kp->pm", Dm, _kmv(K6, l1))
-        beta = l1 - torch.einsum("pkm,pk->mp", Dm, DKl)  # K6^-1 m = l1 - D^T D K6 l1
+        DKl = bmv(Dm, _kmv(K6, l1))  # [M, P]
+        beta = l1 - bmv(Dm, DKl, transpose=True)  # K6^-1 m = l1 - D^T D K6 l1
         ops = dict(Z=Z, Kzz=Kzz, K6=K6, D=Dm, U_W=U_W, beta=beta, Id=Id, infos=infos, potrf=potrf,
                    routes=["whitened"] * self.num_latent_gps, moment_mode=B.TRI_UPPER, whiten_mode=B.TRI_UPPER,
                    whiten_T=None, project_T=None)
@@ -338,12 +339,36 @@ class t_SVGP(base_SVGP):
             return ops
         ops["U9"], ops["Uinv9"] = U9, Uinv9  # K_uu + jitter I = U9 U9^T, tsvgp.py:268-270
         ops["moments_on_kfu"], ops["project_mode"] = False, B.TRI_LOWER
-        # what the epilogue needs of (theta, Z, the OLD sites) is formed here, where it runs beside the K(X, Z) fill:
-        # L L^T (tsvgp.py:293), predict_f(Z)'s mean K_uu beta (:249-254) and, for the direct route, K9^-1 = U9^-T U9^-1
-        ops["LLt"] = L @ L.transpose(-1, -2)
-        ops["meanZ"] = _kmv(Kzz, beta)
-        if routes is not None and "direct" in routes and Uinv9 is not None:
-            ops["K9inv"] = Uinv9.transpose(-1, -2) @ Uinv9
+        # What only the EPILOGUE needs of (theta, Z, the old sites): L L^T (tsvgp.py:293), predict_f(Z)'s mean K_uu beta
+        # (:249-254) and, for the direct route, K9^-1 = U9^-T U9^-1.  Three M^3 GEMMs that nothing in the N-pass waits for:
+        # they go to the side stream (behind the K(X, Z) fill) and run beside the moments kernel instead of in front of
+        # it; ``_apply_site_update`` waits for ops["epi_event"].
+        want_k9inv = routes is not None and "direct" in routes and Uinv9 is not None
+
+        def epilogue_operands():
+            ops["LLt"] = L @ L.transpose(-1, -2)
+            ops["meanZ"] = _kmv(Kzz, beta)
+            if want_k9inv:
+                ops["K9inv"] = Uinv9.transpose(-1, -2) @ Uinv9
+
+        side = getattr(eng, "_side", None)
+        if (self.overlap_fill and side is not None and Kzz.is_cuda and not torch.cuda.is_current_stream_capturing()):
+            main = torch.cuda.current_stream(self.device)
+            ready = torch.cuda.Event()
+            ready.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(ready)
+                epilogue_operands()
+                done = torch.cuda.Event()
+                done.record(side)
+            for t in (L, Kzz, beta) + ((Uinv9,) if want_k9inv else ()):
+                t.record_stream(side)  # blocks of the main stream's pool read on the side stream
+            for k in ("LLt", "meanZ", "K9inv"):
+                if k in ops:
+                    ops[k].record_stream(main)  # and the other way round
+            ops["epi_event"] = done
+        else:
+            epilogue_operands()
         if lower9:
             # a = K9^-1 k by two triangular products with the lower factor: b = L9^-1 k, a = L9^-T b; the moments act on
             # K(X, Z) with D and beta, so nothing on their side depends on the factor of K9
@@ -733,6 +758,8 @@ class t_SVGP(base_SVGP):
         P, M = self.num_latent_gps, self.num_inducing
         eng = self._get_engine()
         acc2, acc1, _, nonpos, rows, _ = D_.reduce_stats(st, P, M, True, self._reduce(), eng)
+        if ops.get("epi_event") is not None:  # L L^T, K_uu beta, K9^-1 from the side stream (see _site_operands)
+            torch.cuda.current_stream(self.device).wait_event(ops["epi_event"])
 
         Uinv9 = ops["Uinv9"]
         Uinv9t = Uinv9.transpose(-1, -2) if Uinv9 is not None else None  # None: projected route on the lower factor

@@ -16,7 +16,7 @@ python bench.py --workload c5s --steps 5 --warmup 2 > $O/c5s_bench.json 2> $O/c5
 echo c5 done
 python bench.py --model white --steps 10 --warmup 3 --no-cpu-baseline > $O/ns_white_bench.json 2> $O/white.err
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/kt -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $R/$O/kt.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/kt -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-elbo-match --no-side-lines > $R/$O/kt.log 2>&1
 cd $R
 echo kt done
 bash tools/pmc_passes.sh $O/pmc > $O/pmc.log 2>&1
