@@ -136,20 +136,13 @@ int tsvgp_trmm_batched_f32(const float *A, int64_t strideA, const float *Tm, int
  *     g0,g1 [Np x P] (rows >= N written as 0; may be NULL when lik == NONE);
  *     ve_partial [Np/128] doubles (per-workgroup sums of ve; may be NULL when lik == NONE);
  *     nonpos_partial [Np/128] int32 (count of var <= 0, the tf.debugging.assert_positive of :113).
- *     lik_param: Gaussian noise variance (ignored otherwise).
- *     split_work: NULL, or 3 * Np * P doubles of scratch.  With it (mode UPPER, at least four 128-wide column tiles,
- *     Mp * sizeof(T) <= 8192) every 128-row panel is taken by TWO workgroups, each with half of the column tiles (balanced
- *     k-ranges), and a second O(N P) kernel adds their partial row sums and runs the likelihood map: same results to
- *     rounding, half the scheduling granule -- the tail of the launch shrinks (3.5 % of the kernel at N = 1e6, 20 % at the
- *     125 000 rows per GPU of an 8-way shard). */
+ *     lik_param: Gaussian noise variance (ignored otherwise). */
 int tsvgp_moments_f64(const double *A, const double *Tm, const double *gamma, const double *Y, double kdiag, int lik,
                       double lik_param, double *mean, double *var, double *g0, double *g1, double *ve_partial,
-                      int32_t *nonpos_partial, int64_t N, int64_t Np, int Mp, int P, int mode, double *split_work,
-                      void *stream);
+                      int32_t *nonpos_partial, int64_t N, int64_t Np, int Mp, int P, int mode, void *stream);
 int tsvgp_moments_f32(const float *A, const float *Tm, const float *gamma, const float *Y, double kdiag, int lik,
                       double lik_param, float *mean, float *var, float *g0, float *g1, double *ve_partial,
-                      int32_t *nonpos_partial, int64_t N, int64_t Np, int Mp, int P, int mode, double *split_work,
-                      void *stream);
+                      int32_t *nonpos_partial, int64_t N, int64_t Np, int Mp, int P, int mode, void *stream);
 
 /* (3b) The moments for P latents with one kernel each: latent p has its own operand A + p*strideA ([Np x Mp] each; strideA = 0
  *     is the shared operand of tsvgp_moments_*) and its own prior variance kdiag_host[p] (HOST array of P doubles, passed
@@ -158,11 +151,11 @@ int tsvgp_moments_f32(const float *A, const float *Tm, const float *gamma, const
 int tsvgp_moments_batched_f64(const double *A, int64_t strideA, const double *Tm, const double *gamma, const double *Y,
                               const double *kdiag_host, int lik, double lik_param, double *mean, double *var, double *g0,
                               double *g1, double *ve_partial, int32_t *nonpos_partial, int64_t N, int64_t Np, int Mp,
-                              int P, int mode, double *split_work, void *stream);
+                              int P, int mode, void *stream);
 int tsvgp_moments_batched_f32(const float *A, int64_t strideA, const float *Tm, const float *gamma, const float *Y,
                               const double *kdiag_host, int lik, double lik_param, float *mean, float *var, float *g0,
                               float *g1, double *ve_partial, int32_t *nonpos_partial, int64_t N, int64_t Np, int Mp,
-                              int P, int mode, double *split_work, void *stream);
+                              int P, int mode, void *stream);
 
 /* (5) Site accumulation (the two einsums of reference src/models/tsvgp.py:278-281 in whitened coordinates):
  *        acc2[p][i][j] = sum_n g1[n,p] * B[n,i] * B[n,j]        (full symmetric [P x Mp x Mp], fp64)

@@ -520,9 +520,6 @@ struct PanelArgs {
     int64_t strideA;  // elements between the operands of consecutive latents (0: one operand shared by all latents)
     int64_t strideC, strideT;  // STORE, latent batch on grid.y
     int Mp, P, mode, lik;
-    double* qpart;                  // MOMENTS, split panels: [2][Np][P] partial row sums of squares (one slice per half)
-    double* mpart;                  // MOMENTS, split panels: [Np][P] the mean (written by half 0, whose tile 0 carries it)
-    int split;                      // MOMENTS/UPPER/FUSE: grid.y = 2, each half of a panel's column tiles in its own workgroup
     int kdiag_uniform;              // MOMENTS: kdiag[0] holds for every latent (one shared kernel; any P)
     double kdiag[TSVGP_MAX_BATCH];  // MOMENTS: k(x, x) = kernel variance of latent p (one kernel per latent: they differ)
 };
@@ -583,26 +580,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void panel_kernel(PanelArgs<T> a) {
         constexpr int DEPTH = PanelK<T>::DEPTH;
         T ra[DEPTH][H], rb[DEPTH][H];
         bool pre = false;  // ra[0] / rb[0] already hold the first chunk of the tile about to start
-        // Split panels (MOMENTS, UPPER, FUSE; grid.y = 2): a panel's column tiles are dealt to two workgroups in snake
-        // order of their k-ranges -- tiles with it % 4 in {0, 3} to half 0, {1, 2} to half 1 (8 tiles: {0,3,4,7} and
-        // {1,2,5,6}, 18 k-tiles each) -- which halves the granule the last dispatch round is made of (the tail of the
-        // launch: 3.5 % of the kernel at N = 1e6, 20 % at 125 000 rows).  Each half leaves its partial row sums in qpart
-        // (half 0 also the mean); moments_finish_kernel adds them and runs the likelihood map.
-        const int half = (FUSE && TRI == TSVGP_TRI_UPPER && a.split) ? (int)blockIdx.y : 0;
-        const bool split = FUSE && TRI == TSVGP_TRI_UPPER && a.split;
         if constexpr (FUSE) {
 #if TSVGP_XTILE >= 2
-            // the first tile (tile 0 for both triangles; tile 1 for the second half of a split panel) starts at its first
-            // chunk: its loads fly while gamma is staged
-            const int it0 = half ? 1 : 0;
-            const int c0 = (TRI == TSVGP_TRI_UPPER) ? it0 * CPT : 0;
-            load_run<T, H>(ra[0], Arow + c0 * KC);
-            load_run<T, H>(rb[0], Tp + (size_t)(it0 * TILE + srow) * Mp + skh * H + c0 * KC);
+            // the first tile (it = 0 for both triangles) starts at chunk 0: its loads fly while gamma is staged
+            load_run<T, H>(ra[0], Arow);
+            load_run<T, H>(rb[0], Tp + (size_t)srow * Mp + skh * H);
             pre = true;
 #endif
-            if (half == 0) {
-                for (int j = t; j < Mp; j += NTHREADS) gsm[j] = a.gamma[(size_t)j * a.P + p];
-            }
+            for (int j = t; j < Mp; j += NTHREADS) gsm[j] = a.gamma[(size_t)j * a.P + p];
             __syncthreads();
         } else if constexpr (MODE == MODE_MOMENTS) {
             // Mean GEMV phase: mean[n] = sum_j A[n, j] * gamma[j, p].  A memory/VALU-only sweep of this workgroup's row
@@ -778,21 +763,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void panel_kernel(PanelArgs<T> a) {
         };  // tile_body
         const auto next_of = [ntile](int it) { return it + 1 < ntile ? it + 1 : -1; };
         if constexpr (FUSE && TRI == TSVGP_TRI_UPPER) {  // upper triangle: the FIRST column tile sweeps every k-chunk
-            if (!split) {
-                tile_body(0, std::true_type{}, next_of(0));
-                for (int it = 1; it < ntile; ++it) tile_body(it, std::false_type{}, next_of(it));
-            } else {
-                // this half's tiles in increasing order: it % 4 in {0, 3} (half 0) or {1, 2} (half 1)
-                const auto mine = [half](int it) { return (((it & 3) == 0 || (it & 3) == 3) ? 0 : 1) == half; };
-                const auto next_mine = [&](int it) {
-                    for (int j = it + 1; j < ntile; ++j)
-                        if (mine(j)) return j;
-                    return -1;
-                };
-                if (half == 0) tile_body(0, std::true_type{}, next_mine(0));
-                for (int it = 1; it < ntile; ++it)
-                    if (mine(it)) tile_body(it, std::false_type{}, next_mine(it));
-            }
+            tile_body(0, std::true_type{}, next_of(0));
+            for (int it = 1; it < ntile; ++it) tile_body(it, std::false_type{}, next_of(it));
         } else if constexpr (FUSE) {  // lower triangle: the LAST one does
             for (int it = 0; it + 1 < ntile; ++it) tile_body(it, std::false_type{}, next_of(it));
             tile_body(ntile - 1, std::true_type{}, -1);
@@ -808,12 +780,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void panel_kernel(PanelArgs<T> a) {
             }
             mpart += __shfl_xor(mpart, 1);
             __syncthreads();
-            if (split) {  // partial sums out; the likelihood map runs in moments_finish_kernel
-                if (skh == 0) {
-                    a.qpart[((size_t)half * a.Np + n0 + srow) * a.P + p] = rowq[srow];
-                    if (half == 0) a.mpart[(size_t)(n0 + srow) * a.P + p] = (double)mpart;
-                }
-            } else {
+            {
                 const int64_t n = n0 + srow;
                 const bool live = n < a.N;
                 const double q = rowq[srow];
@@ -855,7 +822,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void panel_kernel(PanelArgs<T> a) {
         }
     }  // p
 
-    if (MODE == MODE_MOMENTS && !(FUSE && TRI == TSVGP_TRI_UPPER && a.split)) {
+    if constexpr (MODE == MODE_MOMENTS) {
         double s = ve_acc;
         int c = nonpos;
 #pragma unroll
@@ -884,72 +851,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void panel_kernel(PanelArgs<T> a) {
         dbg[3] = __builtin_amdgcn_s_memtime() - diag_c0;  // shader cycles of this workgroup
     }
 #endif
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// moments_finish_kernel (split panels): q = qpart[0] + qpart[1], var = kdiag - q, mean = mpart, then the likelihood map,
-// the per-128-row partial sums of ve and the count of non-positive variances -- what the unsplit panel kernel does in its
-// epilogue, with the same two-threads-per-row split of the Bernoulli quadrature.  O(N P): HBM-bound, microseconds.
-// ---------------------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(NTHREADS) void moments_finish_kernel(PanelArgs<T> a) {
-    __shared__ double red[NTHREADS / 64];
-    __shared__ int redi[NTHREADS / 64];
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const int srow = t >> 1, skh = t & 1;
-    const int64_t n = (int64_t)blockIdx.x * TILE + srow;
-    const bool live = n < a.N;
-    double ve_acc = 0.0;
-    int nonpos = 0;
-    for (int p = 0; p < a.P; ++p) {
-        const size_t o = (size_t)n * a.P + p;
-        const double q = a.qpart[o] + a.qpart[(size_t)a.Np * a.P + o];
-        const double mu = a.mpart[o];
-        const double v = a.kdiag[a.kdiag_uniform ? 0 : p] - q;
-        double g0 = 0.0, g1 = 0.0, ve = 0.0;
-        if ((a.lik & 0xFF) == TSVGP_LIK_BERNOULLI) {
-            double a0, a1, av;
-            const double sd = sqrt(live ? v : 1.0);
-            bern_sums(live ? mu : 0.0, sd, live && (double)a.Y[o] == 1.0, skh * 5, skh * 5 + 5, a0, a1, av);
-            a0 += __shfl_xor(a0, 1);
-            a1 += __shfl_xor(a1, 1);
-            av += __shfl_xor(av, 1);
-            g0 = a0;
-            g1 = a1 / (2.0 * sd);
-            if (!(a.lik & TSVGP_LIK_NOCROP)) g1 = fmin(g1, -1e-8);  // reference tsvgp.py:262-263
-            ve = av;
-        } else if (a.lik != TSVGP_LIK_NONE && live) {
-            lik_eval(a.lik, a.lik_param, mu, v, (double)a.Y[o], g0, g1, ve);
-        }
-        if (skh == 0) {
-            if (live) {
-                if (!(v > 0.0)) nonpos += 1;
-                if (a.mean) a.mean[o] = (T)mu;
-                if (a.var) a.var[o] = (T)v;
-                ve_acc += ve;
-            }
-            if (a.lik != TSVGP_LIK_NONE) {
-                a.g0[o] = (T)(live ? g0 : 0.0);  // rows >= N: zeros (the padding contract of site_accum)
-                a.g1[o] = (T)(live ? g1 : 0.0);
-            }
-        }
-    }
-    double s = ve_acc;
-    int c = nonpos;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        s += __shfl_xor(s, off);
-        c += __shfl_xor(c, off);
-    }
-    if (lane == 0) {
-        red[w] = s;
-        redi[w] = c;
-    }
-    __syncthreads();
-    if (t == 0) {
-        if (a.ve_partial) a.ve_partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
-        if (a.nonpos_partial) a.nonpos_partial[blockIdx.x] = redi[0] + redi[1] + redi[2] + redi[3];
-    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -2067,7 +1968,7 @@ int trmm(const T* A, int64_t strideA, const T* Tm, int64_t strideT, T* C, int64_
 template <typename T>
 int moments(const T* A, int64_t strideA, const T* Tm, const T* gamma, const T* Y, const double* kdiag, bool kdiag_uniform,
             int lik, double lik_param, T* mean, T* var, T* g0, T* g1, double* ve_partial, int32_t* nonpos_partial,
-            int64_t N, int64_t Np, int Mp, int P, int mode, double* split_work, void* stream) {
+            int64_t N, int64_t Np, int Mp, int P, int mode, void* stream) {
     const bool mean_only = (lik & TSVGP_LIK_MEANONLY) != 0;
     if (!A || !gamma || !kdiag || N <= 0 || Np < N || (Np % TILE) || Mp <= 0 || (Mp % TILE) || P <= 0 || strideA < 0)
         return TSVGP_EINVAL;
@@ -2117,22 +2018,10 @@ int moments(const T* A, int64_t strideA, const T* Tm, const T* gamma, const T* Y
                            (hipStream_t)stream, a);
     else if (mode == TSVGP_TRI_LOWER)
         hipLaunchKernelGGL((panel_kernel<T, MODE_MOMENTS, TSVGP_TRI_LOWER>), grid, block, 0, (hipStream_t)stream, a);
-    else if (mode == TSVGP_TRI_UPPER && (size_t)Mp * sizeof(T) <= 8192) {
-        // gamma fits beside the staging buffers without costing the second workgroup per CU: fused mean.
-        // With a work buffer and at least four column tiles: split panels (two workgroups per row panel) + finishing kernel
-        if (split_work && Mp / TILE >= 4) {
-            a.split = 1;
-            a.qpart = split_work;
-            a.mpart = split_work + (size_t)2 * Np * P;
-            hipLaunchKernelGGL((panel_kernel<T, MODE_MOMENTS, TSVGP_TRI_UPPER, true>), dim3((unsigned)(Np / TILE), 2), block,
-                               (size_t)Mp * sizeof(T), (hipStream_t)stream, a);
-            if (launch_status() != TSVGP_OK) return TSVGP_ELAUNCH;
-            hipLaunchKernelGGL((moments_finish_kernel<T>), grid, block, 0, (hipStream_t)stream, a);
-        } else {
-            hipLaunchKernelGGL((panel_kernel<T, MODE_MOMENTS, TSVGP_TRI_UPPER, true>), grid, block, (size_t)Mp * sizeof(T),
-                               (hipStream_t)stream, a);
-        }
-    }
+    else if (mode == TSVGP_TRI_UPPER && (size_t)Mp * sizeof(T) <= 8192)
+        // gamma fits beside the staging buffers without costing the second workgroup per CU: fused mean
+        hipLaunchKernelGGL((panel_kernel<T, MODE_MOMENTS, TSVGP_TRI_UPPER, true>), grid, block, (size_t)Mp * sizeof(T),
+                           (hipStream_t)stream, a);
     else if (mode == TSVGP_TRI_UPPER)
         hipLaunchKernelGGL((panel_kernel<T, MODE_MOMENTS, TSVGP_TRI_UPPER>), grid, block, 0, (hipStream_t)stream, a);
     else
@@ -2334,31 +2223,29 @@ int tsvgp_trmm_batched_f32(const float* A, int64_t strideA, const float* Tm, int
 
 int tsvgp_moments_f64(const double* A, const double* Tm, const double* gamma, const double* Y, double kdiag, int lik,
                       double lik_param, double* mean, double* var, double* g0, double* g1, double* ve_partial,
-                      int32_t* nonpos_partial, int64_t N, int64_t Np, int Mp, int P, int mode, double* split_work,
-                      void* stream) {
+                      int32_t* nonpos_partial, int64_t N, int64_t Np, int Mp, int P, int mode, void* stream) {
     return moments<double>(A, 0, Tm, gamma, Y, &kdiag, true, lik, lik_param, mean, var, g0, g1, ve_partial,
-                           nonpos_partial, N, Np, Mp, P, mode, split_work, stream);
+                           nonpos_partial, N, Np, Mp, P, mode, stream);
 }
 int tsvgp_moments_batched_f64(const double* A, int64_t strideA, const double* Tm, const double* gamma, const double* Y,
                               const double* kdiag_host, int lik, double lik_param, double* mean, double* var, double* g0,
                               double* g1, double* ve_partial, int32_t* nonpos_partial, int64_t N, int64_t Np, int Mp,
-                              int P, int mode, double* split_work, void* stream) {
+                              int P, int mode, void* stream) {
     return moments<double>(A, strideA, Tm, gamma, Y, kdiag_host, false, lik, lik_param, mean, var, g0, g1, ve_partial,
-                           nonpos_partial, N, Np, Mp, P, mode, split_work, stream);
+                           nonpos_partial, N, Np, Mp, P, mode, stream);
 }
 int tsvgp_moments_batched_f32(const float* A, int64_t strideA, const float* Tm, const float* gamma, const float* Y,
                               const double* kdiag_host, int lik, double lik_param, float* mean, float* var, float* g0,
                               float* g1, double* ve_partial, int32_t* nonpos_partial, int64_t N, int64_t Np, int Mp,
-                              int P, int mode, double* split_work, void* stream) {
+                              int P, int mode, void* stream) {
     return moments<float>(A, strideA, Tm, gamma, Y, kdiag_host, false, lik, lik_param, mean, var, g0, g1, ve_partial,
-                          nonpos_partial, N, Np, Mp, P, mode, split_work, stream);
+                          nonpos_partial, N, Np, Mp, P, mode, stream);
 }
 int tsvgp_moments_f32(const float* A, const float* Tm, const float* gamma, const float* Y, double kdiag, int lik,
                       double lik_param, float* mean, float* var, float* g0, float* g1, double* ve_partial,
-                      int32_t* nonpos_partial, int64_t N, int64_t Np, int Mp, int P, int mode, double* split_work,
-                      void* stream) {
+                      int32_t* nonpos_partial, int64_t N, int64_t Np, int Mp, int P, int mode, void* stream) {
     return moments<float>(A, 0, Tm, gamma, Y, &kdiag, true, lik, lik_param, mean, var, g0, g1, ve_partial,
-                          nonpos_partial, N, Np, Mp, P, mode, split_work, stream);
+                          nonpos_partial, N, Np, Mp, P, mode, stream);
 }
 
 int64_t tsvgp_site_accum_work_bytes_f64(int Mp, int P, int nsplit) {

@@ -136,14 +136,6 @@ class EStepEngine:
         # very end (a workgroup left alone on a CU runs its MFMA pipe at ~60 %), measured 18.3 -> 17.2 ms at N = 1e6.
         return ns * self.syrk_oversubscribe
 
-    split_panels = True  # moments kernel: two workgroups per 128-row panel + a finishing kernel (tsvgp_moments_*: split_work)
-
-    def _split_work(self, Np: int, P: int, moment_mode: int):
-        """Scratch pointer of the split-panel schedule of the moments kernel (3 Np P doubles), or None to run unsplit."""
-        if not self.split_panels or moment_mode != B.TRI_UPPER:
-            return None
-        return self._get("split_work", (3 * Np * P,), torch.float64).data_ptr()
-
     def _pad_square(self, A: torch.Tensor, Mp: int, key: str = None) -> torch.Tensor:
         """[.., M, M] fp64 -> zero-padded contiguous [.., Mp, Mp] in the compute dtype (a cached buffer per key)."""
         M = A.shape[-1]
@@ -465,7 +457,7 @@ class EStepEngine:
             self._launch("tsvgp_moments", lambda: self._fn("tsvgp_moments_batched")(
                 KfuP.data_ptr(), stride, Tm.data_ptr(), gam.data_ptr(), _ptr(Y) if need_g else None, kdiag, lik_flags,
                 float(lik_param), _ptr(mean), _ptr(var), _ptr(g0), _ptr(g1), ve_partial.data_ptr(),
-                nonpos_partial.data_ptr(), N, Np, Mp, P, moment_mode, self._split_work(Np, P, moment_mode), self._stream()))
+                nonpos_partial.data_ptr(), N, Np, Mp, P, moment_mode, self._stream()))
         stats = EStepStats(n_rows=N, ve_sum=ve_partial.sum(), nonpos=nonpos_partial.sum().to(torch.float64))
         if want_moments:
             stats.mean, stats.var = mean.to(torch.float64), (None if var is None else var.to(torch.float64))
@@ -704,7 +696,7 @@ class EStepEngine:
             self._launch("tsvgp_moments", lambda: self._fn("tsvgp_moments")(
                 A.data_ptr(), Tm.data_ptr(), gam.data_ptr(), _ptr(Y) if need_g else None, variance, lik_flags,
                 float(lik_param), _ptr(mean), _ptr(var), _ptr(g0), _ptr(g1), ve_partial.data_ptr(),
-                nonpos_partial.data_ptr(), N, Np, Mp, P, moment_mode, self._split_work(Np, P, moment_mode), self._stream()))
+                nonpos_partial.data_ptr(), N, Np, Mp, P, moment_mode, self._stream()))
         stats = EStepStats(n_rows=N, ve_sum=ve_partial.sum(), nonpos=nonpos_partial.sum().to(torch.float64))
         if want_moments:
             stats.mean, stats.var = mean.to(torch.float64), (None if var is None else var.to(torch.float64))

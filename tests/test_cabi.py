@@ -32,7 +32,7 @@ def test_argument_validation_needs_no_gpu():
     # null pointers / unpadded sizes are rejected before any launch
     assert lib.tsvgp_trmm_f64(None, None, None, 128, 128, 0, None) == 1
     assert lib.tsvgp_trmm_f32(None, None, None, 100, 128, 0, None) == 1
-    assert lib.tsvgp_moments_f64(None, None, None, None, 1.0, 0, 0.0, None, None, None, None, None, None, 1, 128, 128, 1, 0, None, None) == 1
+    assert lib.tsvgp_moments_f64(None, None, None, None, 1.0, 0, 0.0, None, None, None, None, None, None, 1, 128, 128, 1, 0, None) == 1
     assert lib.tsvgp_site_accum_f64(None, None, None, None, None, None, 128, 128, 1, 1, None) == 1
     assert lib.tsvgp_potrf_f64(None, 128, 128, 1, 0, None, None, 0, None) == 1
     assert lib.tsvgp_site_accum_work_bytes_f64(1024, 1, 15) == (28 * 15 + 8 * 11) * 128 * 128 * 8 + 11 * 1024 * 8

@@ -75,12 +75,9 @@ def _moments_ref(A, Tm, gamma, kdiag):
 
 @pytest.mark.parametrize("dtype,tol", DTYPES)
 @pytest.mark.parametrize("lik", ["none", "gaussian", "bernoulli"])
-@pytest.mark.parametrize("N,M,P,mode,split", [(100, 128, 1, 2, False), (300, 256, 2, 1, True), (129, 384, 3, 1, False),
-                                              (600, 1024, 1, 1, False), (600, 1024, 1, 1, True), (300, 1024, 8, 1, True),
-                                              (257, 640, 2, 1, True)])
-def test_moments_and_likelihood_map(engines, dtype, tol, lik, N, M, P, mode, split):
-    """M = 1024: the benchmark's 8 x 8 tile grid.  split: the two-workgroups-per-panel schedule + finishing kernel
-    (split_work given; it takes effect from four column tiles on, below that the same call runs unsplit)."""
+@pytest.mark.parametrize("N,M,P,mode", [(100, 128, 1, 2), (300, 256, 2, 1), (129, 384, 3, 1),
+                                        (600, 1024, 1, 1), (300, 1024, 8, 1)])  # the last two: the benchmark's 8 x 8 tile grid
+def test_moments_and_likelihood_map(engines, dtype, tol, lik, N, M, P, mode):
     eng = engines[dtype]
     B = pkg()._backend
     rng = np.random.RandomState(3)
@@ -103,10 +100,9 @@ def test_moments_and_likelihood_map(engines, dtype, tol, lik, N, M, P, mode, spl
     npp = torch.zeros(Np // 128, dtype=torch.int32, device="cuda:0")
     lik_id = {"none": 0, "gaussian": 1, "bernoulli": 2}[lik]
     fn = eng._fn("tsvgp_moments")
-    work = torch.full((3 * Np * P,), float("nan"), dtype=torch.float64, device="cuda:0") if split else None
     B.check(fn(At.data_ptr(), Tmt.data_ptr(), gt.data_ptr(), Yt.data_ptr(), kdiag, lik_id, 0.3, mean.data_ptr(),
                var.data_ptr(), g0.data_ptr(), g1.data_ptr(), vep.data_ptr(), npp.data_ptr(), N, Np, M, P, mode,
-               None if work is None else work.data_ptr(), eng._stream()), "moments")
+               eng._stream()), "moments")
     torch.cuda.synchronize()
     mref, vref = _moments_ref(At.double().cpu().numpy()[:N], Tmt.double().cpu().numpy(), gt.double().cpu().numpy(), kdiag)
     assert relerr(mean.cpu().numpy(), mref) < tol * 20
@@ -152,7 +148,7 @@ def test_moments_mean_only(engines, dtype, tol, lik, N, M, P):
     lik_id = {"none": 0, "gaussian": 1}[lik] | B.LIK_MEANONLY
     fn = eng._fn("tsvgp_moments")
     call = lambda a_ptr, lid, var_ptr: fn(a_ptr, None, gt.data_ptr(), Yt.data_ptr(), 2.5, lid, 0.3, mean.data_ptr(), var_ptr,
-                                          g0.data_ptr(), g1.data_ptr(), vep.data_ptr(), npp.data_ptr(), N, Np, M, P, 1, None,
+                                          g0.data_ptr(), g1.data_ptr(), vep.data_ptr(), npp.data_ptr(), N, Np, M, P, 1,
                                           eng._stream())
     B.check(call(At.data_ptr(), lik_id, None), "moments (mean only)")
     torch.cuda.synchronize()
@@ -399,7 +395,7 @@ def test_moments_and_site_accum_batched(engines, dtype, tol, lik):
     lik_id = {"gaussian": 1, "bernoulli": 2}[lik]
     B.check(eng._fn("tsvgp_moments_batched")(At.data_ptr(), Np * M, Tmt.data_ptr(), gt.data_ptr(), Yt.data_ptr(),
                                              (ctypes.c_double * P)(*kd), lik_id, 0.3, mean.data_ptr(), var.data_ptr(),
-                                             g0.data_ptr(), g1.data_ptr(), vep.data_ptr(), npp.data_ptr(), N, Np, M, P, 1, None,
+                                             g0.data_ptr(), g1.data_ptr(), vep.data_ptr(), npp.data_ptr(), N, Np, M, P, 1,
                                              eng._stream()), "moments batched")
     Ad, Td, gd = At.double().cpu().numpy(), Tmt.double().cpu().numpy(), gt.double().cpu().numpy()
     C = np.einsum("pnj,pij->pni", Ad[:, :N], Td)

@@ -26,12 +26,10 @@ g0 = torch.empty(Np, 1, dtype=torch.float64, device=dev); g1 = torch.empty_like(
 vep = torch.empty(nwg, dtype=torch.float64, device=dev); npp = torch.empty(nwg, dtype=torch.int32, device=dev)
 dbg = torch.zeros(nwg * 4, dtype=torch.int64, device=dev)
 lib.tsvgp_moments_f64.argtypes = [vp, vp, vp, vp, ctypes.c_double, ctypes.c_int, ctypes.c_double, vp, vp, vp, vp, vp, vp, i64, i64,
-                                  ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]
-split_work = torch.empty(3 * Np, dtype=torch.float64, device=dev)
-split_ptr = split_work.data_ptr() if os.environ.get("DIAG_SPLIT", "0") == "1" else None
+                                  ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]
 def run(d):
     assert lib.tsvgp_moments_f64(A.data_ptr(), T.data_ptr(), gam.data_ptr(), Y.data_ptr(), 1e9, 1, 0.1, d, None, g0.data_ptr(),
-                                 g1.data_ptr(), vep.data_ptr(), npp.data_ptr(), rows, Np, M, 1, 1, split_ptr, None) == 0
+                                 g1.data_ptr(), vep.data_ptr(), npp.data_ptr(), rows, Np, M, 1, 1, None) == 0
 for _ in range(3): run(None)
 torch.cuda.synchronize()
 e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
@@ -41,14 +39,14 @@ e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 5
 print(f"flags {flags} rows {rows}: moments {ms:.3f} ms  {rows * M * (M + 1) / ms / 1e9:.2f} TFLOP/s")
 run(dbg.data_ptr()); torch.cuda.synchronize()
-d = dbg.cpu().numpy().reshape(nwg, 4)  # split panels: the stamps of the second half-panel workgroups overwrite the first's (same blockIdx.x)
+d = dbg.cpu().numpy().reshape(nwg, 4)
 t0, t1 = d[:, 0].astype(np.float64), d[:, 1].astype(np.float64)
 base = t0.min()
 t0, t1 = (t0 - base) / 100.0, (t1 - base) / 100.0  # microseconds
 hw, xcc = d[:, 2] & 0xFFFFFFFF, (d[:, 2] >> 32) & 0xF
 clk = d[:, 3].astype(np.float64) / ((d[:, 1] - d[:, 0]).astype(np.float64) / 100.0) / 1e3  # GHz: shader cycles / wall
 print("in-kernel clock (GHz) over workgroups: p10 %.3f median %.3f p90 %.3f" % tuple(np.percentile(clk, [10, 50, 90])))
-mfma_cycles_pair = 2 * 16640 * 64 // (2 if split_ptr else 1)  # two resident workgroups' MFMAs per SIMD (8 tiles, M = 1024, upper form), 64 cycles each
+mfma_cycles_pair = 2 * 16640 * 64  # two resident workgroups' MFMAs per SIMD (8 tiles, M = 1024, upper form), 64 cycles each
 print("steady-state MFMA pipe use = cycles of two workgroups' MFMAs / median workgroup cycles: %.3f" % (mfma_cycles_pair / np.median(d[:, 3])))
 cu_key = xcc * 65536 + ((hw >> 8) & 0xFF)  # (xcc, se/sh/cu bits of HW_ID)
 keys = np.unique(cu_key)

@@ -22,10 +22,10 @@ for flags in ([], ["-DTSVGP_FILL_NT"]):
     lib = ctypes.CDLL(so)
     lib.tsvgp_se_fill_f64.argtypes = [vp, vp, vp, ctypes.c_double, vp, i64, ctypes.c_int, ctypes.c_int, i64, vp]
     lib.tsvgp_moments_f64.argtypes = [vp, vp, vp, vp, ctypes.c_double, ctypes.c_int, ctypes.c_double, vp, vp, vp, vp, vp, vp, i64, i64,
-                                      ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]
+                                      ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]
     fill = lambda: lib.tsvgp_se_fill_f64(X.data_ptr(), Z.data_ptr(), il.data_ptr(), 1.0, K.data_ptr(), N, M, D, M, None)
     mom = lambda: lib.tsvgp_moments_f64(K.data_ptr(), T.data_ptr(), gam.data_ptr(), Y.data_ptr(), 1e9, 1, 0.1, None, None, g0.data_ptr(),
-                                        g1.data_ptr(), vep.data_ptr(), npp.data_ptr(), N, Np, M, 1, 1, None, None)
+                                        g1.data_ptr(), vep.data_ptr(), npp.data_ptr(), N, Np, M, 1, 1, None)
     def timeit(fn, reps=10):
         for _ in range(2): fn()
         torch.cuda.synchronize()

@@ -24,7 +24,7 @@ vep = torch.empty(Np // 128, dtype=torch.float64, device=dev); npp = torch.empty
 fn = eng._fn("tsvgp_moments")
 def moments():
     assert fn(Kfu.data_ptr(), T.data_ptr(), gam.data_ptr(), Y.data_ptr(), 1e9, 1, 0.1, None, None, g0.data_ptr(), g1.data_ptr(),
-              vep.data_ptr(), npp.data_ptr(), N, Np, M, 1, 1, eng._split_work(Np, 1, 1), eng._stream()) == 0
+              vep.data_ptr(), npp.data_ptr(), N, Np, M, 1, 1, eng._stream()) == 0
 def timed(pre, reps=8):
     for _ in range(2): pre(); moments()
     torch.cuda.synchronize()

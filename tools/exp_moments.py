@@ -25,12 +25,10 @@ for rows in [int(r) for r in sys.argv[2:]]:
     Y = (torch.randn(rows, 1, dtype=dt, device=dev) > 0).to(dt) if lik == 2 else torch.randn(rows, 1, dtype=dt, device=dev)
     g0 = torch.empty(Np, 1, dtype=dt, device=dev); g1 = torch.empty_like(g0)
     vep = torch.empty(Np // 128, dtype=torch.float64, device=dev); npp = torch.empty(Np // 128, dtype=torch.int32, device=dev)
-    work = torch.empty(3 * Np, dtype=torch.float64, device=dev)
     def run():
         assert fn(vp(A.data_ptr()), vp(T.data_ptr()), vp(gam.data_ptr()), vp(Y.data_ptr()), ctypes.c_double(1e9), lik,
                                      ctypes.c_double(0.1), None, None, vp(g0.data_ptr()), vp(g1.data_ptr()), vp(vep.data_ptr()),
-                                     vp(npp.data_ptr()), ctypes.c_int64(rows), ctypes.c_int64(Np), M, 1, 1,
-                                     vp(work.data_ptr()) if os.environ.get("EXP_SPLIT", "0") == "1" else None, None) == 0
+                                     vp(npp.data_ptr()), ctypes.c_int64(rows), ctypes.c_int64(Np), M, 1, 1, None) == 0
     for _ in range(3): run()
     torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
