@@ -79,3 +79,34 @@ def test_ns_full_size_row_sample_matches_oracle():
     e_h = float(hip.elbo((Xd[sel], Yd[sel])))
     e_o = float(O.elbo_chunked(ora, (X[idx], Y[idx]), chunk_rows=1024))
     assert abs(e_h - e_o) / abs(e_o) < 1e-9
+
+
+def test_c5_full_size_row_sample_matches_oracle():
+    """BASELINE configs[4] at full size: P = 8 latents, one SE kernel per latent (l_p = linspace(0.8, 1.5, 8)) on shared
+    inducing points, N = 1e6, M = 1024, fp64 -- the latent-batched launches over the [8, Np, Mp] operand (66 GB).  The HIP
+    state after two steps goes to the oracle, which recomputes moments and likelihood gradients on every 997th row."""
+    p = pkg()
+    N, P = 1_000_000, 8
+    w = dict(bench.WORKLOADS["c5"], N=N)
+    X, Y, Z = bench.make_data(w)
+    ls = np.linspace(0.8, 1.5, P)
+    hip = p.t_SVGP(p.SeparateIndependent([p.SquaredExponential(1.0, float(l)) for l in ls]), p.Gaussian(0.1),
+                   p.SharedIndependentInducingVariables(Z), num_latent_gps=P)
+    ora = O.t_SVGP(O.SeparateIndependent([O.SquaredExponential(1.0, float(l)) for l in ls]), O.Gaussian(0.1),
+                   O.SharedIndependentInducingVariables(Z), num_latent_gps=P)
+    Xd, Yd = torch.as_tensor(X, device="cuda:0"), torch.as_tensor(Y, device="cuda:0")
+    for _ in range(2):
+        hip.natgrad_step((Xd, Yd), lr=0.8)
+    assert hip._get_engine().last_batched
+    ora.sites.lambda_1 = hip.lambda_1.numpy()
+    ora.sites._lambda_2_sqrt = np.tril(hip.lambda_2_sqrt.numpy())
+    mean, var, g0, g1 = hip.moments_and_gradients((Xd, Yd))
+    idx = np.arange(0, N, 997)
+    mu_o, var_o = O.predict_f_chunked(ora, X[idx], chunk_rows=512)
+    g0_o, g1_o = ora.likelihood.variational_expectations_grads(mu_o, var_o, Y[idx])
+    sel = torch.as_tensor(idx, device="cuda:0")
+    assert relerr(mean[sel].cpu().numpy(), mu_o) < 1e-8
+    assert relerr(var[sel].cpu().numpy(), var_o) < 1e-8
+    assert relerr(g0[sel].cpu().numpy(), g0_o) < 1e-8
+    assert relerr(g1[sel].cpu().numpy(), np.minimum(g1_o, -1e-8)) < 1e-8
+    hip._get_engine().release()
