@@ -121,7 +121,7 @@ def cpu_baseline(w, budget_s=20.0, model_kind="tsvgp"):
     from oracle import tsvgp_oracle as O
 
     cores, blas = _blas_info()
-    cap = max(2000, int(1.2e8 // (w["M"] * w["P"])))  # [n, M, P] fp64 temporaries <= ~1 GB
+    cap = max(2000, int(4.0e7 // (w["M"] * w["P"])))  # [n, M, P] fp64 temporaries <= ~0.3 GB: a step stays within seconds
     n1 = min(w["N"], max(2000, min(cap // 2, w["N"] // 50)))
     n2 = min(w["N"], max(2 * n1, min(cap, w["N"] // 20)))
     lik = O.Gaussian(variance=w.get("noise", 0.1)) if w["lik"] == "gaussian" else O.Bernoulli()
@@ -132,6 +132,7 @@ def cpu_baseline(w, budget_s=20.0, model_kind="tsvgp"):
     for n_s in sorted({n1, n2}):
         X, Y = Xa[:n_s], Ya[:n_s]
         model = cls(kernel, lik, wrap(Z), num_latent_gps=w["P"])
+        print(f"[cpu_baseline] oracle E-steps on {n_s} rows ...", file=sys.stderr, flush=True)
         model.natgrad_step((X, Y), lr=0.8)  # warm-up (BLAS thread pools, page faults)
         times = []
         t_all = time.perf_counter()
@@ -139,6 +140,7 @@ def cpu_baseline(w, budget_s=20.0, model_kind="tsvgp"):
             t0 = time.perf_counter()
             model.natgrad_step((X, Y), lr=0.8)
             times.append(time.perf_counter() - t0)
+            print(f"[cpu_baseline]   step {len(times)}: {times[-1]:.2f} s", file=sys.stderr, flush=True)
             if time.perf_counter() - t_all > 2 * budget_s:
                 break
         med[n_s] = (float(np.median(times)), len(times))
@@ -181,6 +183,8 @@ def elbo_match(model, w, X, Y, Z, budget_s):
     t_blk = time.perf_counter() - t0
     rows = w["N"] if t_blk * (w["N"] / chunk) <= budget_s else max(chunk, int(budget_s / t_blk) * chunk)
     rows = min(rows, w["N"])
+
+    print(f"[elbo_match] oracle ELBO on {rows} of {w['N']} rows (first block: {t_blk:.1f} s) ...", file=sys.stderr, flush=True)
 
     def tick(done, total, last=[time.perf_counter()]):
         if time.perf_counter() - last[0] > 20.0:

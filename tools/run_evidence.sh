@@ -16,6 +16,8 @@ case "$1" in
   ;;
 2)
   python bench.py --workload c5 --steps 5 --warmup 2 --elbo-budget 60 > $O/c5_bench.json 2> $O/c5.err; echo c5 done
+  ;;
+2b)
   python bench.py --workload c5s --steps 5 --warmup 2 --elbo-budget 60 > $O/c5s_bench.json 2> $O/c5s.err; echo c5s done
   python bench.py --model white --steps 10 --warmup 3 --no-cpu-baseline > $O/ns_white_bench.json 2> $O/white.err; echo white done
   python bench.py --rows 125000 --steps 40 --warmup 5 --no-cpu-baseline --no-elbo-match --no-side-lines > $O/ns_rows125000_bench.json 2> $O/rows.err
