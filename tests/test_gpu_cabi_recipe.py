@@ -1,0 +1,99 @@
+"""The C-ABI seam exercised the way INTEGRATION.md section B describes it: an E-step assembled from raw ``ctypes`` calls into
+``libtsvgp_hip.so`` plus M x M torch algebra written straight from the reference's formulas -- no ``t-svgp_amd`` model or
+engine code in between -- against the oracle.  The recipe uses the plain lower Cholesky factors a reference maintainer would
+have at hand (so the moments run in TSVGP_TRI_DENSE mode) and the direct route (tsvgp.py:246-304)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import tsvgp_oracle as O
+from tests.helpers import pkg, relerr, synthetic
+
+pytestmark = pytest.mark.gpu
+vp, i64, i32, f64 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_double
+SE, GAUSSIAN, BERNOULLI, TRI_DENSE = 0, 1, 2, 2
+
+
+def _lib():
+    lib = ctypes.CDLL(pkg()._backend.LIB_PATH)
+    lib.tsvgp_kernel_fill_f64.argtypes = [i32, vp, vp, vp, f64, vp, i64, i32, i32, i64, vp]
+    lib.tsvgp_moments_f64.argtypes = [vp, vp, vp, vp, f64, i32, f64, vp, vp, vp, vp, vp, vp, i64, i64, i32, i32, i32, vp]
+    lib.tsvgp_site_accum_work_bytes_f64.argtypes, lib.tsvgp_site_accum_work_bytes_f64.restype = [i32, i32, i32], i64
+    lib.tsvgp_site_accum_f64.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]
+    lib.tsvgp_potrf_inv_f64.argtypes = [vp, i32, i32, i32, i64, vp, vp, vp, vp, vp, i32, vp]
+    lib.tsvgp_potrf_f64.argtypes = [vp, i32, i32, i32, i64, vp, vp, i32, vp]
+    return lib
+
+
+def _chol_with_inverse(lib, A):
+    b, M, _ = A.shape
+    L = A.clone()
+    X = torch.empty(2, b, M, M, dtype=A.dtype, device=A.device)
+    info = torch.empty(b, dtype=torch.int32, device=A.device)
+    work = torch.empty(b, 128 * 128, dtype=A.dtype, device=A.device)
+    T = torch.empty_like(L)
+    assert lib.tsvgp_potrf_inv_f64(L.data_ptr(), M, M, b, M * M, info.data_ptr(), work.data_ptr(), X[0].data_ptr(),
+                                   X[1].data_ptr(), T.data_ptr(), 0, None) == 0
+    assert int(info.abs().sum()) == 0
+    return torch.tril(L), X[0]
+
+
+@pytest.mark.parametrize("lik", ["gaussian", "bernoulli"])
+def test_estep_from_raw_cabi_calls_matches_oracle(lik):
+    lib = _lib()
+    dev, dt = "cuda:0", torch.float64
+    N, M, Din, P = 1000, 128, 3, 1  # M a multiple of 128: no padding to write out
+    Xn, Yn, Zn = synthetic(N=N, M=M, D=Din, lik=lik, seed=4)
+    X, Y, Z = (torch.as_tensor(a, device=dev) for a in (Xn, Yn, Zn))
+    variance, noise, lr, jitter = 1.0, 0.1, 0.8, 1e-9
+    inv_ls = torch.ones(Din, dtype=dt, device=dev)
+    Np = -(-N // 128) * 128
+    Id = torch.eye(M, dtype=dt, device=dev)
+    l1 = torch.zeros(M, P, dtype=dt, device=dev)
+    Ls = (-1e-10 * Id)[None].clone()  # tsvgp.py:174-180
+    ora = O.t_SVGP(O.SquaredExponential(variance, 1.0), O.Gaussian(noise) if lik == "gaussian" else O.Bernoulli(), Zn)
+    lik_id = GAUSSIAN if lik == "gaussian" else BERNOULLI
+    for _ in range(2):
+        # M x M prelude, from the reference's formulas (util.py:168-175, tsvgp.py:209-211, 268-270)
+        Kzz = torch.empty(M, M, dtype=dt, device=dev)
+        assert lib.tsvgp_kernel_fill_f64(SE, Z.data_ptr(), Z.data_ptr(), inv_ls.data_ptr(), variance, Kzz.data_ptr(), M, M, Din, M, None) == 0
+        K6, K9 = Kzz + 1e-6 * Id, Kzz + jitter * Id
+        W = Id + Ls[0].T @ K6 @ Ls[0]
+        (cW, c9), (cWinv, c9inv) = [t for t in zip(*[_chol_with_inverse(lib, A[None]) for A in (W, K9)])]
+        D = (cWinv[0] @ Ls[0].T)[None].contiguous()  # chol(W)^-1 L^T, dense
+        beta = l1 - D[0].T @ (D[0] @ (K6 @ l1))  # K6^-1 m
+        K9inv = c9inv[0].T @ c9inv[0]
+        # N pass: fill, moments + likelihood gradients, site sums
+        Kfu = torch.empty(Np, M, dtype=dt, device=dev)
+        assert lib.tsvgp_kernel_fill_f64(SE, X.data_ptr(), Z.data_ptr(), inv_ls.data_ptr(), variance, Kfu.data_ptr(), N, M, Din, M, None) == 0
+        g0 = torch.empty(Np, P, dtype=dt, device=dev)
+        g1 = torch.empty_like(g0)
+        ve = torch.empty(Np // 128, dtype=dt, device=dev)
+        nonpos = torch.empty(Np // 128, dtype=torch.int32, device=dev)
+        assert lib.tsvgp_moments_f64(Kfu.data_ptr(), D.data_ptr(), beta.contiguous().data_ptr(), Y.data_ptr(), variance, lik_id, noise,
+                                     None, None, g0.data_ptr(), g1.data_ptr(), ve.data_ptr(), nonpos.data_ptr(), N, Np, M, P,
+                                     TRI_DENSE, None) == 0
+        assert int(nonpos.sum()) == 0
+        nsplit = 4
+        work = torch.empty(lib.tsvgp_site_accum_work_bytes_f64(M, P, nsplit), dtype=torch.uint8, device=dev)
+        acc2 = torch.empty(P, M, M, dtype=dt, device=dev)
+        acc1 = torch.empty(P, M, dtype=dt, device=dev)
+        assert lib.tsvgp_site_accum_f64(Kfu.data_ptr(), g0.data_ptr(), g1.data_ptr(), acc2.data_ptr(), acc1.data_ptr(),
+                                        work.data_ptr(), Np, M, P, nsplit, None) == 0
+        # epilogue (tsvgp.py:278-303): direct projection, chain rule, convex update, -chol
+        G1 = K9inv @ acc2[0] @ K9inv
+        G0 = K9inv @ acc1.T
+        meanZ = Kzz @ beta
+        l1 = (1 - lr) * l1 + lr * (G0 - 2.0 * G1 @ meanZ)
+        target = (1 - lr) * (Ls[0] @ Ls[0].T) - 2.0 * lr * 0.5 * (G1 + G1.T) + jitter * Id
+        Lnew = target[None].clone()
+        info = torch.empty(1, dtype=torch.int32, device=dev)
+        pw = torch.empty(1, 128 * 128, dtype=dt, device=dev)
+        assert lib.tsvgp_potrf_f64(Lnew.data_ptr(), M, M, 1, M * M, info.data_ptr(), pw.data_ptr(), 0, None) == 0
+        assert int(info[0]) == 0
+        Ls = -torch.tril(Lnew)
+        ora.natgrad_step((Xn, Yn), lr=lr)
+        assert relerr(l1.cpu().numpy(), ora.lambda_1) < 1e-8
+        assert relerr((Ls @ Ls.transpose(-1, -2)).cpu().numpy(), ora.lambda_2) < 1e-8
