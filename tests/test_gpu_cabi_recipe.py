@@ -44,7 +44,8 @@ def _chol_with_inverse(lib, A):
 def test_estep_from_raw_cabi_calls_matches_oracle(lik):
     lib = _lib()
     dev, dt = "cuda:0", torch.float64
-    N, M, Din, P = 1000, 128, 3, 1  # M a multiple of 128: no padding to write out
+    N, M, Din, P = 1000, 128, 8, 1  # M a multiple of 128: no padding to write out; D = 8: cond(K_uu) ~ 1e1, where the
+    # direct route of the recipe is accurate (it needs cond(K_uu + jitter I) <= 6e4)
     Xn, Yn, Zn = synthetic(N=N, M=M, D=Din, lik=lik, seed=4)
     X, Y, Z = (torch.as_tensor(a, device=dev) for a in (Xn, Yn, Zn))
     variance, noise, lr, jitter = 1.0, 0.1, 0.8, 1e-9
