@@ -16,8 +16,9 @@
  *     state is one "dynamic-LDS opt-in done" flag per (kernel, device) for the two
  *     kernels that use more than 64 KB of LDS (set on first use, thread-safe; any
  *     device of the process may be current).
- *   - Input dimension limits: D <= 32 for the fill (tsvgp_kernel_fill_*), D <= 16 for the
- *     M-step gradient contraction (tsvgp_kernel_grad_*); larger D returns 1.
+ *   - Input dimension limits: D <= 32 for the fused fill (tsvgp_kernel_fill_*; beyond that the distance is a
+ *     library GEMM finished by tsvgp_gram_to_kernel_*), D <= 16 for the M-step gradient contraction
+ *     (tsvgp_kernel_grad_*); larger D returns 1.
  *   - Suffix _f64 / _f32 selects the arithmetic type T of the N-sized arrays.
  *   - "Padded" dimensions: Np = N rounded up to 128, Mp = M rounded up to 128.  Work
  *     buffers (Kfu, B) are [Np x Mp] row-major with the padding ZERO-filled by the
@@ -103,6 +104,15 @@ int tsvgp_kernel_fill_batched_f64(int kind, const double *X, const double *Z, co
 int tsvgp_kernel_fill_batched_f32(int kind, const float *X, const float *Z, const float *inv_ls,
                                   const float *variance_host, float *K, int64_t strideK, int64_t N, int M, int D,
                                   int64_t ldk, int P, void *stream);
+
+/* (1d) Input dimensions beyond 32 (the reference's MNIST notebook has D = 784): the scaled squared distance is then a
+ *     GEMM, r2[n,m] = xx[n] + zz[m] - 2 G[n,m] with G = (X/l)(Z/l)^T (GPflow's square_distance form [ext]), which the caller
+ *     takes from the BLAS library into K [rows_pad x ldk]; this call turns it into K = variance * k(r2) in place and
+ *     zero-fills the padding (rows >= N, columns >= M).  xx [N], zz [M]: squared norms of the scaled rows. */
+int tsvgp_gram_to_kernel_f64(int kind, double *K, const double *xx, const double *zz, double variance, int64_t N, int M,
+                             int64_t ldk, void *stream);
+int tsvgp_gram_to_kernel_f32(int kind, float *K, const float *xx, const float *zz, float variance, int64_t N, int M,
+                             int64_t ldk, void *stream);
 
 /* (2) Blocked triangular solve with an N-sized right-hand side, in inverted-factor form:
  *        C[n, i] = sum_{j in range(i)} A[n, j] * Tm[i, j],   range = j<=i | j>=i | all j   (mode)

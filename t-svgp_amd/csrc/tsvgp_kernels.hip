@@ -1887,6 +1887,54 @@ struct DynLdsOptIn {
     }
 };
 
+// K(X, Z) for input dimensions beyond the fill kernel's compile-time sizes (D > 32, e.g. the 784 pixels of the reference's
+// MNIST notebook): at that size the scaled distance IS a GEMM, r2 = |x~|^2 + |z~|^2 - 2 x~.z~ (GPflow's own square_distance
+// form [ext]), which the host takes from the BLAS library; this kernel turns the Gram block G = x~ z~^T into
+// K = variance * k(r2) in place and zero-fills the padding.  One thread per two adjacent columns.
+template <typename T, int KIND>
+__global__ __launch_bounds__(NTHREADS) void gram_to_kernel_kernel(T* __restrict__ K, const T* __restrict__ xx,
+                                                                  const T* __restrict__ zz, T variance, int64_t N, int M,
+                                                                  int64_t ldk, int64_t rows_pad, int cols_pad) {
+    typedef typename Mfma<T>::pair_t pair_t;
+    const int64_t n = blockIdx.y;
+    const int m = (blockIdx.x * NTHREADS + threadIdx.x) * 2;
+    if (n >= rows_pad || m >= cols_pad) return;
+    pair_t* p = reinterpret_cast<pair_t*>(K + n * ldk + m);
+    pair_t out;
+    out[0] = out[1] = T(0);
+    if (n < N) {
+        const pair_t g = *p;
+        const T x = xx[n];
+        if (m < M) out[0] = variance * kernel_profile<KIND>(x + zz[m] - T(2) * g[0]);
+        if (m + 1 < M) out[1] = variance * kernel_profile<KIND>(x + zz[m + 1] - T(2) * g[1]);
+    }
+    *p = out;
+}
+
+template <typename T>
+int gram_to_kernel(int kind, T* K, const T* xx, const T* zz, T variance, int64_t N, int M, int64_t ldk, void* stream) {
+    if (!K || !xx || !zz || N <= 0 || M <= 0 || (kind != TSVGP_KERNEL_SE && kind != TSVGP_KERNEL_MATERN32 && kind != TSVGP_KERNEL_MATERN52))
+        return TSVGP_EINVAL;
+    const int64_t rows_pad = (N + TILE - 1) / TILE * TILE;
+    const int cols_pad = (M + TILE - 1) / TILE * TILE;
+    if (ldk < cols_pad || (ldk % 2) != 0 || rows_pad > 0x7fffffff) return TSVGP_EINVAL;
+    // grid.y is limited to 65535: rows go through y (and z when there are more)
+    const dim3 block(NTHREADS);
+    const unsigned gx = (unsigned)((cols_pad / 2 + NTHREADS - 1) / NTHREADS);
+    for (int64_t r0 = 0; r0 < rows_pad; r0 += 65535) {
+        const unsigned gy = (unsigned)((rows_pad - r0 < 65535) ? rows_pad - r0 : 65535);
+        T* Kr = K + r0 * ldk;
+        const T* xr = xx + (r0 < N ? r0 : 0);
+        const int64_t Nr = N - r0 > 0 ? N - r0 : 0;
+#define TSVGP_G2K(KIND_) hipLaunchKernelGGL((gram_to_kernel_kernel<T, KIND_>), dim3(gx, gy), block, 0, (hipStream_t)stream, Kr, xr, zz, variance, Nr, M, ldk, (int64_t)gy, cols_pad)
+        if (kind == TSVGP_KERNEL_SE) TSVGP_G2K(TSVGP_KERNEL_SE);
+        else if (kind == TSVGP_KERNEL_MATERN32) TSVGP_G2K(TSVGP_KERNEL_MATERN32);
+        else TSVGP_G2K(TSVGP_KERNEL_MATERN52);
+#undef TSVGP_G2K
+    }
+    return launch_status();
+}
+
 // P latents in one launch: inv_ls [P x D] (device), variance [P] (HOST: the scalars travel as kernel arguments, like the
 // single-latent entry point's `variance`), K + p * strideK.
 template <typename T>
@@ -2204,6 +2252,15 @@ int tsvgp_kernel_fill_batched_f32(int kind, const float* X, const float* Z, cons
                                   const float* variance_host, float* K, int64_t strideK, int64_t N, int M, int D,
                                   int64_t ldk, int P, void* stream) {
     return kernel_fill<float>(kind, X, Z, inv_ls, variance_host, K, strideK, N, M, D, ldk, P, stream);
+}
+
+int tsvgp_gram_to_kernel_f64(int kind, double* K, const double* xx, const double* zz, double variance, int64_t N, int M,
+                             int64_t ldk, void* stream) {
+    return gram_to_kernel<double>(kind, K, xx, zz, variance, N, M, ldk, stream);
+}
+int tsvgp_gram_to_kernel_f32(int kind, float* K, const float* xx, const float* zz, float variance, int64_t N, int M,
+                             int64_t ldk, void* stream) {
+    return gram_to_kernel<float>(kind, K, xx, zz, variance, N, M, ldk, stream);
 }
 
 int tsvgp_trmm_f64(const double* A, const double* Tm, double* C, int64_t Np, int Mp, int mode, void* stream) {

@@ -157,8 +157,17 @@ class EStepEngine:
         N, D = X.shape
         M = Z.shape[0]
         if D > MAX_INPUT_DIM:
-            raise ValueError(f"input dimension D = {D} exceeds the HIP fill kernel's limit of {MAX_INPUT_DIM} "
-                             "(include/tsvgp_hip.h: tsvgp_kernel_fill_*)")
+            # beyond the fused kernel's compile-time sizes the scaled distance is a GEMM (GPflow's own square_distance
+            # form): x~ z~^T from the BLAS library into the padded buffer, then tsvgp_gram_to_kernel_* in place
+            Xs, Zs = X * inv_ls, torch.zeros((out.shape[1], D), dtype=X.dtype, device=X.device)
+            Zs[:M] = Z * inv_ls
+            torch.mm(Xs, Zs.t(), out=out[:N])
+            xx, zz = (Xs * Xs).sum(dim=1).contiguous(), (Zs[:M] * Zs[:M]).sum(dim=1).contiguous()
+            fn = self._fn("tsvgp_gram_to_kernel", X.dtype)
+            with torch.cuda.device(self.device):
+                self._launch("tsvgp_se_fill", lambda: fn(kind, out.data_ptr(), xx.data_ptr(), zz.data_ptr(), float(variance),
+                                                         N, M, out.shape[1], self._stream()))
+            return out
         fn = self._fn("tsvgp_kernel_fill", X.dtype)
         with torch.cuda.device(self.device):
             self._launch("tsvgp_se_fill" if N != M or X.data_ptr() != Z.data_ptr() else "tsvgp_se_fill(Kuu)",
@@ -351,7 +360,7 @@ class EStepEngine:
             return t[p]
         return t[p] if t.dim() == 3 else t
 
-    def _batch_plan(self, N, M, kernel, P, whiten_T, whiten_mode, project_T, moments_on_kfu):
+    def _batch_plan(self, N, M, kernel, P, whiten_T, whiten_mode, project_T, moments_on_kfu, D=0):
         """Can the pass over P separately-parameterised latents run as batched launches (tsvgp_*_batched_*)?  Needs one
         kernel family, at most MAX_BATCH latents, no "projected" latent (its second product is not in place), the
         whitening in upper form (in place) and room for the [P, Np, Mp] operand.  Returns the list of whitened latents
@@ -359,6 +368,8 @@ class EStepEngine:
         if not self.batch_separate or P < 2 or P > B.MAX_BATCH or moments_on_kfu:
             return None
         if len({k.kind for k in kernel.kernels}) != 1:
+            return None
+        if D > MAX_INPUT_DIM:  # the GEMM-based fill of large input dimensions is per latent
             return None
         if any(self._per_latent(project_T, p) is not None for p in range(P)):
             return None
@@ -495,7 +506,8 @@ class EStepEngine:
                 whitened = [p for p in range(P) if self._per_latent(whiten_T, p) is not None]
             else:
                 whitened = self._batch_plan(X.shape[0], Z.shape[0], kernel, P, whiten_T,
-                                            kw.get("whiten_mode", B.TRI_UPPER), project_T, kw.get("moments_on_kfu", False))
+                                            kw.get("whiten_mode", B.TRI_UPPER), project_T, kw.get("moments_on_kfu", False),
+                                            D=X.shape[1])
             if whitened is not None:
                 return self._run_batched(X, Y, Z, kernel, whitened, moment_Tm=moment_Tm, moment_mode=kw["moment_mode"],
                                          gamma=gamma, lik_id=kw.get("lik_id", B.LIK_NONE), lik_param=kw.get("lik_param", 0.0),
@@ -545,7 +557,7 @@ class EStepEngine:
             P = len(kernel.kernels)
             if routes is None or any(r == "projected" for r in routes):
                 return None
-            if self._batch_plan(N, M, kernel, P, None, B.TRI_UPPER, None, False) is None:
+            if self._batch_plan(N, M, kernel, P, None, B.TRI_UPPER, None, False, D=D) is None:
                 return None
             main = torch.cuda.current_stream(dev)
             if self._side is None:

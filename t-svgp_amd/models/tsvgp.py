@@ -648,10 +648,9 @@ class t_SVGP(base_SVGP):
             if self.projection == "auto" and self._cond_cache is not None:
                 self._cond_cache[2].update({p: r for p, r in enumerate(routes)})
 
-    def _step_device(self, X, Y, lr, jitter, routes, inplace=False) -> torch.Tensor:
-        """The whole E-step as device work, no host synchronisation: M x M prelude, N-pass, all-reduce, epilogue, state
-        assignment.  Returns the status flags (device).  With ``inplace`` the state tensors are overwritten in place
-        (what a captured graph needs) instead of being replaced."""
+    def _step_front(self, X, Y, lr, jitter, routes):
+        """M x M prelude and the N-pass of one E-step (everything in front of the all-reduce): returns (per-shard
+        statistics, prelude operands).  No host synchronisation."""
         warm_key = self._warm_key(X, jitter)
         eng = self._get_engine()
         # K(X, Z) depends on neither lambda nor the M x M factors: its fill runs on a side stream beside the prelude
@@ -667,6 +666,13 @@ class t_SVGP(base_SVGP):
                      moments_on_kfu=ops["moments_on_kfu"], project_mode=ops["project_mode"],
                      sites=True, b_tag=warm_key,
                      mean_only=self.skip_unused_variance and self.likelihood.lik_id == B.LIK_GAUSSIAN)
+        return st, ops
+
+    def _step_device(self, X, Y, lr, jitter, routes, inplace=False) -> torch.Tensor:
+        """The whole E-step as device work, no host synchronisation: M x M prelude, N-pass, all-reduce, epilogue, state
+        assignment.  Returns the status flags (device).  With ``inplace`` the state tensors are overwritten in place
+        (what a captured graph needs) instead of being replaced."""
+        st, ops = self._step_front(X, Y, lr, jitter, routes)
         return self._apply_site_update(st, ops, lr, jitter, inplace=inplace)
 
     # -- hipGraph replay of the step (launch-bound problem sizes) -------------------------------------------------
@@ -693,9 +699,12 @@ class t_SVGP(base_SVGP):
         if self.device.type != "cuda":
             return False
         eng = self._get_engine()
-        if (D_.world_size() > 1 or self.cache_whitened or eng.profile is not None
-                or isinstance(self.kernel, SeparateIndependent)):
+        if self.cache_whitened or eng.profile is not None or isinstance(self.kernel, SeparateIndependent):
             return False
+        # With several ranks the step is TWO graphs around the all-reduce of the packed accumulators: everything in
+        # front of it (prelude, fill, moments, site sums, packing) and everything behind it (unpacking, epilogue, state
+        # update, status words); the collective itself is issued between the two replays on the same stream.
+        two = self._reduce()
         lik_v = tuple(p.version for p in vars(self.likelihood).values() if hasattr(p, "version"))
         key = (X.data_ptr(), Y.data_ptr(), tuple(X.shape), tuple(Y.shape), X.dtype, Y.dtype, self._kernel_versions(),
                lik_v, id(self.inducing_variable.Z), self.inducing_variable.Z.version, float(lr), float(jitter),
@@ -717,11 +726,26 @@ class t_SVGP(base_SVGP):
             saved_buf, saved_tag = eng._buf, eng._b_tag
             eng._buf, eng._b_tag = {}, None  # the graph's own work buffers (kept alive by the entry)
             try:
-                with torch.cuda.graph(graph):
-                    bl1.copy_(sl1)
-                    bL.copy_(sL)
-                    flags = self._step_device(X, Y, lr, jitter, routes, inplace=True)
-                entry = dict(graph=graph, flags=flags, state=(sl1, sL), backup=(bl1, bL), buf=eng._buf)
+                if not two:
+                    with torch.cuda.graph(graph):
+                        bl1.copy_(sl1)
+                        bL.copy_(sL)
+                        flags = self._step_device(X, Y, lr, jitter, routes, inplace=True)
+                    entry = dict(graph=graph, flags=flags, state=(sl1, sL), backup=(bl1, bL), buf=eng._buf)
+                else:
+                    P_, M_ = self.num_latent_gps, self.num_inducing
+                    with torch.cuda.graph(graph):
+                        bl1.copy_(sl1)
+                        bL.copy_(sL)
+                        st, ops = self._step_front(X, Y, lr, jitter, routes)
+                        packed = D_.pack_stats(st, True, eng)
+                    tail = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(tail, pool=graph.pool()):
+                        acc2, acc1, _, nonpos, rows = D_.unpack_stats(packed, P_, M_, True, eng)
+                        flags = self._apply_site_update(None, ops, lr, jitter, inplace=True,
+                                                        reduced=(acc2, acc1, nonpos, rows))
+                    entry = dict(graph=graph, tail=tail, packed=packed, ops=ops, flags=flags, state=(sl1, sL),
+                                 backup=(bl1, bL), buf=eng._buf)
                 self._graphs[key] = entry
             except Exception:  # not capturable on this stack: never try this key again
                 self._graphs[key] = "seen-uncapturable"
@@ -740,6 +764,9 @@ class t_SVGP(base_SVGP):
             sL.copy_(Lp.value)
             Lp._value = sL
         entry["graph"].replay()
+        if "tail" in entry:
+            D_.all_reduce_sum(entry["packed"])
+            entry["tail"].replay()
         try:
             ok = self._judge(entry["flags"].cpu(), soft_final=any(r != "projected" for r in routes)) is True
         except FloatingPointError:
@@ -752,12 +779,16 @@ class t_SVGP(base_SVGP):
         Lp.version += 1
         return True
 
-    def _apply_site_update(self, st, ops, lr, jitter, inplace=False):
+    def _apply_site_update(self, st, ops, lr, jitter, inplace=False, reduced=None):
         """All-reduce of the packed accumulators (RCCL) + the replicated M x M epilogue (tsvgp.py:278-303).
-        Returns the status flags (device tensor, see ``_status_flags``)."""
+        Returns the status flags (device tensor, see ``_status_flags``).  ``reduced``: the already summed
+        (acc2, acc1, nonpos, rows) when the caller did the collective itself (the two-graph replay)."""
         P, M = self.num_latent_gps, self.num_inducing
         eng = self._get_engine()
-        acc2, acc1, _, nonpos, rows, _ = D_.reduce_stats(st, P, M, True, self._reduce(), eng)
+        if reduced is not None:
+            acc2, acc1, nonpos, rows = reduced
+        else:
+            acc2, acc1, _, nonpos, rows, _ = D_.reduce_stats(st, P, M, True, self._reduce(), eng)
         if ops.get("epi_event") is not None:  # L L^T, K_uu beta, K9^-1 from the side stream (see _site_operands)
             torch.cuda.current_stream(self.device).wait_event(ops["epi_event"])
 

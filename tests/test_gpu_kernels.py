@@ -422,3 +422,22 @@ def test_moments_and_site_accum_batched(engines, dtype, tol, lik):
     g0d, g1d = g0.double().cpu().numpy(), g1.double().cpu().numpy()
     assert relerr(acc2.cpu().numpy(), np.einsum("pnm,pno,np->pmo", Ad, Ad, g1d)) < tol * 50
     assert relerr(acc1.cpu().numpy(), np.einsum("pnm,np->pm", Ad, g0d)) < tol * 50
+
+
+@pytest.mark.parametrize("dtype,tol", DTYPES)
+@pytest.mark.parametrize("kind,name", [(0, "SquaredExponential"), (3, "Matern52")])
+@pytest.mark.parametrize("N,M,D", [(300, 70, 40), (129, 200, 784)])
+def test_fill_large_input_dimension(engines, dtype, tol, kind, name, N, M, D):
+    """D > 32 (the reference's MNIST notebook has 784 inputs): distance by a library GEMM, tsvgp_gram_to_kernel_* in place."""
+    eng = engines[dtype]
+    B = pkg()._backend
+    rng = np.random.RandomState(6)
+    X, Z = rng.randn(N, D) / np.sqrt(D), rng.randn(M, D) / np.sqrt(D)
+    ls = 0.7 + rng.rand(D)
+    t = lambda a: torch.as_tensor(a, dtype=dtype, device="cuda:0").contiguous()
+    out = torch.full((B.round_up(N), B.round_up(M)), float("nan"), dtype=dtype, device="cuda:0")
+    eng.se_fill(t(X), t(Z), t(1.0 / ls), 1.3, out, kind)
+    K = out.double().cpu().numpy()
+    ref = getattr(O, name)(variance=1.3, lengthscales=ls).K(X, Z)
+    assert relerr(K[:N, :M], ref) < (tol * 10 if dtype == torch.float64 else 2e-4)
+    assert np.all(K[N:, :] == 0) and np.all(K[:, M:] == 0)

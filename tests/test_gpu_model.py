@@ -611,3 +611,19 @@ def test_p8_separate_kernels_match_oracle(batched):
     mu_h, var_h = hip.predict_f(X[:200] + 0.05)
     mu_o, var_o = ora.predict_f(X[:200] + 0.05)
     assert relerr(mu_h.cpu().numpy(), mu_o) < 1e-8 and relerr(var_h.cpu().numpy(), var_o) < 1e-8
+
+
+def test_large_input_dimension_matches_oracle():
+    """D = 48 inputs (beyond the fused fill kernel's 32): E-steps, ELBO and predictions against the oracle."""
+    X, Y, Z = synthetic(N=600, M=40, D=48, P=1, lik="bernoulli", seed=14)
+    X, Z = X / np.sqrt(48.0), Z / np.sqrt(48.0)
+    hip, ora = make_pair(Z, lik="bernoulli", lengthscales=0.8)
+    for _ in range(3):
+        hip.natgrad_step((X, Y), lr=0.8)
+        ora.natgrad_step((X, Y), lr=0.8)
+        _compare_state(hip, ora, 1e-8)
+    e_h, e_o = float(hip.elbo((X, Y))), float(ora.elbo((X, Y)))
+    assert abs(e_h - e_o) / abs(e_o) < 1e-9
+    mu_h, var_h = hip.predict_f(X[:100] + 0.01)
+    mu_o, var_o = ora.predict_f(X[:100] + 0.01)
+    assert relerr(mu_h.cpu().numpy(), mu_o) < 1e-8 and relerr(var_h.cpu().numpy(), var_o) < 1e-8

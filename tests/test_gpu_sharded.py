@@ -93,3 +93,39 @@ def test_empty_shard_contributes_zeros(tmp_path):
     m = p.t_SVGP(p.SquaredExponential(1.0, 1.0), p.Gaussian(0.1), Z, device="cuda:0")
     with pytest.raises(ValueError):
         m.natgrad_step((X[:0], Y[:0]), lr=0.8)
+
+
+def _worker_graph(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        p = pkg()
+        X, Y, Z = synthetic(N=3001, M=64, D=4, lik="bernoulli", seed=10)
+        Xs, Ys = p.distributed.shard_rows(X, Y)
+        m = p.t_SVGP(p.SquaredExponential(1.0, 1.0), p.Bernoulli(), Z, num_data=3001, device="cuda:0", use_graph=True)
+        Xd, Yd = torch.as_tensor(Xs, device="cuda:0"), torch.as_tensor(Ys, device="cuda:0")
+        for _ in range(5):  # eager, capture + replay, three more replays
+            m.natgrad_step((Xd, Yd), lr=0.8)
+        captured = any(isinstance(e, dict) and "tail" in e for e in m._graphs.values())
+        e = float(m.elbo((Xd, Yd)))
+        if rank == 0:
+            np.savez(out, l1=m.lambda_1.numpy(), L2=m.lambda_2.cpu().numpy(), elbo=e, captured=captured)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_step_replayed_as_two_graphs_around_the_all_reduce(tmp_path):
+    """use_graph with more than one rank: the step is captured as two graphs (in front of and behind the all-reduce of
+    the packed accumulators) and replayed with the collective issued in between; results against the oracle."""
+    out = str(tmp_path / "r0.npz")
+    port = 25500 + (os.getpid() % 2000)
+    mp.spawn(_worker_graph, args=(2, port, out), nprocs=2, join=True)
+    got = np.load(out)
+    assert bool(got["captured"])
+    X, Y, Z = synthetic(N=3001, M=64, D=4, lik="bernoulli", seed=10)
+    ora = O.t_SVGP(O.SquaredExponential(1.0, 1.0), O.Bernoulli(), Z, num_data=3001)
+    for _ in range(5):
+        ora.natgrad_step((X, Y), lr=0.8)
+    assert relerr(got["l1"], ora.lambda_1) < 1e-8
+    assert relerr(got["L2"], ora.lambda_2) < 1e-8
+    assert abs(float(got["elbo"]) - ora.elbo((X, Y))) < 1e-9 * abs(ora.elbo((X, Y)))
