@@ -354,7 +354,7 @@ def main():
     # there, so `value` above is the replayed rate; the other mode (eager) is reported beside it.  At the metric's
     # sizes "auto" runs eagerly and this block is skipped.
     graph_line = None
-    if world == 1 and args.model == "tsvgp" and w["N"] * w["M"] <= 10_000_000 and not w.get("separate"):
+    if world == 1 and args.model == "tsvgp" and w["N"] * w["M"] <= 200_000_000 and not w.get("separate"):
         auto_on = model._wants_graph(Xd)
         model.use_graph = not auto_on
         for _ in range(4):
