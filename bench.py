@@ -298,6 +298,8 @@ def main():
         conds = [float(c) for c in model._cond_cache[1]] if model._cond_cache is not None else None
     for _ in range(max(args.warmup, 3 if replayed else 0)):  # a graph is captured on the second occurrence of a step
         model.natgrad_step((Xd, Yd), lr=0.8)
+    if not replayed and hasattr(eng, "reserve_events"):
+        eng.reserve_events(2 * 8 * args.steps * max(1, w["P"] if w.get("separate") else 1) + 64)
     barrier()
     eng.profile = None if replayed else {}
     t0 = time.perf_counter()

@@ -88,24 +88,39 @@ class EStepEngine:
         return t
 
     def _launch(self, name, status_fn):
-        """Runs one C-ABI launch; with profiling on, brackets it with events on the stream it is launched on."""
+        """Runs one C-ABI launch; with profiling on, brackets it with events on the stream it is launched on (events
+        come from a pool: creating two per launch costs the host ~0.1 ms per step, which shows at small shards)."""
         if self.profile is None:
             B.check(status_fn(), name)
             return
-        e0 = torch.cuda.Event(enable_timing=True)
-        e1 = torch.cuda.Event(enable_timing=True)
+        e0, e1 = self._event(), self._event()
         e0.record(torch.cuda.current_stream(self.device))
         B.check(status_fn(), name)
         e1.record(torch.cuda.current_stream(self.device))
         self.profile.setdefault(name, []).append((e0, e1))
 
+    def _event(self):
+        pool = self.__dict__.setdefault("_event_pool", [])
+        return pool.pop() if pool else torch.cuda.Event(enable_timing=True)
+
+    def reserve_events(self, n: int):
+        """Pre-creates n timing events (bench.py: before the timed region)."""
+        pool = self.__dict__.setdefault("_event_pool", [])
+        while len(pool) < n:
+            pool.append(torch.cuda.Event(enable_timing=True))
+
     def profile_summary(self):
-        """{kernel: (launches, mean ms)} from the recorded events (synchronises)."""
+        """{kernel: (launches, mean ms)} from the recorded events (synchronises); the events go back to the pool."""
         torch.cuda.synchronize(self.device)
         out = {}
+        pool = self.__dict__.setdefault("_event_pool", [])
         for name, evs in (self.profile or {}).items():
             ms = [a.elapsed_time(b) for a, b in evs]
             out[name] = (len(ms), sum(ms) / max(len(ms), 1))
+            for a, b in evs:
+                pool += [a, b]
+        if self.profile is not None:
+            self.profile.clear()
         return out
 
     def release(self):
