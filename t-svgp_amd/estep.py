@@ -19,6 +19,7 @@ Kernel sequence of ``run(..., sites=True)`` by projection route (models/tsvgp.py
 from __future__ import annotations
 
 import ctypes
+import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -101,6 +102,8 @@ class EStepEngine:
 
     def _event(self):
         pool = self.__dict__.setdefault("_event_pool", [])
+        if os.environ.get("TSVGP_NO_EVENT_POOL"):
+            return torch.cuda.Event(enable_timing=True)
         return pool.pop() if pool else torch.cuda.Event(enable_timing=True)
 
     def reserve_events(self, n: int):
