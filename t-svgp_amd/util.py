@@ -13,8 +13,9 @@ import torch
 
 def bmv(A: torch.Tensor, v: torch.Tensor, transpose: bool = False) -> torch.Tensor:
     """Per-latent matrix-vector products: out[:, p] = A_p v[:, p] (A_p^T v[:, p] with ``transpose``), A [M, M] (shared by
-    all latents) or [P, M, M], v [M, P] -> [M, P].  Goes through gemv (``torch.mv``) for few latents: einsum / matmul hand
-    a one-column right-hand side to a GEMM kernel that takes 30-60 us at M = 1024 where gemv takes ~8."""
+    all latents) or [P, M, M], v [M, P] -> [M, P].  Few latents go through gemv (``torch.mv``) for A v -- einsum / matmul hand
+    a one-column right-hand side to a GEMM kernel that takes 30-60 us at M = 1024 where gemv takes ~8 -- and through a
+    broadcast multiply + column sum for A^T v (rocBLAS's non-transposed gemv on a row-major matrix takes 50 us)."""
     P = v.shape[1]
     if A.dim() == 2 and P > 4:
         return (A.transpose(-1, -2) if transpose else A) @ v
@@ -22,7 +23,7 @@ def bmv(A: torch.Tensor, v: torch.Tensor, transpose: bool = False) -> torch.Tens
         cols = []
         for p in range(P):
             Ap = A if A.dim() == 2 else A[p]
-            cols.append(torch.mv(Ap.transpose(-1, -2) if transpose else Ap, v[:, p]))
+            cols.append((Ap * v[:, p, None]).sum(dim=0) if transpose else torch.mv(Ap, v[:, p]))
         return torch.stack(cols, dim=1)
     return torch.einsum("pkm,kp->mp" if transpose else "pmk,kp->mp", A, v)
 
