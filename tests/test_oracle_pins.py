@@ -388,3 +388,23 @@ def test_white_extra_data_conditioning_pin():
         m2, v2 = O.sgpr_predict_f(k1, Xc, Yc, Z, 0.3, X)
         np.testing.assert_array_almost_equal(m_, m2, decimal=4)
         np.testing.assert_array_almost_equal(v_, v2, decimal=4)
+
+
+def test_row_blocked_evaluators_equal_the_single_call_forms():
+    """oracle.elbo_chunked / predict_f_chunked (what bench.py's `elbo_match` evaluates at N = 1e6) give the numbers of
+    base_SVGP.elbo / predict_f (src/models/tsvgp.py:79-114) for any block size, Gaussian and Bernoulli, P = 2."""
+    rng = np.random.RandomState(5)
+    N, M, D, P = 900, 24, 3, 2
+    X = rng.randn(N, D)
+    F = np.sin(X @ rng.randn(D, P))
+    Z = X[:M].copy()
+    for lik, Y in ((O.Gaussian(0.1), F + 0.3 * rng.randn(N, P)), (O.Bernoulli(), (F + 0.3 * rng.randn(N, P) > 0).astype(float))):
+        m = O.t_SVGP(O.SquaredExponential(1.2, 0.9), lik, Z, num_latent_gps=P, num_data=4 * N)
+        for _ in range(3):
+            m.natgrad_step((X, Y), lr=0.7)
+        e = m.elbo((X, Y))
+        for chunk in (N, 250, 77):
+            assert abs(O.elbo_chunked(m, (X, Y), chunk_rows=chunk) - e) < 1e-12 * abs(e)
+        mu, var = m.predict_f(X[:300])
+        mu_c, var_c = O.predict_f_chunked(m, X[:300], chunk_rows=64)
+        assert np.max(np.abs(mu - mu_c)) < 1e-13 and np.max(np.abs(var - var_c)) < 1e-13
