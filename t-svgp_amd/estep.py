@@ -73,6 +73,7 @@ class EStepEngine:
         self.last_batched = False  # the last pass over separate kernels ran as batched launches
         self.last_trmm_batch = 1  # latents per whitening launch of that pass
         self.profile = None  # set to a dict to record (start, stop) HIP events per kernel launch on the launch stream
+        self.profile_only = None  # a set of kernel names: bracket only these launches
 
     # ------------------------------------------------------------------ helpers
     def _stream(self):
@@ -91,7 +92,7 @@ class EStepEngine:
     def _launch(self, name, status_fn):
         """Runs one C-ABI launch; with profiling on, brackets it with events on the stream it is launched on (events
         come from a pool: creating two per launch costs the host ~0.1 ms per step, which shows at small shards)."""
-        if self.profile is None:
+        if self.profile is None or (self.profile_only is not None and name not in self.profile_only):
             B.check(status_fn(), name)
             return
         e0, e1 = self._event(), self._event()

@@ -93,6 +93,23 @@ class base_SVGP(abc.ABC):
     def _reduce(self) -> bool:
         return D_.world_size() > 1 if self.data_parallel is None else bool(self.data_parallel)
 
+    def _read_flags(self, flags: torch.Tensor) -> torch.Tensor:
+        """The step's one device->host read.  On the GPU: an asynchronous copy into pinned memory and a POLLED event
+        instead of a blocking ``.cpu()`` -- the runtime's blocking wait sleeps on an interrupt, and its wake-up after a
+        30 ms step was measured at 0.1 to 3 ms from run to run (11.5 vs 13.7 ms per step at N = 1e6, M = 512 with
+        identical kernel times; the stall vanished under the profiler).  One host core spins for the length of a step."""
+        if not flags.is_cuda:
+            return flags
+        host = getattr(self, "_flags_host", None)
+        if host is None or host.numel() != flags.numel():
+            host = self._flags_host = torch.empty(flags.numel(), dtype=flags.dtype).pin_memory()
+        host.copy_(flags, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(flags.device))
+        while not ev.query():
+            pass
+        return host.clone()
+
     @abc.abstractmethod
     def get_mean_chol_cov_inducing_posterior(self):
         """Returns the mean and cholesky factor of the covariance matrix of q(u)"""
@@ -428,7 +445,7 @@ class t_SVGP(base_SVGP):
 
     def _check_step(self, ops, nonpos, extra_infos=(), soft_final=False):
         """ONE device->host read per call: Cholesky statuses and the count of non-positive variances."""
-        return self._judge(self._status_flags(ops, nonpos, extra_infos).cpu(), soft_final)
+        return self._judge(self._read_flags(self._status_flags(ops, nonpos, extra_infos)), soft_final)
 
     def get_mean_chol_cov_inducing_posterior(self):
         """Mean and Cholesky factor of q(u) = N(u; m, S) (tsvgp.py:202-212)."""
@@ -631,7 +648,7 @@ class t_SVGP(base_SVGP):
             soft = any(r != "projected" for r in routes)
             try:
                 flags = self._step_device(X, Y, lr, jitter, routes)
-                verdict = self._judge(flags.cpu(), soft_final=soft)
+                verdict = self._judge(self._read_flags(flags), soft_final=soft)
             except FloatingPointError:
                 self.lambda_1.assign(old_l1)  # the reference raises before its assigns: leave the state untouched
                 self.sites.assign_lambda_2_sqrt(old_L)
@@ -768,7 +785,7 @@ class t_SVGP(base_SVGP):
             D_.all_reduce_sum(entry["packed"])
             entry["tail"].replay()
         try:
-            ok = self._judge(entry["flags"].cpu(), soft_final=any(r != "projected" for r in routes)) is True
+            ok = self._judge(self._read_flags(entry["flags"]), soft_final=any(r != "projected" for r in routes)) is True
         except FloatingPointError:
             ok = False
         if not ok:  # put the pre-step state back; the eager path then raises or falls back as it always does

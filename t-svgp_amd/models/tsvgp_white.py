@@ -154,7 +154,7 @@ class t_SVGP_white(base_SVGP):
         parts = [info_sum(ops["infos"]), nonpos.reshape(1).to(torch.float64)]
         if ops.get("direct_info"):
             parts.append(info_sum(ops["direct_info"]))
-        flags = torch.cat(parts).cpu()
+        flags = self._read_flags(torch.cat(parts))
         if float(flags[0]) != 0:
             raise FloatingPointError("Cholesky decomposition was not successful (matrix not positive definite)")
         if len(flags) > 2 and float(flags[2]) != 0:  # Q lost definiteness in M x M: not the reference's failure
