@@ -103,8 +103,6 @@ class EStepEngine:
 
     def _event(self):
         pool = self.__dict__.setdefault("_event_pool", [])
-        if os.environ.get("TSVGP_NO_EVENT_POOL"):
-            return torch.cuda.Event(enable_timing=True)
         return pool.pop() if pool else torch.cuda.Event(enable_timing=True)
 
     def reserve_events(self, n: int):
