@@ -19,7 +19,6 @@ Kernel sequence of ``run(..., sites=True)`` by projection route (models/tsvgp.py
 from __future__ import annotations
 
 import ctypes
-import os
 from dataclasses import dataclass
 from typing import Optional
 
