@@ -281,6 +281,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
+    import gc
+
+    class timed_region:
+        """The cyclic garbage collector is paused inside a timed loop (as ``timeit`` does): a full collection of this
+        process (torch, numpy and scipy loaded: ~1e6 tracked objects) takes 30-40 ms and, when one happened to fall into
+        the 20-30 steps of a timed region, showed as +1.2 ms per step (measured: one 39 ms `_site_operands` call in 30,
+        38.5 instead of 37.0 ms per step at N = 1e6, 12.6 instead of 11.3 ms at M = 512, kernel times unchanged)."""
+
+        def __enter__(self):
+            gc.collect()
+            gc.disable()
+
+        def __exit__(self, *exc):
+            gc.enable()
+
     # Per-kernel HIP events are recorded in the timed region, except where the model's default replays the step from a
     # captured hipGraph (launch-bound sizes, configs[0]): events inside a replay would force the eager path.
     replayed = args.model == "tsvgp" and world == 1 and model._wants_graph(Xd) and not w.get("separate")
@@ -301,34 +316,18 @@ def main():
     if not replayed and hasattr(eng, "reserve_events"):
         eng.reserve_events(2 * 8 * args.steps * max(1, w["P"] if w.get("separate") else 1) + 64)
     barrier()
-    # Inside the timed region only the MFMA kernels (the ones `roofline` is about) are bracketed with HIP events on their
-    # launch stream.  Timing events around the launches of the overlapped section -- the K(X, Z) fill on the side stream,
-    # the factorisations beside it -- serialise the two queues on some boxes: +1.2 ms per step at N = 1e6 and +1.7 ms at
-    # M = 512, identical kernel times (A/B on one box: 37.00 ms with events around the two MFMA kernels or none at all,
-    # 38.2 ms with events around the fill or the factorisations as well).  The other kernels' times come from a short
-    # instrumented pass AFTER the timed region (`kernels[...]["from"]`).
-    MFMA_KERNELS = {"tsvgp_moments", "tsvgp_site_accum", "tsvgp_trmm"}
-    eng.profile_only = MFMA_KERNELS
+    # Every C-ABI launch inside the timed region is bracketed with HIP events on its launch stream (pooled: no event is
+    # created inside the region); they cost 0.05-0.1 ms per step (A/B with the collector paused: 11.38 vs 11.44 ms at
+    # M = 512, 37.14 vs 37.14-37.4 ms at the headline size).
     eng.profile = None if replayed else {}
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        model.natgrad_step((Xd, Yd), lr=0.8)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    prof = {} if replayed else eng.profile_summary()
-    eng.profile, eng.profile_only = None, None
-    prof_src = {k: "timed region" for k in prof}
-    if not replayed:  # instrumented pass: every launch bracketed, outside `value`
-        n_inst = max(2, min(5, args.steps))
-        eng.profile = {}
-        for _ in range(n_inst):
+    with timed_region():
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
             model.natgrad_step((Xd, Yd), lr=0.8)
         barrier()
-        for k, v in eng.profile_summary().items():
-            if k not in prof:
-                prof[k] = (v[0] * args.steps / n_inst, v[1])  # launches scaled to the timed region's step count
-                prof_src[k] = f"instrumented pass of {n_inst} steps after the timed region"
-        eng.profile = None
+        elapsed = time.perf_counter() - t0
+    prof = {} if replayed else eng.profile_summary()
+    eng.profile = None
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:
@@ -341,11 +340,12 @@ def main():
         for _ in range(n_warm):
             model.natgrad_step((Xd, Yd), lr=0.8)
         barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            model.natgrad_step((Xd, Yd), lr=0.8)
-        barrier()
-        tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+        with timed_region():
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                model.natgrad_step((Xd, Yd), lr=0.8)
+            barrier()
+            tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
         if world > 1:
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         return float(tt)
@@ -382,11 +382,12 @@ def main():
         for _ in range(4):
             model.natgrad_step((Xd, Yd), lr=0.8)
         barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            model.natgrad_step((Xd, Yd), lr=0.8)
-        barrier()
-        tg = time.perf_counter() - t0
+        with timed_region():
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                model.natgrad_step((Xd, Yd), lr=0.8)
+            barrier()
+            tg = time.perf_counter() - t0
         model.use_graph = "auto"
         graph_line = {"mode": "eager (use_graph=False)" if auto_on else "hipGraph replay (use_graph=True)",
                       "headline_mode": "hipGraph replay" if auto_on else "eager",
@@ -404,14 +405,15 @@ def main():
         for _ in range(2):
             model.natgrad_step((Xd, Yd), lr=0.8)
         barrier()
-        eng.profile, eng.profile_only = {}, MFMA_KERNELS
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            model.natgrad_step((Xd, Yd), lr=0.8)
-        barrier()
-        ts = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+        eng.profile = {}
+        with timed_region():
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                model.natgrad_step((Xd, Yd), lr=0.8)
+            barrier()
+            ts = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
         skip_prof = eng.profile_summary()
-        eng.profile, eng.profile_only = None, None
+        eng.profile = None
         if world > 1:
             dist.all_reduce(ts, op=dist.ReduceOp.MAX)
         model.skip_unused_variance = False
@@ -445,7 +447,7 @@ def main():
                         "algorithmic_flops_per_launch": flops[dom], "avg_launch_ms": round(mfma[dom], 4)}
         kernels = {}
         for k, (n, ms) in sorted(prof.items()):
-            e = {"launches_per_step": n / args.steps, "avg_ms": round(ms, 4), "from": prof_src.get(k, "timed region")}
+            e = {"launches_per_step": n / args.steps, "avg_ms": round(ms, 4)}
             if k in flops:
                 e["tflops"] = round(flops[k] / (ms * 1e-3) / 1e12, 2)
             if k in byts:
@@ -475,8 +477,8 @@ def main():
             "roofline": roofline,
             "kernels": kernels,
             "kernel_ms_per_step": round(sum(v[0] * v[1] for v in prof.values()) / args.steps, 4),
-            "kernel_timing": "HIP events on the launch stream: the MFMA kernels inside the timed region, the others in an "
-                             "instrumented pass after it (events around the overlapped fill / factorisations perturb the step)",
+            "kernel_timing": "HIP events around every C-ABI launch, on its launch stream, inside the timed region; the cyclic "
+                             "garbage collector is paused inside timed loops (as timeit does)",
         }
         if world == 1 and not args.no_elbo_match and args.model == "tsvgp":
             out["elbo_match"] = elbo_match(model, w, X, Y, Z, args.elbo_budget)

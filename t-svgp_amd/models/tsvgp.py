@@ -95,9 +95,8 @@ class base_SVGP(abc.ABC):
 
     def _read_flags(self, flags: torch.Tensor) -> torch.Tensor:
         """The step's one device->host read.  On the GPU: an asynchronous copy into pinned memory and a POLLED event
-        instead of a blocking ``.cpu()`` -- the runtime's blocking wait sleeps on an interrupt, and its wake-up after a
-        30 ms step was measured at 0.1 to 3 ms from run to run (11.5 vs 13.7 ms per step at N = 1e6, M = 512 with
-        identical kernel times; the stall vanished under the profiler).  One host core spins for the length of a step."""
+        instead of a blocking ``.cpu()``: the wait never sleeps on an interrupt, so the host is back the moment the last
+        kernel of the step retires.  One host core spins for the length of a step."""
         if not flags.is_cuda:
             return flags
         host = getattr(self, "_flags_host", None)
@@ -670,7 +669,9 @@ class t_SVGP(base_SVGP):
         statistics, prelude operands).  No host synchronisation."""
         warm_key = self._warm_key(X, jitter)
         eng = self._get_engine()
-        # K(X, Z) depends on neither lambda nor the M x M factors: its fill runs on a side stream beside the prelude
+        # K(X, Z) depends on neither lambda nor the M x M factors: its fill runs on a side stream beside the prelude.
+        # (Starting it only behind the two GEMMs that assemble W -- they take 147 us each under the fill instead of 60 --
+        # measured 0.1-0.2 ms SLOWER per step: the fill then ends later than the prelude.)
         pre = None
         if self.overlap_fill and hasattr(eng, "start_fill"):
             pre = eng.start_fill(X, self._Z(), self.kernel, b_tag=warm_key,
