@@ -268,28 +268,72 @@ __device__ __forceinline__ void lik_eval(int lik_flags, double s2, double m, dou
 constexpr int FILL_ROWS = 64;
 constexpr int FILL_COLS = 512;
 
+// exp(a) for a <= 0 (every kernel profile below).  fp64: the device library's algorithm restated -- k = rint(a log2 e),
+// r = a - k ln2 (two-term), degree-11 polynomial, ldexp; same constants, same operation order, bit-identical values
+// -- minus what a <= 0 does not need and with the coefficients as FMA addends: 22 VALU instructions instead of the 33
+// the library call compiles to (9 of them register copies in front of v_fmac, 5 for the overflow / underflow selects).
+// The K(X, Z) fill is VALU-issue bound (108 fp64-rate instructions per row pair, 1.66 ms of arithmetic against 1.35 ms
+// of stores at N = 1e6, M = 1024), so this is 24 % of its arithmetic.  Below -1080 the result is 0 as in the library
+// (ldexp underflows); NaN stays NaN.
+template <typename T>
+__device__ __forceinline__ T exp_nonpos(T a) {
+    return exp(a);
+}
+template <>
+__device__ __forceinline__ double exp_nonpos<double>(double a) {
+    constexpr auto C = [](unsigned long long bits) { return __builtin_bit_cast(double, bits); };
+    a = (a < -1080.0) ? -1080.0 : a;
+    const double k = __builtin_rint(a * C(0x3ff71547652b82feULL));
+    double r = fma(C(0xbfe62e42fefa39efULL), k, a);
+    r = fma(C(0xbc7abc9e3b39803fULL), k, r);
+    // q <- r q + c with c in a scalar register pair (VOP3 takes one scalar operand): left to itself the compiler keeps the
+    // coefficients in VGPRs and copies each one in front of a destructive v_fmac
+    auto horner = [](double r_, double q_, double c) {
+        double d;
+        asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(r_), "v"(q_), "s"(c));
+        return d;
+    };
+    double q = horner(r, C(0x3e5ade156a5dcb37ULL), C(0x3e928af3fca7ab0cULL));
+    q = horner(r, q, C(0x3ec71dee623fde64ULL));
+    q = horner(r, q, C(0x3efa01997c89e6b0ULL));
+    q = horner(r, q, C(0x3f2a01a014761f6eULL));
+    q = horner(r, q, C(0x3f56c16c1852b7b0ULL));
+    q = horner(r, q, C(0x3f81111111122322ULL));
+    q = horner(r, q, C(0x3fa55555555502a1ULL));
+    q = horner(r, q, C(0x3fc5555555555511ULL));
+    q = horner(r, q, C(0x3fe000000000000bULL));
+    q = fma(r, q, 1.0);
+    q = fma(r, q, 1.0);
+    return ldexp(q, (int)k);
+}
+
 // stationary kernel profile k(s) as a function of the scaled squared distance s = sum_d ((x_d - z_d) / l_d)^2
 // (GPflow [ext]: Matern kernels take r = sqrt(max(s, 1e-36)))
 template <int KIND, typename T>
 __device__ __forceinline__ T kernel_profile(T s) {
     if constexpr (KIND == TSVGP_KERNEL_SE) {
-        return exp(T(-0.5) * s);
+        return exp_nonpos(T(-0.5) * s);
     } else {
         const T r = sqrt(s > T(1e-36) ? s : T(1e-36));
         if constexpr (KIND == TSVGP_KERNEL_MATERN32) {
             const T a = T(1.7320508075688772935) * r;
-            return (T(1) + a) * exp(-a);
+            return (T(1) + a) * exp_nonpos(-a);
         } else {
             const T a = T(2.2360679774997896964) * r;
-            return (T(1) + a + T(5.0 / 3.0) * r * r) * exp(-a);
+            return (T(1) + a + T(5.0 / 3.0) * r * r) * exp_nonpos(-a);
         }
     }
 }
 
 // DT = D padded to a compile-time size (padded dimensions are zeros on both sides).  The thread's two Z columns live in
-// registers and only the X rows go through LDS (FILL_ROWS * DT elements), the distance loop is fully unrolled:
-// 2.31 ms at N = 1e6, M = 1024, D = 8 against 2.51 ms with the Z tile in LDS (tools/exp_fill.py).  The occupancy cap
-// costs nothing (2.31 / 2.33 / 2.35 ms at 3 / 4 / 8 waves per SIMD): the kernel is bound by its stores and its VALU work.
+// registers and only the X rows go through LDS (FILL_ROWS * DT elements, wave-uniform 16-byte reads), the distance loop
+// is fully unrolled and the two columns' dependent chains are interleaved.  At N = 1e6, M = 1024, D = 8 (fp64) the
+// kernel is bound by VALU issue, not by its stores: 81 fp64-rate instructions per row pair (32 distance, 2 x 23
+// exp / scale, 3 loop) = 1.26 ms with the store disabled (-DTSVGP_EXP_NOSTORE), the same 8.2 GB written by a
+// store-only kernel of this access pattern 1.35 ms (6.1 TB/s, tools/store_pattern.hip), together 1.86 ms -- was
+// 2.23 ms with the library exp (108 instructions, 1.66 ms of arithmetic), per-row 64-bit VALU index compares and
+// exec-masked column branches.  The occupancy cap costs nothing (3 / 4 / 8 waves per SIMD within 2 %), the order in
+// which row blocks and column tiles are dealt to workgroups neither (2.18 vs 2.18 ms), non-temporal stores 3 %.
 #ifndef TSVGP_FILL_MAXWAVES
 #define TSVGP_FILL_MAXWAVES 3
 #endif
@@ -311,8 +355,11 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, TSV
     inv_ls += (size_t)blockIdx.z * D;
     K += (size_t)blockIdx.z * strideK;
     const int t = threadIdx.x;
-    const int m = blockIdx.y * FILL_COLS + 2 * t;  // this thread's column pair
+    const int ctile = blockIdx.y;
+    const int64_t rb_first = blockIdx.x, rb_step = gridDim.x;
+    const int m = ctile * FILL_COLS + 2 * t;  // this thread's column pair
     const bool v0 = (m < M), v1 = (m + 1 < M), active = (m < cols_pad);
+    const T var0 = v0 ? variance : T(0), var1 = v1 ? variance : T(0);
     T z0[DT], z1[DT];
 #pragma unroll
     for (int d = 0; d < DT; ++d) {
@@ -323,7 +370,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, TSV
     // Row blocks are dealt round-robin to the workgroups of a column tile.  The default grid has one workgroup per
     // row block; a smaller grid (tsvgp_kernel_fill's cap) leaves CU slots free for work on another stream.
     const int64_t nrb = (rows_pad + FILL_ROWS - 1) / FILL_ROWS;
-    for (int64_t rb = blockIdx.x; rb < nrb; rb += gridDim.x) {
+    for (int64_t rb = rb_first; rb < nrb; rb += rb_step) {
         const int64_t n0 = rb * FILL_ROWS;
         for (int idx = t; idx < FILL_ROWS * DT; idx += NTHREADS) {
             const int rr = idx / DT, d = idx - rr * DT;
@@ -332,10 +379,14 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, TSV
         }
         __syncthreads();
         if (active) {
+            // row counts of this block as wave-uniform ints: valid rows get kernel values, the padding rows up to
+            // rows_pad zeros.  Invalid columns of the last pair come out as exact zeros through their variance factor.
+            const int64_t left = N - n0, left_pad = rows_pad - n0;
+            const int nvalid = left >= FILL_ROWS ? FILL_ROWS : (left > 0 ? (int)left : 0);
+            const int nrows = left_pad >= FILL_ROWS ? FILL_ROWS : (int)left_pad;
+            T* const Kp = K + n0 * ldk + m;
 #pragma unroll 2
-            for (int rr = 0; rr < FILL_ROWS; ++rr) {
-                const int64_t n = n0 + rr;
-                if (n >= rows_pad) break;
+            for (int rr = 0; rr < nvalid; ++rr) {
                 T s0 = T(0), s1 = T(0);
 #pragma unroll
                 for (int d = 0; d < DT; ++d) {
@@ -345,22 +396,24 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, TSV
                     s1 += d1 * d1;
                 }
                 pair_t out;
-                const bool rowok = (n < N);
 #ifdef TSVGP_EXP_NOEXP  // ablation switch (tools/exp_fill.py): the store-bound floor of the kernel
-                out[0] = (rowok && v0) ? variance * (T(1) - T(0.5) * s0) : T(0);
-                out[1] = (rowok && v1) ? variance * (T(1) - T(0.5) * s1) : T(0);
+                out[0] = var0 * (T(1) - T(0.5) * s0);
+                out[1] = var1 * (T(1) - T(0.5) * s1);
 #else
-                out[0] = (rowok && v0) ? variance * kernel_profile<KIND>(s0) : T(0);
-                out[1] = (rowok && v1) ? variance * kernel_profile<KIND>(s1) : T(0);
+                out[0] = var0 * kernel_profile<KIND>(s0);
+                out[1] = var1 * kernel_profile<KIND>(s1);
 #endif
-#ifdef TSVGP_FILL_NT  // experiment: streaming (non-temporal) stores
-                __builtin_nontemporal_store(out, reinterpret_cast<pair_t*>(K + n * ldk + m));
+#ifdef TSVGP_EXP_NOSTORE  // ablation switch: the arithmetic alone (the store never executes, the compiler cannot know)
+                if (out[0] == T(-1)) *reinterpret_cast<pair_t*>(Kp + (int64_t)rr * ldk) = out;
+#elif defined(TSVGP_FILL_NT)  // experiment: streaming (non-temporal) stores
+                __builtin_nontemporal_store(out, reinterpret_cast<pair_t*>(Kp + (int64_t)rr * ldk));
 #else
-                *reinterpret_cast<pair_t*>(K + n * ldk + m) = out;
+                *reinterpret_cast<pair_t*>(Kp + (int64_t)rr * ldk) = out;
 #endif
             }
+            for (int rr = nvalid; rr < nrows; ++rr) *reinterpret_cast<pair_t*>(Kp + (int64_t)rr * ldk) = pair_t{T(0), T(0)};
         }
-        if (rb + gridDim.x < nrb) __syncthreads();  // Xs is rewritten by the next row block
+        if (rb + rb_step < nrb) __syncthreads();  // Xs is rewritten by the next row block
     }
 }
 
@@ -1193,13 +1246,14 @@ constexpr int CH_WT = 32;          // wave tile of the panel / update / inverse-
 constexpr int CH_LD = CH_NB + 1;   // odd LDS row stride: one-lane-per-row column sweeps touch 32 different banks
 constexpr int CH_THREADS = 512;    // 8 waves
 
-// 1/sqrt(x) to fp64 accuracy: hardware estimate (v_rsq_f64) + two Newton-Raphson steps; NaN for x <= 0 like sqrt.
+// 1/sqrt(x) to fp64 accuracy: hardware estimate (v_rsq_f64, 2^-24 measured) + ONE third-order step
+//   e = 1 - x y^2,  y <- y + y e (1/2 + 3/8 e):  max rel err 1.4e-16 over 2^20 arguments (tools/rsq_probe.hip), four
+// dependent fp64 ops instead of the six of two Newton steps (2.4e-16).  x <= 0 gives NaN without a select: v_rsq_f64
+// returns NaN for x < 0 and +inf for x = 0, and inf * 0 in the residual is NaN.
 __device__ __forceinline__ double rsqrt_nr(double x) {
-    double y = __builtin_amdgcn_rsq(x);
-    double h = 0.5 * x;
-    y = y * fma(-h * y, y, 1.5);
-    y = y * fma(-h * y, y, 1.5);
-    return (x > 0.0) ? y : __builtin_nan("");
+    const double y = __builtin_amdgcn_rsq(x);
+    const double e = fma(-x * y, y, 1.0);
+    return fma(y * e, fma(e, 0.375, 0.5), y);
 }
 
 // value of `v` in lane `src` (compile-time lane), as a wave-uniform double
@@ -1209,19 +1263,47 @@ __device__ __forceinline__ double readlane_d(double v, int src) {
     return __hiloint2double(hi, lo);
 }
 
-// One wave factors the 32x32 diagonal sub-block at (s0, s0) of S in registers: lane r (mod 32) owns row r.  Four
-// columns per step: the 4x4 pivot block is broadcast with v_readlane and factored redundantly by every lane
-// (reciprocal square roots by v_rsq_f64 + two Newton steps: no f64 divide / sqrt sequences on the critical path),
-// each lane solves its own row against it, and the rank-4 update of the remaining columns takes its second factor
-// from a small LDS scratch (wave-uniform reads).  No workgroup barriers inside.
-__device__ __forceinline__ void chol_factor_sb(double* __restrict__ S, double* __restrict__ dinv, double* __restrict__ xs,
-                                              int s0, int lane, int* fail, int col_base) {
-    const int r = lane & (CH_SB - 1);
-    double* const row = S + (s0 + r) * CH_LD + s0;
-    double a[CH_SB];
+// One pass over the block column of the 16-wide sub-block at (s0, s0) of S, one lane per row, the rows in registers.
+// Lanes 0..15 of EVERY participating wave hold the sub-block's own rows (factored redundantly per wave, so that no wave
+// waits for another); lanes 16..63 of wave w hold 48 further rows: the rows below the sub-block and, behind them, the
+// 16 rows of the identity.  Four columns per step: the 4x4 pivot block is broadcast with v_readlane and factored
+// redundantly by every lane (reciprocal square roots by v_rsq_f64 + two Newton steps: no f64 divide / sqrt sequences on
+// the critical path), each lane solves its own row against it, and the rank-4 update of the remaining columns takes
+// its second factor from a small per-wave LDS scratch (wave-uniform reads).  For a row below the sub-block that IS the
+// substitution x L_ss^T = a, and for row i of the identity it yields column i of inv(L_ss): the row solves and the
+// sub-block inverse cost no pass of their own.  No workgroup barriers inside.
+// Rows below the sub-block are written back here; the sub-block's rows and the inverse stay in `a` for
+// chol_store_sb, which the caller runs behind a barrier (the other waves load the unfactored sub-block).
+struct ChRole {
+    int sub, below, ident;  // ident: row of the identity held by this lane, -1 for none
+};
+__device__ __forceinline__ ChRole chol_factor_rows(double* __restrict__ S, double* __restrict__ dinv, double* __restrict__ xs,
+                                                   int s0, int lane, int w, int need_inverse, int* fail, int col_base,
+                                                   double (&a)[CH_SB]) {
+    const int nbelow = CH_NB - s0 - CH_SB;
+    const int idx = (64 - CH_SB) * w + lane - CH_SB;
+    ChRole role;
+    role.sub = lane < CH_SB;
+    role.below = !role.sub && idx < nbelow;
+    role.ident = (!role.sub && !role.below && need_inverse && idx < nbelow + CH_SB) ? idx - nbelow : -1;
+    double* const row = S + (role.sub ? s0 + lane : s0 + CH_SB + idx) * CH_LD + s0;
+    if (role.sub || role.below) {
 #pragma unroll
-    for (int c = 0; c < CH_SB; ++c) a[c] = row[c];
+        for (int c = 0; c < CH_SB; ++c) a[c] = row[c];
+    } else {
+#pragma unroll
+        for (int c = 0; c < CH_SB; ++c) a[c] = (c == role.ident) ? 1.0 : 0.0;
+    }
     int bad = 0;
+#ifdef TSVGP_DIAG_POTRF
+    extern __shared__ __attribute__((aligned(16))) unsigned char diag_raw[];
+    unsigned long long* fst = reinterpret_cast<unsigned long long*>(diag_raw + (size_t)CH_NB * CH_LD * sizeof(double));
+    int nf = 0;
+#define FSTAMP() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); if (w == 0 && (s0 == 0 || s0 == 80)) { unsigned long long tt = __builtin_amdgcn_s_memtime(); if (lane == 0) fst[(s0 == 0 ? 0 : 32) + nf] = tt; } ++nf; }
+#else
+#define FSTAMP()
+#endif
+    FSTAMP()
 #pragma unroll
     for (int j0 = 0; j0 < CH_SB; j0 += 4) {
         const double p00 = readlane_d(a[j0], j0), p10 = readlane_d(a[j0], j0 + 1), p20 = readlane_d(a[j0], j0 + 2),
@@ -1240,6 +1322,10 @@ __device__ __forceinline__ void chol_factor_sb(double* __restrict__ S, double* _
         const double l32 = (p32 - l30 * l20 - l31 * l21) * i2;
         const double d3 = p33 - l30 * l30 - l31 * l31 - l32 * l32;
         const double i3 = rsqrt_nr(d3);
+#ifdef TSVGP_DIAG_POTRF
+        { double q = i3; asm volatile("" : "+v"(q)); }
+        FSTAMP()
+#endif
         if (bad == 0) bad = !(p00 > 0.0) ? j0 + 1 : !(d1 > 0.0) ? j0 + 2 : !(d2 > 0.0) ? j0 + 3 : !(d3 > 0.0) ? j0 + 4 : 0;
         // own row against the pivot block; for the pivot rows this reproduces the factor's rows
         // (x_q = d_q * rsqrt(d_q) = sqrt(d_q) on the diagonal)
@@ -1251,86 +1337,72 @@ __device__ __forceinline__ void chol_factor_sb(double* __restrict__ S, double* _
         a[j0 + 1] = x1;
         a[j0 + 2] = x2;
         a[j0 + 3] = x3;
-        if (lane == 0) {
+#ifdef TSVGP_DIAG_POTRF
+        { double q = x3; asm volatile("" : "+v"(q)); }
+        FSTAMP()
+#endif
+        if (lane == 0 && w == 0) {
             dinv[s0 + j0] = i0;
             dinv[s0 + j0 + 1] = i1;
             dinv[s0 + j0 + 2] = i2;
             dinv[s0 + j0 + 3] = i3;
         }
         if (j0 + 4 < CH_SB) {
-            // the four new columns go through a 1 KB LDS scratch: row c's entries come back as one wave-uniform 32-byte
-            // read per column of the update (two LDS reads instead of eight v_readlane per column)
-            if (lane < CH_SB) *reinterpret_cast<v4d*>(xs + 4 * r) = v4d{x0, x1, x2, x3};
+            // the four new columns of the sub-block's rows go through a 512-byte LDS scratch (one per wave): row c's
+            // entries come back as one wave-uniform 32-byte read per column of the update (two LDS reads instead of
+            // eight v_readlane per column)
+            if (lane < CH_SB) *reinterpret_cast<v4d*>(xs + 4 * lane) = v4d{x0, x1, x2, x3};
             __builtin_amdgcn_wave_barrier();  // one wave, in-order LDS: the reads below see the writes
+            // the second factors are requested four columns at a time before the first FMA of the group (8 ds_read_b128
+            // in flight: one LDS latency per group, not one per column).  Not all of a step's at once: the kernel has to
+            // stay within 112 VGPRs, see potrf_diag_kernel.
 #pragma unroll
-            for (int c = j0 + 4; c < CH_SB; ++c) {
-                const v4d y = *reinterpret_cast<const v4d*>(xs + 4 * c);
-                double v = a[c];
-                v = fma(-x0, y[0], v);
-                v = fma(-x1, y[1], v);
-                v = fma(-x2, y[2], v);
-                v = fma(-x3, y[3], v);
-                // pin the update here: otherwise the optimiser sinks the FMAs towards the final stores and the operands
-                // of the whole step stay live
-                asm volatile("" : "+v"(v));
-                a[c] = v;
+            for (int c0 = j0 + 4; c0 < CH_SB; c0 += 4) {
+                v4d y[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) y[c] = *reinterpret_cast<const v4d*>(xs + 4 * (c0 + c));
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    double v = a[c0 + c];
+                    v = fma(-x0, y[c][0], v);
+                    v = fma(-x1, y[c][1], v);
+                    v = fma(-x2, y[c][2], v);
+                    v = fma(-x3, y[c][3], v);
+                    // pin the update here: otherwise the optimiser sinks the FMAs towards the final stores and the
+                    // operands of the whole step stay live
+                    asm volatile("" : "+v"(v));
+                    a[c0 + c] = v;
+                }
             }
             __builtin_amdgcn_wave_barrier();  // the next step's writes come after these reads
+            FSTAMP()
         }
     }
-    if (lane < CH_SB) {
+    FSTAMP()
+#undef FSTAMP
+    if (role.below) {
+#pragma unroll
+        for (int c = 0; c < CH_SB; ++c) row[c] = a[c];
+    }
+    if (lane == 0 && w == 0 && bad != 0 && *fail == 0) *fail = col_base + s0 + bad;  // first non-positive pivot, 1-based
+    return role;
+}
+
+// The sub-block's factor (wave 0) and the inverse of it: X[c][i] = a[c] of identity row i, parked transposed in the
+// unused strict upper triangle of the sub-block (S[s0 + i][s0 + c], c > i); the diagonal of the inverse is dinv.
+__device__ __forceinline__ void chol_store_sb(double* __restrict__ S, int s0, int lane, int w, const ChRole& role,
+                                              const double (&a)[CH_SB]) {
+    if (role.sub && w == 0) {
+        double* const row = S + (s0 + lane) * CH_LD + s0;
 #pragma unroll
         for (int c = 0; c < CH_SB; ++c)
-            if (c <= r) row[c] = a[c];
-    }
-    if (lane == 0 && bad != 0 && *fail == 0) *fail = col_base + s0 + bad;  // first non-positive pivot, 1-based
-}
-
-// Row `gr` (below the sub-block) against the finished L_ss: x = a L_ss^-T by forward substitution, one lane per row;
-// the entries of L_ss are wave-uniform LDS reads (broadcast).
-__device__ __forceinline__ void chol_subst_sb(double* __restrict__ S, const double* __restrict__ dinv, int s0, int gr) {
-    asm volatile("" : "+v"(gr));  // nothing derived from the lane id is hoisted out of the caller's sub-block loop
-    double* const row = S + gr * CH_LD + s0;
-    const double* const Ls = S + s0 * CH_LD + s0;
-    double a[CH_SB];
+            if (c <= lane) row[c] = a[c];
+    } else if (role.ident >= 0) {
+        double* const prow = S + (s0 + role.ident) * CH_LD + s0;
 #pragma unroll
-    for (int c = 0; c < CH_SB; ++c) a[c] = row[c];
-    // row c: x[c] = (a[c] - sum_{kk<c} x[kk] L[c][kk]) / L[c][c]; four partial sums keep the FMA chain short, and the
-    // entries of row c of L_ss are contiguous (wide wave-uniform LDS reads)
-#pragma unroll
-    for (int c = 0; c < CH_SB; ++c) {
-        double v[4] = {a[c], 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int kk = 0; kk < c; ++kk) v[kk & 3] = fma(-a[kk], Ls[c * CH_LD + kk], v[kk & 3]);
-        double x = ((v[0] + v[1]) + (v[2] + v[3])) * dinv[s0 + c];
-        asm volatile("" : "+v"(x));  // pins the row here (see chol_factor_sb): bounds the L_ss entries in flight
-        a[c] = x;
-    }
-#pragma unroll
-    for (int c = 0; c < CH_SB; ++c) row[c] = a[c];
-}
-
-// inv(L_ss) by columns: lane j (mod 32) solves L_ss x = e_j with wave-uniform reads of L_ss; X[r][j] is parked
-// transposed in the unused strict upper triangle of the sub-block (S[s0 + j][s0 + r], r > j); the diagonal is dinv.
-__device__ __forceinline__ void chol_inv_sb(double* __restrict__ S, const double* __restrict__ dinv, int s0, int lane) {
-    asm volatile("" : "+v"(lane));  // as in chol_subst_sb
-    const int j = lane & (CH_SB - 1);
-    const double* const Ls = S + s0 * CH_LD + s0;
-    double x[CH_SB];
-#pragma unroll
-    for (int r = 0; r < CH_SB; ++r) {
-        double v[4] = {(r == j) ? 1.0 : 0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int kk = 0; kk < r; ++kk) v[kk & 3] = fma(-Ls[r * CH_LD + kk], x[kk], v[kk & 3]);
-        double xr = ((v[0] + v[1]) + (v[2] + v[3])) * dinv[s0 + r];
-        asm volatile("" : "+v"(xr));
-        x[r] = xr;
-    }
-    if (lane < CH_SB) {
-        double* const prow = S + (s0 + j) * CH_LD + s0;
-#pragma unroll
-        for (int r = 1; r < CH_SB; ++r)
-            if (r > j) prow[r] = x[r];
+        for (int c = 1; c < CH_SB; ++c)
+            if (c > role.ident) prow[c] = a[c];
     }
 }
 
@@ -1377,24 +1449,29 @@ __device__ __forceinline__ void chol_inv_offdiag(double* __restrict__ S, const d
             S[(l0 + 16 * J + li) * CH_LD + h0 + 16 * I + lk + 4 * r] = O[I][r];
 }
 
-// Diagonal block: right-looking over four 32-wide sub-blocks, everything in LDS / registers:
-//   (1) wave 0 factors the 32x32 diagonal sub-block in registers (chol_factor_sb);
-//   (2) the rows below solve against it, one lane per row (chol_subst_sb); wave 7 meanwhile inverts L_ss (chol_inv_sb);
-//   (3) the trailing part of the block is updated with 16x16 MFMA tiles, A_ij -= L_is L_js^T, by all waves.
-// Then L_kk is written out and inv(L_kk) is assembled from the four sub-block inverses by two levels of the 2x2
+// Diagonal block: right-looking over eight 16-wide sub-blocks, everything in LDS / registers.  Round s:
+//   (1) waves 0..2 factor the 16x16 diagonal sub-block in registers and, in the same pass, solve the rows below against
+//       it and invert it (chol_factor_rows: 64 rows per wave, the sub-block redundantly in each); the other waves
+//       meanwhile apply the PREVIOUS phase's update, A_ij -= L_is L_js^T in 16x16 MFMA tiles, to the block columns
+//       beyond this one;
+//   (2) all waves apply this phase's update to the next block column only (one tile each).
+// Then L_kk is written out and inv(L_kk) is assembled from the sub-block inverses by three levels of the 2x2
 // recursion (chol_inv_offdiag) and written to `work` for the panel kernel.
 __global__ __launch_bounds__(CH_THREADS) void potrf_diag_kernel(double* __restrict__ A, int lda, int64_t stride, int k,
                                                                 double* __restrict__ work, int* __restrict__ info,
                                                                 int need_inverse, double* __restrict__ Xout,
                                                                 double* __restrict__ Xtout, int ldx, int64_t xstride) {
     // These few waves are the critical path of the M x M prelude while the K(X, Z) fill of the same step fills every CU
-    // from a side stream: ask the SIMD arbiter to issue them first.
+    // from a side stream: ask the SIMD arbiter to issue them first.  The fill (96 VGPRs, three waves per SIMD) leaves 224
+    // registers per SIMD lane: with at most 112 VGPRs this workgroup (two waves per SIMD) is placed on a CU the fill
+    // occupies without waiting for one of its workgroups to retire -- at 144 a factorisation under the fill took 0.2 ms
+    // longer (A/B on one box; tools/kres.py prints the count).
     __builtin_amdgcn_s_setprio(TSVGP_CHOL_PRIO);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     double* S = reinterpret_cast<double*>(smem_raw);  // [CH_NB][CH_LD]; lower: A -> L, strict upper: inv(L)^T
     __shared__ int fail;
     __shared__ double dinv[CH_NB];
-    __shared__ __attribute__((aligned(32))) double xs[4 * CH_SB];
+    __shared__ __attribute__((aligned(32))) double xs[4 * 4 * CH_SB];  // one scratch per participating wave
     const int t = threadIdx.x, lane = t & 63, b = blockIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     double* Ab = A + (size_t)b * stride + (size_t)k * CH_NB * lda + (size_t)k * CH_NB;
@@ -1426,39 +1503,48 @@ __global__ __launch_bounds__(CH_THREADS) void potrf_diag_kernel(double* __restri
     __syncthreads();
     PSTAMP()
 
+    // one 16x16 tile of a trailing update: A[i0.., j0..] -= L[i0.., c0..c0+16) L[j0.., c0..c0+16)^T (lower part only: the
+    // strict upper triangles of the diagonal tiles hold the sub-block inverses)
+    auto update_tile = [&](int c0, int i0, int j0) {
+        int lane_ = lane;
+        asm volatile("" : "+v"(lane_));
+        const int li = lane_ & 15, lk = lane_ >> 4;
+        v4d acc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = S[(i0 + lk + 4 * r) * CH_LD + j0 + li];
+#pragma unroll
+        for (int kk = 0; kk < CH_SB / 4; ++kk)
+            acc = Mfma<double>::run(-S[(i0 + li) * CH_LD + c0 + 4 * kk + lk], S[(j0 + li) * CH_LD + c0 + 4 * kk + lk], acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (j0 + li <= i0 + lk + 4 * r) S[(i0 + lk + 4 * r) * CH_LD + j0 + li] = acc[r];
+    };
+    // At the top of round s the block column of sub-block s carries the updates of all earlier phases, the block columns
+    // beyond it those of all but the last: that one is applied during the round by the waves that do not factor.
     for (int s0 = 0; s0 < CH_NB; s0 += CH_SB) {
-        if (w == 0) chol_factor_sb(S, dinv, xs, s0, lane, &fail, k * CH_NB);
-        __syncthreads();
-        PSTAMP()
-        const int nbelow = CH_NB - s0 - CH_SB;
-        if (t < nbelow)
-            chol_subst_sb(S, dinv, s0, s0 + CH_SB + t);
-        else if (w == 7 && need_inverse)
-            chol_inv_sb(S, dinv, s0, lane);
-        __syncthreads();
-        PSTAMP()
-        // trailing update on the lower 16x16 tiles of rows/columns [s0 + 32, 128)
-        const int n16 = nbelow / 16, ntile = n16 * (n16 + 1) / 2;
-        for (int ti = w; ti < ntile; ti += CH_THREADS / 64) {
-            int I = 0;
-            while ((I + 1) * (I + 2) / 2 <= ti) ++I;
-            const int J = ti - I * (I + 1) / 2;
-            const int i0 = s0 + CH_SB + 16 * I, j0 = s0 + CH_SB + 16 * J;
-            int lane_ = lane;
-            asm volatile("" : "+v"(lane_));
-            const int li = lane_ & 15, lk = lane_ >> 4;
-            v4d acc;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[r] = S[(i0 + lk + 4 * r) * CH_LD + j0 + li];
-#pragma unroll
-            for (int kk = 0; kk < CH_SB / 4; ++kk)
-                acc = Mfma<double>::run(-S[(i0 + li) * CH_LD + s0 + 4 * kk + lk], S[(j0 + li) * CH_LD + s0 + 4 * kk + lk],
-                                        acc);
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (j0 + li <= i0 + lk + 4 * r) S[(i0 + lk + 4 * r) * CH_LD + j0 + li] = acc[r];
+        const int nbelow = CH_NB - s0 - CH_SB, n16 = nbelow / 16;
+        const int nrows = nbelow + (need_inverse ? CH_SB : 0);
+        const int ntake = nrows > 0 ? (nrows + 63 - CH_SB) / (64 - CH_SB) : 1;  // 16 + 48 rows per factoring wave
+        const bool takes = w < ntake;
+        double a[CH_SB];
+        ChRole role{0, 0, -1};
+        if (takes) {
+            role = chol_factor_rows(S, dinv, xs + 4 * CH_SB * w, s0, lane, w, need_inverse, &fail, k * CH_NB, a);
+        } else if (s0 > 0) {
+            const int ntile = n16 * (n16 + 1) / 2;
+            for (int ti = w - ntake; ti < ntile; ti += CH_THREADS / 64 - ntake) {
+                int I = 0;
+                while ((I + 1) * (I + 2) / 2 <= ti) ++I;
+                const int J = ti - I * (I + 1) / 2;
+                update_tile(s0 - CH_SB, s0 + CH_SB + 16 * I, s0 + CH_SB + 16 * J);
+            }
         }
-        if (nbelow > 0) __syncthreads();
+        __syncthreads();
+        if (takes) chol_store_sb(S, s0, lane, w, role, a);  // nothing reads these rows before the next barrier
+        PSTAMP()
+        // this phase's update of the NEXT block column, one tile per wave; the rest waits for the next round
+        if (w < n16) update_tile(s0, s0 + CH_SB + 16 * w, s0 + CH_SB);
+        __syncthreads();
         PSTAMP()
     }
 
@@ -1507,6 +1593,8 @@ __global__ __launch_bounds__(CH_THREADS) void potrf_diag_kernel(double* __restri
         unsigned long long* dst = reinterpret_cast<unsigned long long*>(work + (size_t)b * CH_NB * CH_NB);
         dst[0] = nstamp;
         for (int i = 0; i < nstamp; ++i) dst[1 + i] = stamp[i];
+        const unsigned long long* fst = reinterpret_cast<const unsigned long long*>(smem_raw + (size_t)CH_NB * CH_LD * sizeof(double));
+        for (int i = 0; i < 64; ++i) dst[64 + i] = fst[i];
     }
 #endif
 #undef PSTAMP
@@ -2139,7 +2227,11 @@ int potrf(double* A, int M, int lda, int batch, int64_t stride, int* info, doubl
     const bool inv = X != nullptr, subst = (flags & TSVGP_POTRF_SUBST) != 0;
     if (inv && (!Xt || !T)) return TSVGP_EINVAL;
     const int nt = M / CH_NB;
+#ifdef TSVGP_DIAG_POTRF
+    const size_t smem = (size_t)CH_NB * CH_LD * sizeof(double) + 64 * sizeof(unsigned long long);  // + in-phase stamps
+#else
     const size_t smem = (size_t)CH_NB * CH_LD * sizeof(double);
+#endif
     static DynLdsOptIn optin;
     if (optin.ensure(reinterpret_cast<const void*>(&potrf_diag_kernel), smem) != TSVGP_OK) return TSVGP_ELAUNCH;
     hipStream_t st = (hipStream_t)stream;

@@ -16,13 +16,20 @@ for _ in range(3):
     W = A.clone()
     assert lib.tsvgp_potrf_f64(vp(W.data_ptr()), M, M, 1, ctypes.c_int64(M * M), vp(info.data_ptr()), vp(work.data_ptr()), 0, None) == 0
 torch.cuda.synchronize()
-st = work[:40].view(torch.int64).cpu().numpy()
+raw = work[:128].view(torch.int64).cpu().numpy()
+st = raw[:40]
 n = int(st[0]); st = st[1:1 + n]
 names = ["load"]
-nsb = (n - 5) // 3  # sub-blocks per 128-block (TSVGP_CHOL_SB = 16 -> 8)
+nsb = (n - 5) // 2  # sub-blocks per 128-block (TSVGP_CHOL_SB = 16 -> 8)
 for s_ in range(nsb):
-    names += [f"s{s_}: factor sub-block", f"s{s_}: row solves + sub-block inverse", f"s{s_}: trailing MFMA update"]
-names += ["store L", "assemble inverse (2 levels)", "store inverse"]
+    names += [f"s{s_}: factor + row solves + inverse || previous update", f"s{s_}: update of the next block column"]
+names += ["store L", "assemble inverse (3 levels)", "store inverse"]
 for i in range(n - 1):
     print(f"{names[i] if i < len(names) else '?':32s} {int(st[i + 1] - st[i]):8d} ticks  {(st[i + 1] - st[i]) / 2.3e3:7.2f} us")
 print(f"{'total':32s} {int(st[-1] - st[0]):8d} ticks  {(st[-1] - st[0]) / 2.3e3:7.2f} us   (s_memtime ticks at ~2.3 GHz)")
+
+# stamps inside the factor pass of sub-blocks 0 and 5 (wave 0): start, then per 4-column step: pivots done, own row done,
+# remaining columns updated
+for name, off in (("sub-block 0 (3 waves)", 64), ("sub-block 5 (1 wave)", 96)):
+    f = raw[off:off + 14]
+    print(name + ": " + " ".join(str(int(f[i + 1] - f[i])) for i in range(12)) + "  ticks between stamps")
