@@ -1,5 +1,8 @@
+#!/usr/bin/env python3
+"""The K(X, Z) fill alone at the `ns` sizes (N=1e6, M=1024, D=8, fp64), 20 launches back to back; TSVGP_HIP_LIB picks the
+build (tools/ab_builds.sh).  GPU box."""
 import importlib, os, sys, time
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench
 pkg = importlib.import_module("t-svgp_amd")
 w = bench.WORKLOADS["ns"]
