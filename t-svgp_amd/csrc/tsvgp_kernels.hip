@@ -1244,8 +1244,6 @@ constexpr int CH_SB = TSVGP_CHOL_SB;  // sub-block of the diagonal block factore
 constexpr int CH_WT = 32;          // wave tile of the panel / update / inverse-assembly products
 constexpr int CH_LD = CH_NB + 1;   // odd LDS row stride: one-lane-per-row column sweeps touch 32 different banks
 constexpr int CH_THREADS = 512;    // 8 waves
-constexpr int CH_PC = 8;           // columns per LDS chunk of the panel block in the lookahead update
-constexpr int CH_PLD = 10;         // its row stride (even: 16-byte rows)
 
 // 1/sqrt(x) to fp64 accuracy: hardware estimate (v_rsq_f64, 2^-24 measured) + ONE third-order step
 //   e = 1 - x y^2,  y <- y + y e (1/2 + 3/8 e):  max rel err 1.4e-16 over 2^20 arguments (tools/rsq_probe.hip), four
@@ -1298,7 +1296,7 @@ __device__ __forceinline__ ChRole chol_factor_rows(double* __restrict__ S, doubl
     int bad = 0;
 #ifdef TSVGP_DIAG_POTRF
     extern __shared__ __attribute__((aligned(16))) unsigned char diag_raw[];
-    unsigned long long* fst = reinterpret_cast<unsigned long long*>(diag_raw + (size_t)CH_NB * (CH_LD + CH_PLD) * sizeof(double));
+    unsigned long long* fst = reinterpret_cast<unsigned long long*>(diag_raw + (size_t)CH_NB * CH_LD * sizeof(double));
     int nf = 0;
 #define FSTAMP() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); if (w == 0 && (s0 == 0 || s0 == 80)) { unsigned long long tt = __builtin_amdgcn_s_memtime(); if (lane == 0) fst[(s0 == 0 ? 0 : 32) + nf] = tt; } ++nf; }
 #else
@@ -1450,58 +1448,6 @@ __device__ __forceinline__ void chol_inv_offdiag(double* __restrict__ S, const d
             S[(l0 + 16 * J + li) * CH_LD + h0 + 16 * I + lk + 4 * r] = O[I][r];
 }
 
-// Trailing update of block column kc for the lookahead launch (potrf_diag_kernel's extra workgroups): wave `wid` takes
-// the lower 32 x 32 tile number wid + 10 of the trailing matrix (the first ten are the diagonal block right behind the
-// panel, which the factoring workgroup updates itself), A[i, j] -= A[i, kc] A[j, kc]^T.  Same lane -> k mapping idea as
-// chol_tile_kernel (the sum over k does not care which lane group supplies which k), but in eight steps of 16 columns
-// with 32 bytes per lane and operand row: this code shares its register allocation with the factorisation, which has
-// to stay below 112 VGPRs, and it runs beside that factorisation, so its own latency does not matter.
-__device__ __forceinline__ void chol_update_role(double* __restrict__ Ab, int lda, int kc, int nt, int wid, int lane) {
-    const int nb32 = (nt - kc - 1) * (CH_NB / CH_WT);
-    wid += 10;
-    if (wid >= nb32 * (nb32 + 1) / 2) return;
-    int r = (int)((sqrtf(8.0f * (float)wid + 1.0f) - 1.0f) * 0.5f);
-    while (r * (r + 1) / 2 > wid) --r;
-    while ((r + 1) * (r + 2) / 2 <= wid) ++r;
-    const int ti = r, tj = wid - r * (r + 1) / 2;
-    const int li = lane & 15, g = lane >> 4;
-    const int base = (kc + 1) * CH_NB;
-    const double* Arow = Ab + (size_t)(base + CH_WT * ti + li) * lda + (size_t)kc * CH_NB + 4 * g;
-    const double* Brow = Ab + (size_t)(base + CH_WT * tj + li) * lda + (size_t)kc * CH_NB + 4 * g;
-    v4d acc[2][2];
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int n = 0; n < 2; ++n) acc[s][n] = v4d{0, 0, 0, 0};
-#pragma unroll 2
-    for (int e = 0; e < CH_NB / 16; ++e) {
-        v2d ra[2][2], rb[2][2];
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                ra[s][q] = *reinterpret_cast<const v2d*>(Arow + (size_t)16 * s * lda + 16 * e + 2 * q);
-                rb[s][q] = *reinterpret_cast<const v2d*>(Brow + (size_t)16 * s * lda + 16 * e + 2 * q);
-            }
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int n = 0; n < 2; ++n)
-                    acc[s][n] = Mfma<double>::run(ra[s][kk >> 1][kk & 1], rb[n][kk >> 1][kk & 1], acc[s][n]);
-    }
-    double* Cb = Ab + (size_t)(base + CH_WT * ti) * lda + (size_t)base + CH_WT * tj + li;
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-            double* Cr = Cb + (size_t)(16 * s + g + 4 * r4) * lda;
-#pragma unroll
-            for (int n = 0; n < 2; ++n) Cr[16 * n] -= acc[s][n][r4];
-        }
-}
-
 // Diagonal block: right-looking over eight 16-wide sub-blocks, everything in LDS / registers.  Round s:
 //   (1) waves 0..2 factor the 16x16 diagonal sub-block in registers and, in the same pass, solve the rows below against
 //       it and invert it (chol_factor_rows: 64 rows per wave, the sub-block redundantly in each); the other waves
@@ -1513,8 +1459,7 @@ __device__ __forceinline__ void chol_update_role(double* __restrict__ Ab, int ld
 __global__ __launch_bounds__(CH_THREADS) void potrf_diag_kernel(double* __restrict__ A, int lda, int64_t stride, int k,
                                                                 double* __restrict__ work, int* __restrict__ info,
                                                                 int need_inverse, double* __restrict__ Xout,
-                                                                double* __restrict__ Xtout, int ldx, int64_t xstride,
-                                                                int batch, int nupd, int nt) {
+                                                                double* __restrict__ Xtout, int ldx, int64_t xstride) {
     // These few waves are the critical path of the M x M prelude while the K(X, Z) fill of the same step fills every CU
     // from a side stream: ask the SIMD arbiter to issue them first.  The fill (96 VGPRs, three waves per SIMD) leaves 224
     // registers per SIMD lane: with at most 112 VGPRs this workgroup (two waves per SIMD) is placed on a CU the fill
@@ -1526,17 +1471,8 @@ __global__ __launch_bounds__(CH_THREADS) void potrf_diag_kernel(double* __restri
     __shared__ int fail;
     __shared__ double dinv[CH_NB];
     __shared__ __attribute__((aligned(32))) double xs[4 * 4 * CH_SB];  // one scratch per participating wave
-    const int t = threadIdx.x, lane = t & 63;
+    const int t = threadIdx.x, lane = t & 63, b = blockIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-    if ((int)blockIdx.x >= batch) {
-        // LOOKAHEAD: the workgroups behind the first `batch` apply the trailing update of block column k - 1 to everything
-        // but the diagonal block (k, k), which the factoring workgroup takes itself below -- so the factorisation of
-        // block k runs BESIDE the update instead of behind it (one stream, no events).
-        const int u = blockIdx.x - batch;
-        chol_update_role(A + (size_t)(u / nupd) * stride, lda, k - 1, nt, (u % nupd) * (CH_THREADS / 64) + w, lane);
-        return;
-    }
-    const int b = blockIdx.x;
     double* Ab = A + (size_t)b * stride + (size_t)k * CH_NB * lda + (size_t)k * CH_NB;
 #ifdef TSVGP_DIAG_POTRF
     unsigned long long stamp[40];
@@ -1547,15 +1483,6 @@ __global__ __launch_bounds__(CH_THREADS) void potrf_diag_kernel(double* __restri
 #endif
     PSTAMP()
     if (t == 0) fail = 0;
-    // Lookahead (k > 0): the first chunks of the panel block P = L[k, k-1] are requested before anything else.  Four chunks
-    // in flight per thread (what the register budget allows): the block was written by workgroups on other XCDs a moment
-    // ago, each load comes across the fabric (~1 us), and with two in flight the sixteen chunks took 16 us.
-    const double* Pg = Ab - CH_NB + (size_t)(t >> 2) * lda + 2 * (t & 3);  // row t/4, columns 2 (t%4), +1 of a chunk
-    v2d nx[4];
-    if (k > 0) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) nx[c] = *reinterpret_cast<const v2d*>(Pg + CH_PC * c);
-    }
     // 16-byte loads, eight in flight per thread; the strict upper triangle is read and dropped
 #pragma unroll
     for (int it0 = 0; it0 < CH_NB * CH_NB / 2 / CH_THREADS; it0 += 8) {
@@ -1570,59 +1497,6 @@ __global__ __launch_bounds__(CH_THREADS) void potrf_diag_kernel(double* __restri
             const int idx = t + (it0 + u) * CH_THREADS, r = idx >> 6, c = (idx & 63) * 2;
             S[r * CH_LD + c] = (c <= r) ? v[u][0] : 0.0;
             S[r * CH_LD + c + 1] = (c + 1 <= r) ? v[u][1] : 0.0;
-        }
-    }
-    PSTAMP()
-    if (k > 0) {
-        // the update this block still misses, S -= P P^T with P = L[k, k-1] (128 x 128, written by the panel launch just
-        // before): P goes through an 8-column LDS chunk (eight more prefetched in registers; with a wider chunk the
-        // workgroup would no longer fit beside three workgroups of the K(X, Z) fill on one CU), each wave keeps the
-        // accumulators of five lower 16 x 16 tiles over the sixteen chunks (36 tiles on 40 slots: the last four redo tile
-        // 0 and drop the result, so that the tile loop has no branches and its LDS reads are issued together)
-        double* Pc = S + CH_NB * CH_LD;  // [CH_NB][CH_PLD]
-        int lane_ = lane;
-        asm volatile("" : "+v"(lane_));
-        const int li = lane_ & 15, lk = lane_ >> 4;
-        int ti0[5], tj0[5];
-        v4d pacc[5];
-#pragma unroll
-        for (int q = 0; q < 5; ++q) {
-            const int ti = (w + 8 * q < 36) ? w + 8 * q : 0;
-            int I = 0;
-            while ((I + 1) * (I + 2) / 2 <= ti) ++I;
-            ti0[q] = 16 * I;
-            tj0[q] = 16 * (ti - I * (I + 1) / 2);
-            pacc[q] = v4d{0, 0, 0, 0};
-        }
-#pragma unroll
-        for (int c = 0; c < CH_NB / CH_PC; ++c) {
-            __syncthreads();  // the previous chunk has been read (first pass: S is complete, not needed yet)
-            *reinterpret_cast<v2d*>(Pc + (t >> 2) * CH_PLD + 2 * (t & 3)) = nx[c & 3];
-            if (c + 4 < CH_NB / CH_PC) nx[c & 3] = *reinterpret_cast<const v2d*>(Pg + CH_PC * (c + 4));
-            __syncthreads();
-            double pa[5][2], pb[5][2];
-#pragma unroll
-            for (int q = 0; q < 5; ++q)
-#pragma unroll
-                for (int kk = 0; kk < CH_PC / 4; ++kk) {
-                    pa[q][kk] = Pc[(ti0[q] + li) * CH_PLD + 4 * kk + lk];
-                    pb[q][kk] = Pc[(tj0[q] + li) * CH_PLD + 4 * kk + lk];
-                }
-#pragma unroll
-            for (int kk = 0; kk < CH_PC / 4; ++kk)
-#pragma unroll
-                for (int q = 0; q < 5; ++q) pacc[q] = Mfma<double>::run(pa[q][kk], pb[q][kk], pacc[q]);
-#ifdef TSVGP_DIAG_POTRF_CHUNKS
-            if (c == 0 || c == 1 || c == 8) { PSTAMP() }
-#endif
-        }
-        __syncthreads();  // S complete for everyone
-#pragma unroll
-        for (int q = 0; q < 5; ++q) {
-            if (w + 8 * q >= 36) continue;
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (tj0[q] + li <= ti0[q] + lk + 4 * r) S[(ti0[q] + lk + 4 * r) * CH_LD + tj0[q] + li] -= pacc[q][r];
         }
     }
     __syncthreads();
@@ -1721,7 +1595,7 @@ __global__ __launch_bounds__(CH_THREADS) void potrf_diag_kernel(double* __restri
         unsigned long long* dst = reinterpret_cast<unsigned long long*>(work + (size_t)b * CH_NB * CH_NB);
         dst[0] = nstamp;
         for (int i = 0; i < nstamp; ++i) dst[1 + i] = stamp[i];
-        const unsigned long long* fst = reinterpret_cast<const unsigned long long*>(smem_raw + (size_t)CH_NB * (CH_LD + CH_PLD) * sizeof(double));
+        const unsigned long long* fst = reinterpret_cast<const unsigned long long*>(smem_raw + (size_t)CH_NB * CH_LD * sizeof(double));
         for (int i = 0; i < 64; ++i) dst[64 + i] = fst[i];
     }
 #endif
@@ -2355,11 +2229,10 @@ int potrf(double* A, int M, int lda, int batch, int64_t stride, int* info, doubl
     const bool inv = X != nullptr, subst = (flags & TSVGP_POTRF_SUBST) != 0;
     if (inv && (!Xt || !T)) return TSVGP_EINVAL;
     const int nt = M / CH_NB;
-    // the block itself + the lookahead's 8-column chunk of the panel block (+ in-phase stamps in the diagnostic build)
 #ifdef TSVGP_DIAG_POTRF
-    const size_t smem = (size_t)CH_NB * (CH_LD + CH_PLD) * sizeof(double) + 64 * sizeof(unsigned long long);
+    const size_t smem = (size_t)CH_NB * CH_LD * sizeof(double) + 64 * sizeof(unsigned long long);  // + in-phase stamps
 #else
-    const size_t smem = (size_t)CH_NB * (CH_LD + CH_PLD) * sizeof(double);
+    const size_t smem = (size_t)CH_NB * CH_LD * sizeof(double);
 #endif
     static DynLdsOptIn optin;
     if (optin.ensure(reinterpret_cast<const void*>(&potrf_diag_kernel), smem) != TSVGP_OK) return TSVGP_ELAUNCH;
@@ -2371,26 +2244,27 @@ int potrf(double* A, int M, int lda, int batch, int64_t stride, int* info, doubl
         zero_fill(X, sizeof(double) * xstride * batch, st);
         zero_fill(Xt, sizeof(double) * xstride * batch, st);
     }
-    // Launch sequence with lookahead: [factor block 0], then per block column k: the panel below it, and ONE launch
-    // that factors block k + 1 (after applying column k's update to it itself) beside the trailing update of column k on
-    // everything else.
-    const int wpb = CH_THREADS / 64;
+    // Lookahead in ONE launch was built and measured (commit 472dfec, not kept): the factoring workgroup of block k + 1
+    // applies column k's update to its own block (S -= P P^T through LDS chunks of the panel block) while extra workgroups
+    // of the same launch update the rest of the trailing matrix.  0.464 vs 0.458 ms at M = 1024: that in-kernel update
+    // costs 15 us (LDS-read bound: 80 KB of operand reads per 8-column chunk for 10 MFMAs per wave), as much as the
+    // 13 us update launch it hides, and the 10 KB chunk buffer brings the workgroup to the edge of what fits beside
+    // three workgroups of the K(X, Z) fill on one CU (with 18 KB it no longer fits and waits: 1.22 vs 0.96 ms under the fill).
+    const int wpb = NTHREADS / 64;
     for (int k = 0; k < nt; ++k) {
-        int nupd = 0;
-        if (k > 0) {
-            const int nb32 = (nt - k) * (CH_NB / CH_WT);  // trailing matrix behind column k - 1, in 32-wide tiles
-            nupd = (nb32 * (nb32 + 1) / 2 - 10 + wpb - 1) / wpb;
-        }
-        hipLaunchKernelGGL(potrf_diag_kernel, dim3(batch * (1 + nupd)), dim3(CH_THREADS), smem, st, A, lda, stride, k, work,
-                           info, (inv || (k + 1 < nt && !subst)) ? 1 : 0, X, Xt, M, xstride, batch, nupd, nt);
+        hipLaunchKernelGGL(potrf_diag_kernel, dim3(batch), dim3(CH_THREADS), smem, st, A, lda, stride, k, work, info,
+                           (inv || (k + 1 < nt && !subst)) ? 1 : 0, X, Xt, M, xstride);
         const int below = nt - k - 1;
         if (below > 0) {
+            const int nb32 = below * (CH_NB / CH_WT), ntile = nb32 * (nb32 + 1) / 2;
             if (subst)
                 hipLaunchKernelGGL(chol_panel_subst_kernel, dim3(below * (CH_NB / PS_ROWS), batch), dim3(NTHREADS), 0, st, A,
                                    lda, stride, k);
             else
-                hipLaunchKernelGGL(chol_tile_kernel<0>, dim3(below * (CH_NB / CH_WT), batch), dim3(NTHREADS), 0, st, A, lda,
-                                   stride, k, nt, work);
+                hipLaunchKernelGGL(chol_tile_kernel<0>, dim3(nb32, batch), dim3(NTHREADS), 0, st, A, lda, stride, k, nt,
+                                   work);
+            hipLaunchKernelGGL(chol_tile_kernel<1>, dim3((ntile + wpb - 1) / wpb, batch), dim3(NTHREADS), 0, st, A,
+                               lda, stride, k, nt, work);
         }
     }
     if (inv) {

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostic build: in-kernel cycle stamps of potrf_diag_kernel's phases (GPU box).  usage: diag_potrf.py [k]: the block
-column whose factoring workgroup is stamped (0: no lookahead update in front of it; 1: with it)."""
+column whose factoring workgroup is stamped (default 0)."""
 import ctypes, os, subprocess, sys
 import torch
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -21,8 +21,8 @@ torch.cuda.synchronize()
 raw = work[:128].view(torch.int64).cpu().numpy()
 st = raw[:40]
 n = int(st[0]); st = st[1:1 + n]
-names = ["load", "lookahead update of this block (S -= P P^T)"]
-nsb = (n - 6) // 2  # sub-blocks per 128-block (TSVGP_CHOL_SB = 16 -> 8)
+names = ["load"]
+nsb = (n - 5) // 2  # sub-blocks per 128-block (TSVGP_CHOL_SB = 16 -> 8)
 for s_ in range(nsb):
     names += [f"s{s_}: factor + row solves + inverse || previous update", f"s{s_}: update of the next block column"]
 names += ["store L", "assemble inverse (3 levels)", "store inverse"]
