@@ -347,7 +347,7 @@ struct FillBatch {
 template <typename T, int KIND, int DT>
 __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, TSVGP_FILL_MAXWAVES))) void se_fill_kernel(
     const T* __restrict__ X, const T* __restrict__ Z, const T* __restrict__ inv_ls, FillBatch<T> var, T* __restrict__ K,
-    int64_t strideK, int64_t N, int M, int D, int64_t ldk, int64_t rows_pad, int cols_pad) {
+    int64_t strideK, int64_t N, int M, int D, int64_t ldk, int64_t rows_pad, int cols_pad, int stream_out) {
     __shared__ __attribute__((aligned(16))) T Xs[FILL_ROWS][DT];  // pre-scaled by inv_ls
     typedef typename Mfma<T>::pair_t pair_t;
 
@@ -404,10 +404,11 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, TSV
 #endif
 #ifdef TSVGP_EXP_NOSTORE  // ablation switch: the arithmetic alone (the store never executes, the compiler cannot know)
                 if (out[0] == T(-1)) *reinterpret_cast<pair_t*>(Kp + (int64_t)rr * ldk) = out;
-#elif defined(TSVGP_FILL_NT)  // experiment: streaming (non-temporal) stores
-                __builtin_nontemporal_store(out, reinterpret_cast<pair_t*>(Kp + (int64_t)rr * ldk));
 #else
-                *reinterpret_cast<pair_t*>(Kp + (int64_t)rr * ldk) = out;
+                if (stream_out)
+                    __builtin_nontemporal_store(out, reinterpret_cast<pair_t*>(Kp + (int64_t)rr * ldk));
+                else
+                    *reinterpret_cast<pair_t*>(Kp + (int64_t)rr * ldk) = out;
 #endif
             }
             for (int rr = nvalid; rr < nrows; ++rr) *reinterpret_cast<pair_t*>(Kp + (int64_t)rr * ldk) = pair_t{T(0), T(0)};
@@ -2046,9 +2047,18 @@ int kernel_fill(int kind, const T* X, const T* Z, const T* inv_ls, const T* vari
     if ((unsigned)(TSVGP_FILL_GRID_CAP) < grid.x) grid.x = (unsigned)(TSVGP_FILL_GRID_CAP);
 #endif
     const int DT = D <= 1 ? 1 : D <= 2 ? 2 : D <= 4 ? 4 : D <= 8 ? 8 : D <= 16 ? 16 : 32;
+    // An output far beyond the caches (4 MB of L2 per XCD, 256 MB of Infinity Cache) is written with non-temporal stores:
+    // nothing of it would still be cached when its reader arrives, and the M x M factorisations that run beside the fill of
+    // an E-step keep their operands in L2 (under the fill a factorisation call: 0.87 -> 0.80 ms; the step at N = 1e6
+    // 36.79 -> 36.45 ms on one box, within noise on two others, never slower).  A small output stays cacheable for its reader.
+#ifdef TSVGP_FILL_STREAM  // experiment builds (tools/exp_fill_nt.py, tools/ab_builds.sh): 0 / 1 for every launch
+    const int stream_out = TSVGP_FILL_STREAM;
+#else
+    const int stream_out = (double)rows_pad * (double)ldk * sizeof(T) * P >= 512.0 * 1024 * 1024;
+#endif
 #define TSVGP_FILL_LAUNCH(KIND_, DT_)                                                                                 \
     hipLaunchKernelGGL((se_fill_kernel<T, KIND_, DT_>), grid, dim3(NTHREADS), 0, (hipStream_t)stream, X, Z, inv_ls,   \
-                       var, K, strideK, N, M, D, ldk, rows_pad, cols_pad)
+                       var, K, strideK, N, M, D, ldk, rows_pad, cols_pad, stream_out)
 #define TSVGP_FILL_DT(KIND_)                          \
     switch (DT) {                                     \
         case 1: TSVGP_FILL_LAUNCH(KIND_, 1); break;   \

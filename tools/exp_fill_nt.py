@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A/B of the K(X, Z) fill with plain vs non-temporal stores (-DTSVGP_FILL_NT), alone and followed by the moments kernel
+"""A/B of the K(X, Z) fill with plain vs non-temporal stores (-DTSVGP_FILL_STREAM=0 / 1; the library picks by output size), alone and followed by the moments kernel
 (does bypassing the caches on the way out cost the reader?).  usage: exp_fill_nt.py   (GPU box)"""
 import ctypes, os, subprocess, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -15,7 +15,7 @@ T = torch.triu(torch.randn(1, M, M, dtype=torch.float64, device=dev)) / 32
 gam = torch.randn(M, 1, dtype=torch.float64, device=dev); Y = torch.randn(N, 1, dtype=torch.float64, device=dev)
 g0 = torch.empty(Np, 1, dtype=torch.float64, device=dev); g1 = torch.empty_like(g0)
 vep = torch.empty(Np // 128, dtype=torch.float64, device=dev); npp = torch.empty(Np // 128, dtype=torch.int32, device=dev)
-for flags in ([], ["-DTSVGP_FILL_NT"]):
+for flags in (["-DTSVGP_FILL_STREAM=0"], ["-DTSVGP_FILL_STREAM=1"]):
     so = "/tmp/libtsvgp_fillnt_%d.so" % len(flags)
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", *flags,
                            "-I", root + "/include", root + "/t-svgp_amd/csrc/tsvgp_kernels.hip", "-o", so])
