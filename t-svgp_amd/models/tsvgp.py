@@ -670,8 +670,9 @@ class t_SVGP(base_SVGP):
         warm_key = self._warm_key(X, jitter)
         eng = self._get_engine()
         # K(X, Z) depends on neither lambda nor the M x M factors: its fill runs on a side stream beside the prelude.
-        # (Starting it only behind the two GEMMs that assemble W -- they take 147 us each under the fill instead of 60 --
-        # measured 0.1-0.2 ms SLOWER per step: the fill then ends later than the prelude.)
+        # (Starting it only behind the two GEMMs that assemble W -- they take 130-190 us each under the fill instead of 40 --
+        # measured 0.1-0.2 ms SLOWER per step, and again 36.61 vs 36.46 ms after the fill and the factorisation were reworked:
+        # the factorisation and the moments kernel behind a later fill lose more than the two GEMMs gain.)
         pre = None
         if self.overlap_fill and hasattr(eng, "start_fill"):
             pre = eng.start_fill(X, self._Z(), self.kernel, b_tag=warm_key,
