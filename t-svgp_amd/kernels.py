@@ -27,12 +27,20 @@ class SquaredExponential:
 
     def inv_lengthscales(self, D: int, dtype=None, device=None) -> torch.Tensor:
         """[D] vector of 1/lengthscale (isotropic values are broadcast)."""
+        # cached per parameter version: the E-step asks for it twice per step (K_uu, K(X, Z)) right behind the status
+        # read of the previous step, where the GPU waits for the host
+        key = (self.lengthscales.version, D, dtype, str(device))
+        hit = self.__dict__.get("_inv_ls_cache")
+        if hit is not None and hit[0] == key:
+            return hit[1]
         ls = self.lengthscales.value
         if ls.dim() == 0:
             ls = ls.expand(D)
         if ls.shape[0] != D:
             raise ValueError(f"lengthscales has {ls.shape[0]} entries but the inputs have {D} columns")
-        return to_tensor(1.0 / ls, dtype, device).contiguous()
+        out = to_tensor(1.0 / ls, dtype, device).contiguous()
+        self.__dict__["_inv_ls_cache"] = (key, out)
+        return out
 
     def K_diag(self, X) -> torch.Tensor:
         X = to_tensor(X)
