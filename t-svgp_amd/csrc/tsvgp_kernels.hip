@@ -622,7 +622,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void panel_kernel(PanelArgs<T> a) {
 
     for (int p = 0; p < a.P; ++p) {
         const T* Tp = (MODE == MODE_STORE) ? a.Tm + (size_t)pb * a.strideT : a.Tm + (size_t)p * Mp * Mp;
-        const T* Arow = a.A + (size_t)(MODE == MODE_STORE ? pb : p) * a.strideA + (n0 + srow) * (int64_t)Mp + skh * H;
+        // operand addresses as a wave-uniform base (scalar registers) + one 32-bit per-thread offset shared by A and Tm (a row
+        // panel and a row tile of Tm are both < 4 GB): no 64-bit per-thread pointers, no 64-bit VALU adds per chunk
+        const T* Abase = a.A + (size_t)(MODE == MODE_STORE ? pb : p) * a.strideA + n0 * (int64_t)Mp;
+        const unsigned roff = (unsigned)((srow * Mp + skh * H) * sizeof(T));  // in BYTES: stays 32-bit after scaling
+#define TSVGP_AT(base_, c_) reinterpret_cast<const T*>(reinterpret_cast<const char*>(base_) + (roff + (unsigned)((c_) * KC * sizeof(T))))
+#define TSVGP_AROW(c_) TSVGP_AT(Abase, c_)
         // Row sums of squares: after every column tile the 8 per-register partials (2 row blocks x 4 registers) are
         // summed over the 16 lanes that share (lane>>4) and lane lr keeps the one with index lr & 7.
         double rs_mine = 0.0;
@@ -636,8 +641,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void panel_kernel(PanelArgs<T> a) {
         if constexpr (FUSE) {
 #if TSVGP_XTILE >= 2
             // the first tile (it = 0 for both triangles) starts at chunk 0: its loads fly while gamma is staged
-            load_run<T, H>(ra[0], Arow);
-            load_run<T, H>(rb[0], Tp + (size_t)srow * Mp + skh * H);
+            load_run<T, H>(ra[0], TSVGP_AROW(0));
+            load_run<T, H>(rb[0], TSVGP_AT(Tp, 0));
             pre = true;
 #endif
             for (int j = t; j < Mp; j += NTHREADS) gsm[j] = a.gamma[(size_t)j * a.P + p];
@@ -654,7 +659,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void panel_kernel(PanelArgs<T> a) {
 #pragma unroll 4
             for (int c = 0; c < nchunk; ++c) {
                 T ra[H];
-                load_run<T, H>(ra, Arow + c * KC);
+                load_run<T, H>(ra, TSVGP_AROW(c));
 #pragma unroll
                 for (int q = 0; q < H; ++q) mpart += ra[q] * gk[c * KC + q];
             }
@@ -664,7 +669,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void panel_kernel(PanelArgs<T> a) {
 
         auto tile_body = [&](const int it, auto first_tag, const int it_next) {
             constexpr bool FIRST = decltype(first_tag)::value;  // FUSE: the tile that also accumulates the mean
-            const T* Trow = Tp + (size_t)(it * TILE + srow) * Mp + skh * H;
+            const T* Tbase = Tp + (size_t)it * TILE * Mp;
+#define TSVGP_TROW(c_) TSVGP_AT(Tbase, c_)
 
             acc_t acc[2][8];
 #pragma unroll
@@ -683,8 +689,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void panel_kernel(PanelArgs<T> a) {
             // one barrier per chunk.  PAR = parity of c_ (compile time).
 #define TSVGP_FETCH(SET, cnext)                           \
     {                                                     \
-        load_run<T, H>(ra[SET], Arow + (cnext) * KC);     \
-        load_run<T, H>(rb[SET], Trow + (cnext) * KC);     \
+        load_run<T, H>(ra[SET], TSVGP_AROW(cnext));       \
+        load_run<T, H>(rb[SET], TSVGP_TROW(cnext));       \
     }
 #define TSVGP_STAGE(SET, cnext, b_)                                                        \
     {                                                                                      \
@@ -773,12 +779,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void panel_kernel(PanelArgs<T> a) {
 #undef TSVGP_STEP2
 #undef TSVGP_STAGE
 #undef TSVGP_FETCH
+#undef TSVGP_TROW
             pre = false;
 #if TSVGP_XTILE
             if (DEPTH == 1 && it_next >= 0) {  // request the next tile's first chunk; the epilogue below covers its latency
                 const int cn = (TRI == TSVGP_TRI_UPPER) ? it_next * CPT : 0;
-                load_run<T, H>(ra[0], Arow + cn * KC);
-                load_run<T, H>(rb[0], Tp + (size_t)(it_next * TILE + srow) * Mp + skh * H + cn * KC);
+                load_run<T, H>(ra[0], TSVGP_AROW(cn));
+                load_run<T, H>(rb[0], TSVGP_AT(Tp + (size_t)it_next * TILE * Mp, cn));
                 pre = true;
             }
 #endif

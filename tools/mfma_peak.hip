@@ -139,6 +139,55 @@ __global__ __launch_bounds__(256) void k_f32(float* out, int iters, float seed, 
     if (threadIdx.x == 0) { clk[2 * blockIdx.x] = t1 - t0; clk[2 * blockIdx.x + 1] = r1 - r0; }
 }
 
+// As k_f64_lds<8, 0, BAR>, with the accumulators in AGPRs (AG = 1) and / or the operand reads of the NEXT 16 MFMAs issued in
+// front of the current ones (PIPE = 1: two register sets, loop unrolled by two): does the 7 % that eight ds_read_b64 per 16
+// MFMAs cost come from the LDS latency, or from the reads' VGPR writes competing with the MFMAs' accumulator traffic?
+#define MFMA16(ACC, F, CON)                                                                                              \
+    _Pragma("unroll") for (int i = 0; i < 16; ++i) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0"               \
+                                                                 : CON(ACC[i])                                           \
+                                                                 : "v"(F[i & 3]), "v"(F[4 + (i >> 2)]));
+template <int AG, int PIPE, int BAR>
+__global__ __launch_bounds__(256, 2) void k_f64_lds2(double* out, int iters, unsigned long long* clk) {
+    __shared__ double sm[4608];
+    v4d acc[16];
+    for (int i = 0; i < 16; ++i) acc[i] = v4d{0, 0, 0, 0};
+    unsigned h = (blockIdx.x * 256 + threadIdx.x) * 2654435761u + 12345u;
+    for (int i = threadIdx.x; i < 4608; i += 256) { h = h * 1664525u + 1013904223u; sm[i] = ((double)(h >> 8) / 16777216.0 - 0.5); }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const double* base = sm + (lane & 15) * 17 + (lane >> 4);
+    double f[8], g[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = base[(i & 15) * 272 + (i & 3) * 4];
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; it += 2) {
+        if (PIPE) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) g[i] = base[((it + 1 + i) & 15) * 272 + (i & 3) * 4];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) f[i] = base[((it + i) & 15) * 272 + (i & 3) * 4];
+        }
+        if (AG) { MFMA16(acc, f, "+a") } else { MFMA16(acc, f, "+v") }
+        if (PIPE) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) f[i] = base[((it + 2 + i) & 15) * 272 + (i & 3) * 4];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) g[i] = base[((it + 1 + i) & 15) * 272 + (i & 3) * 4];
+        }
+        if (AG) { MFMA16(acc, g, "+a") } else { MFMA16(acc, g, "+v") }
+        if (BAR > 0 && ((it >> 1) % BAR) == BAR - 1) __builtin_amdgcn_s_barrier();
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+    double s = 0;
+    for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (threadIdx.x == 0) { clk[2 * blockIdx.x] = t1 - t0; clk[2 * blockIdx.x + 1] = r1 - r0; }
+}
+
 template <typename F>
 void run(const char* name, F launch, int blocks, int iters, int nacc, double flop_per_mfma) {
     hipEvent_t e0, e1;
@@ -192,6 +241,15 @@ int main() {
     run("8acc: 6 reads/8 MFMA, bar/64 MFMA, 2 waves/SIMD", [&](unsigned long long* c) { hipLaunchKernelGGL((k_f64_lds8<8>), dim3(512), dim3(256), 0, 0, od, iters * 2, c); }, 512, iters * 2, 8, 2048.0);
     run("8acc: 6 reads/8 MFMA, no barrier, 4 waves/SIMD", [&](unsigned long long* c) { hipLaunchKernelGGL((k_f64_lds8<0>), dim3(1024), dim3(256), 0, 0, od, iters * 2, c); }, 1024, iters * 2, 8, 2048.0);
     run("f64 + 8 ds_read + 1 gload16B /16 MFMA", [&](unsigned long long* c) { hipLaunchKernelGGL((k_f64_lds<8, 1>), dim3(512), dim3(256), 0, 0, od, src, iters, c); }, 512, iters, 16, 2048.0);
+#define RUN2(NAME, AG, PIPE, BAR) run(NAME, [&](unsigned long long* c) { hipLaunchKernelGGL((k_f64_lds2<AG, PIPE, BAR>), dim3(512), dim3(256), 0, 0, od, iters, c); }, 512, iters, 16, 2048.0)
+    RUN2("8 reads/16 MFMA, acc VGPR, no barrier", 0, 0, 0);
+    RUN2("8 reads/16 MFMA, acc AGPR, no barrier", 1, 0, 0);
+    RUN2("  reads one body ahead, acc VGPR", 0, 1, 0);
+    RUN2("  reads one body ahead, acc AGPR", 1, 1, 0);
+    RUN2("8 reads/16 MFMA, VGPR, barrier/64 MFMA", 0, 0, 2);
+    RUN2("8 reads/16 MFMA, AGPR, barrier/64 MFMA", 1, 0, 2);
+    RUN2("  reads ahead, VGPR, barrier/64 MFMA", 0, 1, 2);
+    RUN2("  reads ahead, AGPR, barrier/64 MFMA", 1, 1, 2);
     for (int blocks : {256, 512}) {
         run("f64 16x16x4, 4 accumulators", [&](unsigned long long* c) { hipLaunchKernelGGL(k_f64<4>, dim3(blocks), dim3(256), 0, 0, od, iters * 4, 0.37, c); }, blocks, iters * 4, 4, 2048.0);
     }
