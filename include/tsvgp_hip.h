@@ -73,7 +73,9 @@ int tsvgp_site_accum_slots_f32(void);
  *     Replaces gpflow.covariances.Kuf / Kuu (reference src/models/tsvgp.py:209-211, 222-225, 268-269).
  *     X [N x D] row-major, Z [M x D] row-major, inv_ls [D] (1/lengthscale per dimension),
  *     K [rows_alloc x ldk] row-major with rows_alloc >= round_up(N,128) and ldk >= round_up(M,128); entries with n >= N or
- *     m >= M (up to the padded extents) are written as 0.  D <= 32 (padded to 1, 2, 4, 8, 16 or 32 inside). */
+ *     m >= M (up to the padded extents) are written as 0.  D <= 32 (padded to 1, 2, 4, 8, 16 or 32 inside).
+ *     fp64: exp is the device library's algorithm restated for arguments <= 0 (bit-identical values).  An output of 512 MB or
+ *     more is written with non-temporal stores (it cannot stay cached for its reader; work on other streams keeps its L2). */
 int tsvgp_se_fill_f64(const double *X, const double *Z, const double *inv_ls, double variance, double *K, int64_t N,
                       int M, int D, int64_t ldk, void *stream);
 int tsvgp_se_fill_f32(const float *X, const float *Z, const float *inv_ls, float variance, float *K, int64_t N, int M,
