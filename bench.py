@@ -105,6 +105,44 @@ def _blas_info():
         return int(os.cpu_count() or 1), "unknown"
 
 
+class blas_threads:
+    """The BLAS pools NumPy / SciPy run on, widened to every host core for the oracle's sections: a rank started by
+    torch.distributed.run inherits OMP_NUM_THREADS=1 (its default for more than one process per node), which would time the
+    CPU baseline on one core and stretch the oracle's ELBO over all N rows from 40 s to many minutes."""
+
+    def __enter__(self):
+        self._ctx = None
+        try:
+            from threadpoolctl import threadpool_limits
+
+            self._ctx = threadpool_limits(limits=os.cpu_count() or 1, user_api="blas")
+        except Exception:
+            pass
+        return self
+
+    def __exit__(self, *exc):
+        if self._ctx is not None:
+            self._ctx.restore_original_limits()
+
+
+def elbo_vs_1gpu(args, w, elbo, taken):
+    """The ELBO after this run's steps against the committed ONE-GPU value of the same workload (profiles/elbo_1gpu.json,
+    written by tools/make_elbo_1gpu.py from 1-GPU bench lines measured on MI355X): the multi-rank half of "ELBO match".
+    Sharding only changes the order of the row sums, so the two agree to rounding (the 1-GPU tolerances)
+    once both runs have taken the same number of steps -- or enough of them to sit at the fixed point."""
+    path = os.path.join(ROOT, "profiles", "elbo_1gpu.json")
+    key = args.workload if not args.rows else f"{args.workload}@{args.rows}"
+    try:
+        ref = json.load(open(path)).get("white" if args.model == "white" else "tsvgp", {}).get(key)
+    except Exception:
+        ref = None
+    if not ref:
+        return None
+    return {"one_gpu": ref["elbo_after_steps"], "one_gpu_steps": ref["steps_taken"], "steps_taken": taken,
+            "rel": abs(elbo - ref["elbo_after_steps"]) / abs(ref["elbo_after_steps"]),
+            "same_steps": taken == ref["steps_taken"], "source": ref.get("source")}
+
+
 def oracle_step_flops(w, n):
     """Flops the reference's op sequence executes per E-step on n rows: (4 + 4P) n M^2 + ~37 M^3 P."""
     M, P = w["M"], w["P"]
@@ -166,10 +204,13 @@ def cpu_baseline(w, budget_s=20.0, model_kind="tsvgp"):
     }
 
 
-def elbo_match(model, w, X, Y, Z, budget_s):
+def elbo_match(model, w, X, Y, Z, budget_s, elbo_all_ranks=None):
     """The "ELBO match" half of the metric: the oracle's ELBO (row-blocked ``conditional`` + ``variational_expectations``,
     oracle.elbo_chunked) evaluated on the HIP model's state, against the HIP model's own ELBO of the same rows.
-    Full N when the first block's timing says it fits `budget_s`, else a prefix (the HIP side is recomputed on it)."""
+    Full N when the first block's timing says it fits `budget_s`, else a prefix (the HIP side is recomputed on it).
+    With several ranks (`elbo_all_ranks`: the all-reduced ELBO of the sharded rows, every rank's kernels + RCCL) this runs on
+    rank 0 alone: the state is replicated, the oracle takes all N rows on the host, and whatever the HIP side recomputes
+    here (a row prefix, the row sample) runs on rank 0's GPU without collectives."""
     import torch
     from oracle import tsvgp_oracle as O
 
@@ -195,9 +236,15 @@ def elbo_match(model, w, X, Y, Z, budget_s):
     e_o = float(O.elbo_chunked(ora, (X[:rows], Y[:rows]), chunk_rows=chunk, progress=tick))
     t_o = time.perf_counter() - t0
     dev, dt = model.device, model.compute_dtype
-    Xd = torch.as_tensor(X[:rows], dtype=dt).to(dev)
-    Yd = torch.as_tensor(Y[:rows], dtype=dt).to(dev)
-    e_h = float(model.elbo((Xd, Yd)))
+    dp_saved, model.data_parallel = model.data_parallel, False  # rank 0 alone from here on: no collective
+    if elbo_all_ranks is not None and rows == w["N"]:
+        e_h = float(elbo_all_ranks)
+    else:
+        model._get_engine().release()
+        Xd = torch.as_tensor(X[:rows], dtype=dt).to(dev)
+        Yd = torch.as_tensor(Y[:rows], dtype=dt).to(dev)
+        e_h = float(model.elbo((Xd, Yd)))
+        del Xd, Yd
     # intermediates of tsvgp.py:246-263 on a row sample spread over the whole range
     idx = np.arange(0, w["N"], max(1, w["N"] // 20000))[:20000]
     Xs, Ys = X[idx], Y[idx]
@@ -206,13 +253,33 @@ def elbo_match(model, w, X, Y, Z, budget_s):
     g1_o = np.minimum(g1_o, -1e-8)
     got = model.moments_and_gradients((torch.as_tensor(Xs, dtype=dt).to(dev), torch.as_tensor(Ys, dtype=dt).to(dev)))
     rel = lambda a, b: float(np.max(np.abs(a.cpu().numpy() - b)) / np.max(np.abs(b)))
-    return {"hip": e_h, "oracle": e_o, "rel": abs(e_h - e_o) / abs(e_o), "rows": int(rows), "full_N": bool(rows == w["N"]),
+    model.data_parallel = dp_saved
+    return {"hip": e_h, "hip_is": "all-reduced ELBO of the sharded rows (every rank)" if (elbo_all_ranks is not None and rows == w["N"])
+            else "one GPU", "oracle": e_o, "rel": abs(e_h - e_o) / abs(e_o), "rows": int(rows), "full_N": bool(rows == w["N"]),
             "oracle_seconds": round(t_o, 1),
             "sample_rows": int(len(idx)),
             "sample_max_rel_err": {k: rel(g, o) for k, g, o in zip(("mean", "var", "g0", "g1"), got, (mu_o, var_o, g0_o, g1_o))},
             "note": "oracle.elbo_chunked / predict_f_chunked (GPflow conditional + variational_expectations restated, "
                     "reference src/models/tsvgp.py:79-114) evaluated on the HIP model's (lambda_1, lambda_2_sqrt) after the "
                     "timed steps; rel = |hip - oracle| / |oracle|; tolerance stated in SURVEY 8(d): 1e-9 (fp64), 1e-4 (fp32)"}
+
+
+def self_launch(n_ranks: int) -> int:
+    """`python bench.py --gpus N` without a launcher: runs `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>` as a child and returns its exit code."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:  # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this pool
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // n_ranks)))
+    print(f"[bench] launching {n_ranks} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
@@ -231,6 +298,12 @@ def main():
                     help="seconds the oracle's ELBO evaluation may take; beyond it a row prefix is compared instead of all N")
     ap.add_argument("--no-side-lines", action="store_true", help="skip warm / forced-route / mean-only side measurements")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # A plain `python bench.py --gpus N`: start one rank per GPU as a FRESH child process (torch.distributed.run), relay
+        # its output (rank 0 prints the one JSON line) and exit with its code.  Nothing in this process has touched the GPU
+        # yet (torch is not even imported), and it never replaces itself with another program.
+        sys.exit(self_launch(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -264,8 +337,8 @@ def main():
     Xd = torch.as_tensor(X[lo:hi], dtype=dtype).to(device).contiguous()
     Yd = torch.as_tensor(Y[lo:hi], dtype=dtype).to(device).contiguous()
     rows = hi - lo
-    if world > 1:
-        del X, Y
+    if rank != 0:
+        del X, Y  # rank 0 keeps the host copy: the oracle side of `elbo_match` runs there on all N rows
 
     lik = pkg.Gaussian(variance=w.get("noise", 0.1)) if w["lik"] == "gaussian" else pkg.Bernoulli()
     kernel, wrap = make_kernel(pkg, w)
@@ -311,7 +384,8 @@ def main():
         torch.cuda.synchronize(device)
         route_gate_ms = (time.perf_counter() - t0) * 1e3
         conds = [float(c) for c in model._cond_cache[1]] if model._cond_cache is not None else None
-    for _ in range(max(args.warmup, 3 if replayed else 0)):  # a graph is captured on the second occurrence of a step
+    n_warm = max(args.warmup, 3 if replayed else 0)  # a graph is captured on the second occurrence of a step
+    for _ in range(n_warm):
         model.natgrad_step((Xd, Yd), lr=0.8)
     if not replayed and hasattr(eng, "reserve_events"):
         eng.reserve_events(2 * 8 * args.steps * max(1, w["P"] if w.get("separate") else 1) + 64)
@@ -467,7 +541,7 @@ def main():
                        "cond_Kuu_plus_jitter": conds},
             "route_gate_ms": None if route_gate_ms is None else round(route_gate_ms, 3),
             "other_routes": forced,
-            "elbo_after_steps": elbo,
+            "elbo_after_steps": elbo, "steps_before_elbo": n_warm + args.steps,
             "warm": {"value": round(args.steps / warm_elapsed, 4), "unit": "E-steps/s",
                      "ms_per_step": round(warm_elapsed / args.steps * 1e3, 4),
                      "note": "cache_whitened=True: the factor of K_uu+jitter I, its inverse and the N x M operand (K_fu, or "
@@ -480,10 +554,15 @@ def main():
             "kernel_timing": "HIP events around every C-ABI launch, on its launch stream, inside the timed region; the cyclic "
                              "garbage collector is paused inside timed loops (as timeit does)",
         }
-        if world == 1 and not args.no_elbo_match and args.model == "tsvgp":
-            out["elbo_match"] = elbo_match(model, w, X, Y, Z, args.elbo_budget)
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(w, args.cpu_budget, model_kind=args.model)
+        # The parity half of the metric and the CPU baseline ride on every line, also with N > 1 ranks: the oracle runs on
+        # rank 0's host cores while the other ranks wait in the closing barrier.  (torch.distributed.run exports
+        # OMP_NUM_THREADS=1 to its children unless told otherwise: the BLAS pool is widened to the box's cores here.)
+        with blas_threads():
+            if not args.no_elbo_match and args.model == "tsvgp":
+                out["elbo_match"] = elbo_match(model, w, X, Y, Z, args.elbo_budget, elbo_all_ranks=elbo if world > 1 else None)
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(w, args.cpu_budget, model_kind=args.model)
+        out["elbo_vs_1gpu"] = elbo_vs_1gpu(args, w, elbo, n_warm + args.steps)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -40,7 +40,7 @@ def to_tensor(value, dtype=None, device=None) -> torch.Tensor:
 def _host_scalar(value):
     """Python float of a scalar that already lives on the host; None for arrays and for device tensors."""
     if isinstance(value, Parameter):
-        return value._host if value._host_version == value.version else None
+        return value._host if value._host_version == value._stamp() else None
     if isinstance(value, torch.Tensor):
         return float(value) if (value.dim() == 0 and value.device.type == "cpu") else None
     if isinstance(value, (int, float, np.floating, np.integer)):
@@ -59,15 +59,19 @@ class Parameter:
         self.name = name
         self.version = 0  # bumped by assign(): lets cached kernel factorisations notice external parameter changes
         self._host = _host_scalar(value)  # scalar parameters: the value as a Python float, without a device read
-        self._host_version = 0 if self._host is not None else -1
+        self._host_version = self._stamp() if self._host is not None else None
+
+    def _stamp(self):
+        """(assign counter, the tensor's own edit counter): an in-place edit of ``.value`` changes the second."""
+        return (self.version, self._value._version)
 
     def item(self) -> float:
         """The scalar value as a Python float.  Kernel launches take scalars by value; reading them back from the
         device on every E-step would put a host synchronisation in the middle of the step, so the host copy is kept
         from the assignment (or read once per assignment when the value came as a device tensor)."""
-        if self._host_version != self.version:
+        if self._host_version != self._stamp():
             self._host = float(self._value)
-            self._host_version = self.version
+            self._host_version = self._stamp()
         return self._host
 
     @property
@@ -96,7 +100,7 @@ class Parameter:
         self.version += 1
         host = _host_scalar(value)
         if host is not None:
-            self._host, self._host_version = host, self.version
+            self._host, self._host_version = host, self._stamp()
         return self
 
     def assign_owned(self, new: torch.Tensor):

@@ -901,14 +901,23 @@ __global__ __launch_bounds__(NTHREADS, 2) void panel_kernel(PanelArgs<T> a) {
         }
     }
 #ifdef TSVGP_DIAG_PANEL
-    // stamps go to a buffer of their own (passed in place of `mean`, which this build never writes: see the guard below)
+    // Stamps go to a buffer of their own, passed in place of `mean` (which NO kernel of this build writes: every store
+    // through `mean` is compiled out under TSVGP_DIAG_PANEL).  The buffer describes itself: word 0 holds the number of
+    // 4-word slots that follow the 4-word header, and a workgroup whose index is not below it writes nothing.  (Round 2's
+    // stamp write was unchecked, and an experiment's finishing kernel stored its N means through the same pointer: a
+    // memory access fault, profiles/r02_moments_split_panel_experiment.txt.)
     if (t == 0 && a.mean) {
-        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(a.mean) + (size_t)blockIdx.x * 4;
-        dbg[0] = diag_t0;
-        dbg[1] = __builtin_amdgcn_s_memrealtime();
-        dbg[2] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)) |          // HW_REG_HW_ID
-                 ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)) << 32);  // HW_REG_XCC_ID
-        dbg[3] = __builtin_amdgcn_s_memtime() - diag_c0;  // shader cycles of this workgroup
+        unsigned long long* const hdr = reinterpret_cast<unsigned long long*>(a.mean);
+        const unsigned long long slots = hdr[0];
+        const unsigned long long slot = (unsigned long long)blockIdx.x + (unsigned long long)blockIdx.y * gridDim.x;
+        if (slot < slots) {
+            unsigned long long* dbg = hdr + 4 + slot * 4;
+            dbg[0] = diag_t0;
+            dbg[1] = __builtin_amdgcn_s_memrealtime();
+            dbg[2] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)) |          // HW_REG_HW_ID
+                     ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)) << 32);  // HW_REG_XCC_ID
+            dbg[3] = __builtin_amdgcn_s_memtime() - diag_c0;  // shader cycles of this workgroup
+        }
     }
 #endif
 }
@@ -962,7 +971,9 @@ __global__ __launch_bounds__(NTHREADS) void mean_lik_kernel(PanelArgs<T> a) {
                 const double mu = (double)(lane ? s1 : s0);
                 double g0 = 0.0, g1 = 0.0, ve = 0.0;
                 if (n < a.N) {
+#ifndef TSVGP_DIAG_PANEL  // in that build `mean` is the stamp buffer of panel_kernel: nothing else may store through it
                     if (a.mean) a.mean[n * P + p] = (T)mu;
+#endif
                     if (a.lik != TSVGP_LIK_NONE) lik_eval(a.lik, a.lik_param, mu, 0.0, (double)a.Y[n * P + p], g0, g1, ve);
                     if (!(fabs(mu) <= 1.79769313486231570815e308) || !(fabs(g0) <= 1.79769313486231570815e308)) atomicAdd(&bad, 1);
                 }

@@ -7,8 +7,24 @@ RCCL over xGMI with backend "nccl", gloo on CPU for tests.  The M x M prelude/ep
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
+
+
+# Issue the collectives whenever a process group exists, also when it has ONE rank (default: a single rank passes its
+# tensors through).  For tests: a world_size-1 "nccl" group on the one GPU of a test box drives the real RCCL calls -- group
+# initialisation with a device id, stream ordering against the kernels around them, capture of the step as two graphs
+# around the all-reduce -- that otherwise only an 8-GPU node would reach.  Also settable as TSVGP_FORCE_COLLECTIVES=1.
+FORCE_COLLECTIVES = os.environ.get("TSVGP_FORCE_COLLECTIVES", "0") == "1"
+
+
+def collectives_on() -> bool:
+    """True when all_reduce_sum / broadcast_from_rank0 go to the backend: more than one rank, or a forced single rank."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or FORCE_COLLECTIVES
 
 
 def world_size() -> int:
@@ -103,7 +119,7 @@ def reduce_stats(stats, P: int, M: int, with_sites: bool, reduce: bool, eng=None
 
 def all_reduce_sum(packed: torch.Tensor) -> torch.Tensor:
     """In-place sum over ranks (no-op for a single process)."""
-    if world_size() > 1:
+    if collectives_on():
         dist.all_reduce(packed, op=dist.ReduceOp.SUM)
     return packed
 
@@ -112,6 +128,6 @@ def broadcast_from_rank0(t: torch.Tensor) -> torch.Tensor:
     """In-place broadcast of rank 0's values (no-op for a single process).  Used for host-side DECISIONS derived from
     replicated data (the projection route from cond(K_uu)): every rank must take the same branch even if a library
     routine were to round differently from one device to the next."""
-    if world_size() > 1:
+    if collectives_on():
         dist.broadcast(t, src=0)
     return t

@@ -29,7 +29,10 @@ class SquaredExponential:
         """[D] vector of 1/lengthscale (isotropic values are broadcast)."""
         # cached per parameter version: the E-step asks for it twice per step (K_uu, K(X, Z)) right behind the status
         # read of the previous step, where the GPU waits for the host
-        key = (self.lengthscales.version, D, dtype, str(device))
+        # keyed on the Parameter object and on the tensor behind it as well: a replaced Parameter restarts its version at 0,
+        # an in-place edit of .value bumps only the tensor's own counter.  The returned tensor is shared: read-only.
+        par = self.lengthscales
+        key = (id(par), par.version, par.value.data_ptr(), par.value._version, D, dtype, str(device))
         hit = self.__dict__.get("_inv_ls_cache")
         if hit is not None and hit[0] == key:
             return hit[1]

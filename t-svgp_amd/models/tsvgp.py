@@ -29,6 +29,8 @@ from __future__ import annotations
 
 import abc
 import functools
+import time
+import warnings
 
 import numpy as np
 import torch
@@ -79,6 +81,7 @@ class base_SVGP(abc.ABC):
         self.compute_dtype = compute_dtype or default_float()
         self.device = torch.device(device) if device is not None else default_device()
         self._engine = None
+        self.poll_status = True  # how the step's status read waits for the GPU: see _read_flags
         self.data_parallel = None  # None = automatic: shard-reduce whenever torch.distributed has > 1 rank
 
     # -- engine ------------------------------------------------------------------------------------------------
@@ -91,22 +94,27 @@ class base_SVGP(abc.ABC):
         return self._engine
 
     def _reduce(self) -> bool:
-        return D_.world_size() > 1 if self.data_parallel is None else bool(self.data_parallel)
+        return D_.collectives_on() if self.data_parallel is None else bool(self.data_parallel)
 
     def _read_flags(self, flags: torch.Tensor) -> torch.Tensor:
         """The step's one device->host read.  On the GPU: an asynchronous copy into pinned memory and a POLLED event
         instead of a blocking ``.cpu()``: the wait never sleeps on an interrupt, so the host is back the moment the last
-        kernel of the step retires.  One host core spins for the length of a step."""
+        kernel of the step retires.  The poll yields between queries (``time.sleep(0)``), so one host core is busy for the
+        length of a step but other Python threads are not starved of the GIL; ``model.poll_status = False`` waits in a
+        blocking stream synchronisation instead (an idle core per rank, the host back some tens of microseconds later)."""
         if not flags.is_cuda:
             return flags
         host = getattr(self, "_flags_host", None)
         if host is None or host.numel() != flags.numel():
             host = self._flags_host = torch.empty(flags.numel(), dtype=flags.dtype).pin_memory()
         host.copy_(flags, non_blocking=True)
+        if not self.poll_status:
+            torch.cuda.current_stream(flags.device).synchronize()
+            return host.clone()
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(flags.device))
         while not ev.query():
-            pass
+            time.sleep(0)  # gives up the GIL and the time slice: other Python threads (loaders, logging) keep running
         return host.clone()
 
     @abc.abstractmethod
@@ -244,7 +252,10 @@ class t_SVGP(base_SVGP):
                 id(self.inducing_variable.Z), self.inducing_variable.Z.version, float(jitter), self.compute_dtype)
 
     def _kernel_versions(self):
-        return tuple((id(k), k.variance.version, k.lengthscales.version)
+        # Parameter identity and the tensors' own edit counters ride along: a replaced Parameter restarts at version 0 and an
+        # in-place edit of .value does not pass through assign()
+        return tuple((id(k), id(k.variance), k.variance.version, k.variance.value._version,
+                      id(k.lengthscales), k.lengthscales.version, k.lengthscales.value._version)
                      for k in latent_kernels(self.kernel, self.num_latent_gps))
 
     # Route gates on cond(K_uu + jitter I), per latent GP.  direct: K^-1 (sum g k k^T) K^-1 cancels two factors of K, so its
@@ -766,7 +777,13 @@ class t_SVGP(base_SVGP):
                     entry = dict(graph=graph, tail=tail, packed=packed, ops=ops, flags=flags, state=(sl1, sL),
                                  backup=(bl1, bL), buf=eng._buf)
                 self._graphs[key] = entry
-            except Exception:  # not capturable on this stack: never try this key again
+            except RuntimeError as exc:
+                # What torch / HIP raise when an operation is not permitted under stream capture: never try this key again
+                # and say so once (anything else -- a TypeError, a KeyError -- is a bug and propagates).  With several ranks
+                # the outcome needs no agreement: a rank that runs eagerly issues the same ONE all-reduce of the same
+                # packed buffer per step as a rank that replays its two graphs around it.
+                warnings.warn(f"natgrad_step: hipGraph capture failed, running eagerly for this configuration ({exc})",
+                              RuntimeWarning, stacklevel=3)
                 self._graphs[key] = "seen-uncapturable"
                 entry = None
             finally:

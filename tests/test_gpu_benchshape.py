@@ -110,3 +110,35 @@ def test_c5_full_size_row_sample_matches_oracle():
     assert relerr(g0[sel].cpu().numpy(), g0_o) < 1e-8
     assert relerr(g1[sel].cpu().numpy(), np.minimum(g1_o, -1e-8)) < 1e-8
     hip._get_engine().release()
+
+
+def test_c3_full_size_row_sample_matches_oracle():
+    """BASELINE configs[2] at full size: Bernoulli (probit, GH-20), N = 1e6, M = 1024, D = 16, fp32 N-arrays (the M x M
+    algebra stays fp64).  The HIP state after two steps goes to the fp64 oracle, which recomputes the moments and the
+    likelihood gradients of reference src/models/tsvgp.py:246-263 on every 997th row, and the ELBO of the sample.
+    fp32 tolerances of SURVEY 8(d) against the fp64 oracle: moments atol 1e-4 + rtol 1e-3, |dELBO| / |ELBO| <= 1e-4."""
+    p = pkg()
+    N = 1_000_000
+    w = dict(bench.WORKLOADS["c3"], N=N)
+    X, Y, Z = bench.make_data(w)
+    hip = p.t_SVGP(p.SquaredExponential(1.0, 1.0), p.Bernoulli(), Z, compute_dtype=torch.float32)
+    ora = O.t_SVGP(O.SquaredExponential(1.0, 1.0), O.Bernoulli(), Z)
+    Xd = torch.as_tensor(X, dtype=torch.float32, device="cuda:0")
+    Yd = torch.as_tensor(Y, dtype=torch.float32, device="cuda:0")
+    for _ in range(2):
+        hip.natgrad_step((Xd, Yd), lr=0.8)
+    ora.sites.lambda_1 = hip.lambda_1.numpy()
+    ora.sites._lambda_2_sqrt = np.tril(hip.lambda_2_sqrt.numpy())
+    mean, var, g0, g1 = hip.moments_and_gradients((Xd, Yd))  # the full-size fp32 launch
+    idx = np.arange(0, N, 997)
+    mu_o, var_o = O.predict_f_chunked(ora, X[idx], chunk_rows=1024)
+    g0_o, g1_o = ora.likelihood.variational_expectations_grads(mu_o, var_o, Y[idx])
+    g1_o = np.minimum(g1_o, -1e-8)
+    sel = torch.as_tensor(idx, device="cuda:0")
+    close = lambda got, want: np.all(np.abs(got[sel].cpu().numpy() - want) <= 1e-4 + 1e-3 * np.abs(want))
+    assert close(mean, mu_o) and close(var, var_o)
+    assert close(g0, g0_o) and close(g1, g1_o)  # smooth maps of (mean, var): the same bounds carry over
+    hip.num_data = ora.num_data = N
+    e_h = float(hip.elbo((Xd[sel], Yd[sel])))
+    e_o = float(O.elbo_chunked(ora, (X[idx], Y[idx]), chunk_rows=1024))
+    assert abs(e_h - e_o) / abs(e_o) < 1e-4

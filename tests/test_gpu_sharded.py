@@ -129,3 +129,73 @@ def test_two_rank_step_replayed_as_two_graphs_around_the_all_reduce(tmp_path):
     assert relerr(got["l1"], ora.lambda_1) < 1e-8
     assert relerr(got["L2"], ora.lambda_2) < 1e-8
     assert abs(float(got["elbo"]) - ora.elbo((X, Y))) < 1e-9 * abs(ora.elbo((X, Y)))
+
+
+def _worker_rccl(rank, world, port, out):
+    """ONE rank on backend "nccl" (RCCL) with the collectives forced on: the calls an 8-GPU run makes -- group initialisation
+    with a device id, all-reduce of the packed accumulators between the N-pass and the epilogue on the step's stream, the
+    broadcast of the route decision, the step captured as two hipGraphs with the collective between the replays -- on the one
+    GPU of this box."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    try:
+        p = pkg()
+        p.distributed.FORCE_COLLECTIVES = True
+        assert p.distributed.collectives_on()
+        calls = {"all_reduce": 0, "broadcast": 0}
+        real_ar, real_bc = dist.all_reduce, dist.broadcast
+
+        def counted_ar(t, *a, **k):
+            assert t.is_cuda  # the RCCL path: device buffers, no host staging
+            calls["all_reduce"] += 1
+            return real_ar(t, *a, **k)
+
+        def counted_bc(t, *a, **k):
+            calls["broadcast"] += 1
+            return real_bc(t, *a, **k)
+
+        dist.all_reduce, dist.broadcast = counted_ar, counted_bc
+        X, Y, Z = synthetic(N=4001, M=160, D=4, lik="bernoulli", seed=12)
+        Xd, Yd = torch.as_tensor(X, device="cuda:0"), torch.as_tensor(Y, device="cuda:0")
+        res = {}
+        for tag, use_graph in (("eager", False), ("graph", True)):
+            m = p.t_SVGP(p.SquaredExponential(1.0, 1.0), p.Bernoulli(), Z, num_data=4001, device="cuda:0", use_graph=use_graph)
+            assert m._reduce()
+            n0 = calls["all_reduce"]
+            for _ in range(5):  # graph: eager, capture + replay, three more replays
+                m.natgrad_step((Xd, Yd), lr=0.8)
+            res[tag + "_reduces"] = calls["all_reduce"] - n0
+            if use_graph:
+                res["captured"] = any(isinstance(e, dict) and "tail" in e for e in m._graphs.values())
+            res[tag + "_l1"], res[tag + "_L2"] = m.lambda_1.numpy(), m.lambda_2.cpu().numpy()
+            res[tag + "_elbo"] = float(m.elbo((Xd, Yd)))
+            e2, grads = m.elbo_and_grads((Xd, Yd))
+            res[tag + "_elbo2"] = float(e2)
+        res["broadcasts"] = calls["broadcast"]
+        np.savez(out, **res)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_single_rank_drives_the_collective_path(tmp_path):
+    """Backend nccl = RCCL, world_size 1, collectives forced on (``distributed.FORCE_COLLECTIVES``): eager steps, the
+    two-graph replay around the all-reduce, the route broadcast and the ELBO / gradient reductions all go through RCCL on
+    device buffers and must reproduce the oracle (reference src/models/tsvgp.py:278-281, :95 summed over ranks)."""
+    out = str(tmp_path / "r0.npz")
+    port = 23500 + (os.getpid() % 2000)
+    mp.spawn(_worker_rccl, args=(1, port, out), nprocs=1, join=True)
+    got = np.load(out)
+    X, Y, Z = synthetic(N=4001, M=160, D=4, lik="bernoulli", seed=12)
+    ora = O.t_SVGP(O.SquaredExponential(1.0, 1.0), O.Bernoulli(), Z, num_data=4001)
+    for _ in range(5):
+        ora.natgrad_step((X, Y), lr=0.8)
+    e = ora.elbo((X, Y))
+    assert bool(got["captured"])
+    assert int(got["eager_reduces"]) == 5 and int(got["graph_reduces"]) == 5  # one all-reduce per step, replayed or not
+    assert int(got["broadcasts"]) >= 1  # the route decision (cond(K_uu + jitter I)) came from rank 0
+    for tag in ("eager", "graph"):
+        assert relerr(got[tag + "_l1"], ora.lambda_1) < 1e-8
+        assert relerr(got[tag + "_L2"], ora.lambda_2) < 1e-8
+        assert abs(float(got[tag + "_elbo"]) - e) < 1e-9 * abs(e)
+        assert abs(float(got[tag + "_elbo2"]) - e) < 1e-9 * abs(e)

@@ -24,7 +24,10 @@ gam = torch.randn(M, 1, dtype=torch.float64, device=dev)
 Y = torch.randn(rows, 1, dtype=torch.float64, device=dev)
 g0 = torch.empty(Np, 1, dtype=torch.float64, device=dev); g1 = torch.empty_like(g0)
 vep = torch.empty(nwg, dtype=torch.float64, device=dev); npp = torch.empty(nwg, dtype=torch.int32, device=dev)
-dbg = torch.zeros(nwg * 4, dtype=torch.int64, device=dev)
+# stamp buffer: a 4-word header whose first word is the number of 4-word slots behind it (the kernel checks its slot index
+# against it), then one slot per workgroup
+dbg = torch.zeros(4 + nwg * 4, dtype=torch.int64, device=dev)
+dbg[0] = nwg
 lib.tsvgp_moments_f64.argtypes = [vp, vp, vp, vp, ctypes.c_double, ctypes.c_int, ctypes.c_double, vp, vp, vp, vp, vp, vp, i64, i64,
                                   ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]
 def run(d):
@@ -39,7 +42,8 @@ e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 5
 print(f"flags {flags} rows {rows}: moments {ms:.3f} ms  {rows * M * (M + 1) / ms / 1e9:.2f} TFLOP/s")
 run(dbg.data_ptr()); torch.cuda.synchronize()
-d = dbg.cpu().numpy().reshape(nwg, 4)
+d = dbg.cpu().numpy()[4:].reshape(nwg, 4)
+assert (d[:, 1] > 0).all(), "a workgroup left no stamp"
 t0, t1 = d[:, 0].astype(np.float64), d[:, 1].astype(np.float64)
 base = t0.min()
 t0, t1 = (t0 - base) / 100.0, (t1 - base) / 100.0  # microseconds
