@@ -149,11 +149,37 @@ __device__ __forceinline__ int row_block(int w, int slot) { return slot == 0 ? w
 template <typename T, int MLO, int MHI>
 __device__ __forceinline__ void mma_chunk_rowk(typename Mfma<T>::acc_t (&acc)[2][8], const T* __restrict__ As,
                                                const T* __restrict__ Bs, int w, int lane) {
-    constexpr int RS = PanelK<T>::RS, PKC = PanelK<T>::KC;
+    constexpr int RS = PanelK<T>::RS, PKC = PanelK<T>::KC, NKS = PKC / 4;
     const int lr = lane & 15, lk = lane >> 4;
     const T* ap0 = As + (w * 16 + lr) * RS + lk;
     const T* ap1 = As + ((7 - w) * 16 + lr) * RS + lk;
     const T* bp = Bs + lr * RS + lk;
+#ifdef TSVGP_ROWK_PIPE
+    // Two fragment register sets of ONE k-step each (the same 2 x (2 + 8) values the unpipelined form holds for two k-steps):
+    // the reads of k-step ks + 1 are issued in front of the MFMAs of k-step ks, so that within a chunk only the first
+    // k-step's read latency is exposed to a wave that has the matrix pipe to itself (the partner workgroup of the CU in a
+    // prologue, an epilogue or a latency-bound diagonal chunk).
+    T a[2][2], b[2][8];
+    auto rd = [&](const int set, const int ks, const int NMASK) __attribute__((always_inline)) {
+        a[set][0] = ap0[ks * 4];
+        a[set][1] = ap1[ks * 4];
+#pragma unroll
+        for (int n = 0; n < 8; ++n)
+            if (NMASK & (1 << n)) b[set][n] = bp[n * 16 * RS + ks * 4];
+    };
+    rd(0, 0, MLO);
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        const int NMASK = (ks < NKS / 2) ? MLO : MHI;
+        if (ks + 1 < NKS) rd((ks + 1) & 1, ks + 1, (ks + 1 < NKS / 2) ? MLO : MHI);
+#pragma unroll
+        for (int n = 0; n < 8; ++n)
+            if (NMASK & (1 << n)) {
+                acc[0][n] = Mfma<T>::run(a[ks & 1][0], b[ks & 1][n], acc[0][n]);
+                acc[1][n] = Mfma<T>::run(a[ks & 1][1], b[ks & 1][n], acc[1][n]);
+            }
+    }
+#else
 #pragma unroll
     for (int ks = 0; ks < PKC / 4; ++ks) {
         const int NMASK = (ks < PKC / 8) ? MLO : MHI;
@@ -170,6 +196,7 @@ __device__ __forceinline__ void mma_chunk_rowk(typename Mfma<T>::acc_t (&acc)[2]
                 acc[1][n] = Mfma<T>::run(a[1], b[n], acc[1][n]);
             }
     }
+#endif
 }
 
 // One k-chunk (16) of MFMAs on [k][row] images.  DIAG: only accumulators with column block <= row block
@@ -598,6 +625,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void panel_kernel(PanelArgs<T> a) {
 #ifdef TSVGP_DIAG_PANEL  // diagnostic build (tools/diag_panel.py): when and where every workgroup ran
     const unsigned long long diag_t0 = __builtin_amdgcn_s_memrealtime();
     const unsigned long long diag_c0 = __builtin_amdgcn_s_memtime();
+    // shader cycles of this wave by phase: [0] full k-chunks (64 MFMAs per wave and barrier), [1] the masked chunks of the
+    // diagonal k-tile, [2] a column tile's prologue (first fetch, staging, barrier), [3] its epilogue (square-sum / store)
+    unsigned long long diag_ph[4] = {0, 0, 0, 0};
+    unsigned long long diag_pre = 0, diag_post0 = 0;  // cycles before the first column tile / stamp at the end of the last one
+#define TSVGP_PHASE(i_, t_) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); diag_ph[i_] += now_ - (t_); (t_) = now_; }
+#else
+#define TSVGP_PHASE(i_, t_)
 #endif
 #ifdef TSVGP_EXP_SLOTPRIO  // experiment: the second resident workgroup of a CU (second dispatch half-round) at wave priority 1
     if ((blockIdx.x >> 8) & 1) __builtin_amdgcn_s_setprio(TSVGP_EXP_SLOTPRIO);
@@ -677,6 +711,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void panel_kernel(PanelArgs<T> a) {
             for (int s = 0; s < 2; ++s)
 #pragma unroll
                 for (int n = 0; n < 8; ++n) acc[s][n] = acc_t{0, 0, 0, 0};
+#ifdef TSVGP_DIAG_PANEL
+            unsigned long long ph_t = __builtin_amdgcn_s_memtime();
+#endif
 
             // DEPTH chunks of global prefetch are held in registers (one set of H + H values per chunk in flight).
             // fp64 has room for one set only (128 accumulator registers); fp32 could take two (-DTSVGP_PANEL_DEPTH_F32=2),
@@ -726,6 +763,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void panel_kernel(PanelArgs<T> a) {
                 if (TSVGP_EXP_HASNEXT(c_first + 1 < c_end)) TSVGP_FETCH(1, c_first + 1)
             }
             __syncthreads();
+            TSVGP_PHASE(2, ph_t)
 
             if constexpr (TRI == TSVGP_TRI_DENSE) {
                 for (int c = 0; c < nchunk; c += 2) {
@@ -738,6 +776,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void panel_kernel(PanelArgs<T> a) {
                     TSVGP_STEP(0xFF, 0, c)
                     TSVGP_STEP(0xFF, 1, c + 1)
                 }
+                TSVGP_PHASE(0, ph_t)
                 if constexpr (KC == 16) {
                     TSVGP_STEP(0xFF, 0, cd)
                     TSVGP_STEP(0xFE, 1, cd + 1)
@@ -753,6 +792,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void panel_kernel(PanelArgs<T> a) {
                     TSVGP_STEP2(0xF0, 0xE0, 0, cd + 2)
                     TSVGP_STEP2(0xC0, 0x80, 1, cd + 3)
                 }
+                TSVGP_PHASE(1, ph_t)
             } else {
                 // the diagonal k-tile first: chunk cl only meets column blocks cb <= cl; then full k-tiles it+1..
                 if constexpr (KC == 16) {
@@ -770,10 +810,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void panel_kernel(PanelArgs<T> a) {
                     TSVGP_STEP2(0x1F, 0x3F, 0, cd + 2)
                     TSVGP_STEP2(0x7F, 0xFF, 1, cd + 3)
                 }
+                TSVGP_PHASE(1, ph_t)
                 for (int c = cd + CPT; c < nchunk; c += 2) {
                     TSVGP_STEP(0xFF, 0, c)
                     TSVGP_STEP(0xFF, 1, c + 1)
                 }
+                TSVGP_PHASE(0, ph_t)
             }
 #undef TSVGP_STEP
 #undef TSVGP_STEP2
@@ -820,8 +862,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void panel_kernel(PanelArgs<T> a) {
                     }
                 rs_mine += keep;
             }
+            TSVGP_PHASE(3, ph_t)
         };  // tile_body
         const auto next_of = [ntile](int it) { return it + 1 < ntile ? it + 1 : -1; };
+#ifdef TSVGP_DIAG_PANEL
+        if (p == 0) diag_pre = __builtin_amdgcn_s_memtime() - diag_c0;
+#endif
         if constexpr (FUSE && TRI == TSVGP_TRI_UPPER) {  // upper triangle: the FIRST column tile sweeps every k-chunk
             tile_body(0, std::true_type{}, next_of(0));
             for (int it = 1; it < ntile; ++it) tile_body(it, std::false_type{}, next_of(it));
@@ -832,6 +878,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void panel_kernel(PanelArgs<T> a) {
             for (int it = 0; it < ntile; ++it) tile_body(it, std::false_type{}, next_of(it));
         }
 
+#ifdef TSVGP_DIAG_PANEL
+        diag_post0 = __builtin_amdgcn_s_memtime();
+#endif
         if constexpr (MODE == MODE_MOMENTS) {
             // lane (lr < 8, lane>>4) holds the complete sum of row  row_block(w, lr>>2)*16 + rowmap(lane, lr&3)
             if ((lane & 15) < 8) {
@@ -903,7 +952,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void panel_kernel(PanelArgs<T> a) {
 #ifdef TSVGP_DIAG_PANEL
     // Stamps go to a buffer of their own, passed in place of `mean` (which NO kernel of this build writes: every store
     // through `mean` is compiled out under TSVGP_DIAG_PANEL).  The buffer describes itself: word 0 holds the number of
-    // 4-word slots that follow the 4-word header, and a workgroup whose index is not below it writes nothing.  (Round 2's
+    // 8-word slots that follow the 8-word header, and a workgroup whose index is not below it writes nothing.  (Round 2's
     // stamp write was unchecked, and an experiment's finishing kernel stored its N means through the same pointer: a
     // memory access fault, profiles/r02_moments_split_panel_experiment.txt.)
     if (t == 0 && a.mean) {
@@ -911,12 +960,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void panel_kernel(PanelArgs<T> a) {
         const unsigned long long slots = hdr[0];
         const unsigned long long slot = (unsigned long long)blockIdx.x + (unsigned long long)blockIdx.y * gridDim.x;
         if (slot < slots) {
-            unsigned long long* dbg = hdr + 4 + slot * 4;
+            unsigned long long* dbg = hdr + 8 + slot * 8;
             dbg[0] = diag_t0;
             dbg[1] = __builtin_amdgcn_s_memrealtime();
             dbg[2] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)) |          // HW_REG_HW_ID
                      ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)) << 32);  // HW_REG_XCC_ID
             dbg[3] = __builtin_amdgcn_s_memtime() - diag_c0;  // shader cycles of this workgroup
+            for (int i = 0; i < 4; ++i) dbg[4 + i] = diag_ph[i];  // wave 0's cycles by phase
+            hdr[8 + (slots + slot) * 8 + 0] = diag_pre;  // second bank of slots: before the first tile, after the last
+            hdr[8 + (slots + slot) * 8 + 1] = __builtin_amdgcn_s_memtime() - diag_post0;
         }
     }
 #endif

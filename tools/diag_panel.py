@@ -24,9 +24,9 @@ gam = torch.randn(M, 1, dtype=torch.float64, device=dev)
 Y = torch.randn(rows, 1, dtype=torch.float64, device=dev)
 g0 = torch.empty(Np, 1, dtype=torch.float64, device=dev); g1 = torch.empty_like(g0)
 vep = torch.empty(nwg, dtype=torch.float64, device=dev); npp = torch.empty(nwg, dtype=torch.int32, device=dev)
-# stamp buffer: a 4-word header whose first word is the number of 4-word slots behind it (the kernel checks its slot index
+# stamp buffer: an 8-word header whose first word is the number of 8-word slots behind it (the kernel checks its slot index
 # against it), then one slot per workgroup
-dbg = torch.zeros(4 + nwg * 4, dtype=torch.int64, device=dev)
+dbg = torch.zeros(8 + 2 * nwg * 8, dtype=torch.int64, device=dev)  # header, one bank of per-workgroup slots, a second bank
 dbg[0] = nwg
 lib.tsvgp_moments_f64.argtypes = [vp, vp, vp, vp, ctypes.c_double, ctypes.c_int, ctypes.c_double, vp, vp, vp, vp, vp, vp, i64, i64,
                                   ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]
@@ -42,8 +42,20 @@ e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 5
 print(f"flags {flags} rows {rows}: moments {ms:.3f} ms  {rows * M * (M + 1) / ms / 1e9:.2f} TFLOP/s")
 run(dbg.data_ptr()); torch.cuda.synchronize()
-d = dbg.cpu().numpy()[4:].reshape(nwg, 4)
+d2 = dbg.cpu().numpy()[8 + nwg * 8:].reshape(nwg, 8)
+d = dbg.cpu().numpy()[8:8 + nwg * 8].reshape(nwg, 8)
 assert (d[:, 1] > 0).all(), "a workgroup left no stamp"
+# wave 0's shader cycles by phase (median over workgroups), against the cycles its MFMAs need when two workgroups share a CU
+# (2 x 64 cycles per v_mfma_f64_16x16x4): per workgroup 28 full k-tiles x 8 chunks x 64 MFMAs, 8 diagonal k-tiles x 288 MFMAs
+ph = np.median(d[:, 4:8].astype(np.float64), axis=0)
+tot = np.median(d[:, 3].astype(np.float64))
+nt = M // 128
+full_mfma, diag_mfma = (nt * (nt - 1) // 2) * 8 * 64, nt * 288
+print("wave-0 cycles by phase (median workgroup): full chunks %.0f (MFMA x2: %.0f, use %.3f) | diagonal chunks %.0f (MFMA x2: %.0f, use %.3f) | "
+      "tile prologues %.0f | tile epilogues %.0f | rest %.0f | total %.0f" % (
+          ph[0], 2 * 64 * full_mfma, 2 * 64 * full_mfma / max(ph[0], 1), ph[1], 2 * 64 * diag_mfma, 2 * 64 * diag_mfma / max(ph[1], 1),
+          ph[2], ph[3], tot - ph.sum(), tot))
+print("   rest = before the first tile %.0f + after the last tile %.0f (median cycles)" % (np.median(d2[:, 0]), np.median(d2[:, 1])))
 t0, t1 = d[:, 0].astype(np.float64), d[:, 1].astype(np.float64)
 base = t0.min()
 t0, t1 = (t0 - base) / 100.0, (t1 - base) / 100.0  # microseconds
