@@ -975,6 +975,360 @@ __global__ __launch_bounds__(NTHREADS, 2) void panel_kernel(PanelArgs<T> a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// panel1_kernel (round 3): the fp64 moments of panel_kernel<MOMENTS, UPPER, FUSE> as ONE 256-thread workgroup per CU with a
+// hand-laid instruction stream -- 0.90 of the fp64 MFMA peak where panel_kernel holds 0.83 on the same box
+// (profiles/r03_moments_lab_notes.txt; tools/panel_lab.hip is the bench it was developed in).
+//   * one wave per SIMD (__launch_bounds__(256, 1)): 512 registers per wave, so two fragment register sets, the accumulators
+//     and everything else live without a single scratch access (panel_kernel is pinned at 256 by its partner workgroup);
+//   * the chunk stream of a row panel runs through all column tiles without draining: every MFMA is followed by at most one
+//     other instruction -- a fragment read of the NEXT k-step, an LDS-DMA issue, a piece of the mean -- and
+//     __builtin_amdgcn_sched_barrier(0) pins that order, so a wave keeps the matrix pipe busy on its own:
+//         k-step 0: MFMAs on set X | reads of k-step 1 -> set Y     (+ the mean's LDS reads in column tile 0)
+//         k-step 1: MFMAs on set Y | reads of k-step 2 -> set X     (+ the mean's FMAs)
+//         k-step 2: MFMAs on set X | reads of k-step 3 -> set Y, in the first slots
+//         s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier     (next chunk landed for every wave; this chunk's buffer is free)
+//         k-step 3: MFMAs on set Y | 8 LDS-DMA issues for chunk c + 2 into this chunk's buffer, reads of (c + 1, 0) -> X
+//   * operands go global -> LDS by LDS-DMA (global_load_lds_dwordx4 from inline asm: no staging registers, no ds_write,
+//     and no compiler-inserted vmcnt waits in front of fragment reads of other buffers).  LDS images are
+//     [128 rows][8 units of 16 B], unpadded (a DMA instruction writes 1 KiB lane-linear); the unit index is XOR-ed with
+//     f(row) = (row & 7) ^ ((row >> 3) & 1) on the per-lane global source address and on the reads: conflict free for
+//     ds_read_b64 over each half wave;
+//   * the T fragments of a set are read first and the two A fragments -- operands of the step's LAST MFMAs -- last, and a set's
+//     registers stay occupied to the end of its step: a ds_read landing in an A/B operand register of a
+//     v_mfma_f64_16x16x4_f64 issued just before it corrupted results (the compiler's hazard recognizer does not know it).
+// ---------------------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void lds_void_t;
+constexpr int P1_OPS = TILE * 16;    // doubles per operand image of a chunk (16 KB)
+constexpr int P1_BUFS = 2 * P1_OPS;  // doubles per chunk buffer (A image + T image, 32 KB)
+constexpr size_t P1_GAMMA_LDS_MAX = 64 * 1024;  // dynamic LDS for gamma_p beside the 64 KB ring: Mp <= 8192
+
+template <int I, int N, class F>
+__device__ __forceinline__ void cfor(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        cfor<I + 1, N>(f);
+    }
+}
+constexpr int popc8(int m) { return m ? (m & 1) + popc8(m >> 1) : 0; }
+struct Frag1 {
+    double v[10];  // v[0], v[1]: A fragments of the wave's two row blocks; v[2 + n]: T fragment of column block n
+};
+#define TSVGP_AI __attribute__((always_inline))
+#define TSVGP_IC(x) std::integral_constant<int, (x)>{}
+#define TSVGP_BC(x) std::integral_constant<bool, (x)>{}
+#define TSVGP_SB() __builtin_amdgcn_sched_barrier(0)
+
+__global__ __launch_bounds__(NTHREADS, 1) void panel1_kernel(PanelArgs<double> a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char panel_dyn_smem[];
+    double* const gsm = reinterpret_cast<double*>(panel_dyn_smem);  // gamma_p, Mp doubles
+    __shared__ __attribute__((aligned(1024))) double lds[2 * P1_BUFS];
+    __shared__ double rowq[TILE];
+    __shared__ double rowm[TILE];
+    __shared__ double red[NTHREADS / 64];
+    __shared__ int redi[NTHREADS / 64];
+    constexpr int KC = 16;
+    typedef v4d acc_t;
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int Mp = a.Mp;
+    const int ntile = Mp / TILE, nchunk = Mp / KC;
+    const int64_t n0 = (int64_t)blockIdx.x * TILE;
+    const int srow = t >> 1, skh = t & 1;  // epilogue role: row of the panel, half of the Bernoulli quadrature
+
+    // DMA role: wave w moves the 1-KiB pieces 4 q + w (q = 0..3) of each operand image = rows 32 q + 8 w .. + 7; lane L lands
+    // at unit L & 7 of row (L >> 3) of the piece and fetches the global unit (L & 7) ^ f(row), f(row) = (L >> 3) ^ (w & 1)
+    const int drow = lane >> 3;
+    const int dlog = (lane & 7) ^ drow ^ (w & 1);
+    const unsigned dvoff = (unsigned)((drow * Mp + 2 * dlog) * sizeof(double));
+    const size_t grp = (size_t)32 * Mp * sizeof(double);
+    const unsigned lds_base = (unsigned)(uintptr_t)(lds_void_t*)lds + (unsigned)(w * 1024);
+
+    // fragment reads: row r of a 16-row block, element k = 4 ks + lk of the chunk -> unit (2 ks + (lk >> 1)) ^ f(r), half lk & 1
+    const int lr = lane & 15, lk = lane >> 4;
+    const int fr = (lr & 7) ^ (lr >> 3);
+    int offa0[4], offa1[4], offb[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const int o = lr * 16 + (((2 * ks + (lk >> 1)) ^ fr) << 1) + (lk & 1);
+        offb[ks] = o + P1_OPS;
+        offa0[ks] = o + w * 256;
+        offa1[ks] = o + (7 - w) * 256;
+    }
+    // mean (column tile 0): the thread reads the 16-byte unit t & 7 of rows 32 q + (t >> 3) of the landed A image; behind
+    // that physical unit sits the logical unit glog (columns 2 glog, 2 glog + 1 of the chunk)
+    const int glog = (t & 7) ^ ((t >> 3) & 7) ^ (w & 1);
+
+    double ve_acc = 0.0;
+    int nonpos = 0;
+
+    for (int p = 0; p < a.P; ++p) {
+        const double* Tp = a.Tm + (size_t)p * Mp * Mp;
+        const char* Ab = reinterpret_cast<const char*>(a.A + (size_t)p * a.strideA + (n0 + 8 * w) * (int64_t)Mp);
+        __syncthreads();  // the previous latent's readers of gsm / rowq / rowm are done
+        for (int j = t; j < Mp; j += NTHREADS) gsm[j] = a.gamma[(size_t)j * a.P + p];
+
+        struct Cursor {
+            int it, c;
+        } cf{0, 0};  // fetch position in the chunk stream of this panel: column tile, k-chunk (tile it: chunks 8 it .. nchunk - 1)
+        // DMA addresses: one per-lane byte offset (VGPR) + wave-uniform 64-bit bases.  The bases are made scalar HERE, at the
+        // start of a chunk (readfirstlane of both halves; the casts matter: readfirstlane returns int, and an int low half would
+        // be sign-extended into the high one), long before the LDS-DMA instructions of k-step 3 read them: a scalar register
+        // written by a vector instruction needs five wait states in front of a memory instruction that reads it, and nothing
+        // inserts them inside an asm statement.
+        auto uni64 = [](const void* ptr) TSVGP_AI {
+            const uint64_t v = (uint64_t)(uintptr_t)ptr;
+            return ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+                   (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+        };
+        const uint64_t ab_u = uni64(Ab);
+        const unsigned lds_u = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_base);
+        unsigned dma_vo = 0;
+        uint64_t tb_u = 0;
+        auto dma_setup = [&](const Cursor cu) TSVGP_AI {
+            dma_vo = dvoff + (unsigned)(cu.c * KC * sizeof(double));
+            tb_u = uni64(Tp + ((size_t)cu.it * TILE + 8 * w) * Mp);
+        };
+        auto dma_piece = [&](auto i_tag, const int buf) TSVGP_AI {  // piece I of a chunk: I even -> A piece I / 2, I odd -> T piece
+            constexpr int I = decltype(i_tag)::value, q = I >> 1;
+            const unsigned la = lds_u + (unsigned)((buf * P1_BUFS + q * 512 + (I & 1) * P1_OPS) * sizeof(double));
+            const uint64_t g = ((I & 1) ? tb_u : ab_u) + q * grp;
+            const unsigned vo_ = dma_vo;  // (an asm operand alone does not capture a variable in a generic lambda)
+            // one wait state between the write of M0 and the LDS-DMA that reads it
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(la), "v"(vo_), "s"(g) : "memory");
+        };
+        auto advance = [&](Cursor& cu) TSVGP_AI {  // saturates at the last chunk (a harmless re-fetch into a dead buffer)
+            if (cu.c + 1 == nchunk) {
+                if (cu.it + 1 < ntile) {
+                    ++cu.it;
+                    cu.c = cu.it * (TILE / KC);
+                }
+            } else {
+                ++cu.c;
+            }
+        };
+
+        acc_t acc[2][8];
+        Frag1 fx, fy;
+        double rs_mine = 0.0;
+        double mpart[4] = {0, 0, 0, 0};
+        v2d gx[4], gg;  // the mean's operands in flight (column tile 0)
+
+        auto rd1 = [&](Frag1& f, auto e_tag, auto ks_tag, const int boff) TSVGP_AI {
+            constexpr int E = decltype(e_tag)::value, KS = decltype(ks_tag)::value;
+            if constexpr (E == 0) f.v[0] = lds[offa0[KS] + boff];
+            else if constexpr (E == 1) f.v[1] = lds[offa1[KS] + boff];
+            else f.v[E] = lds[offb[KS] + boff + (E - 2) * 256];
+        };
+        // slot S of a k-step's reads -> element of the set: T fragments first, the two A fragments last (see the header)
+        auto rds = [&](Frag1& f, auto slot_tag, auto m_tag, auto ks_tag, const int boff) TSVGP_AI {
+            constexpr int S = decltype(slot_tag)::value, MM = decltype(m_tag)::value;
+            if constexpr (S < MM) rd1(f, TSVGP_IC(2 + S), ks_tag, boff);
+            else rd1(f, TSVGP_IC(S - MM), ks_tag, boff);
+        };
+        auto keep_set = [&](const Frag1& f, auto m_tag) TSVGP_AI {  // the set's registers stay occupied up to this point
+            cfor<0, 2 + decltype(m_tag)::value>([&](auto e) TSVGP_AI {
+                const double x = f.v[decltype(e)::value];
+                asm volatile("" ::"v"(x));
+            });
+        };
+        auto mf = [&](const Frag1& f, auto i_tag) TSVGP_AI {  // MFMA I of a k-step: column block I / 2, row block I % 2
+            constexpr int I = decltype(i_tag)::value, n = I >> 1, sblk = I & 1;
+            acc[sblk][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.v[sblk], f.v[2 + n], acc[sblk][n], 0, 0, 0);
+        };
+        // One chunk of the stream.  M: its column-block mask (upper form: blocks 0 .. m - 1); MN: the mask of the NEXT chunk of
+        // the stream (0: none); BUF: its LDS buffer (parity of the chunk index); GC: it belongs to column tile 0 (its A image
+        // feeds the mean); c_this: its k-chunk index.  On entry set X holds the fragments of its k-step 0.
+        auto chunk = [&](auto m_tag, auto mn_tag, auto buf_tag, auto gc_tag, const int c_this) TSVGP_AI {
+            constexpr int M = decltype(m_tag)::value, MN = decltype(mn_tag)::value, BUF = decltype(buf_tag)::value;
+            constexpr bool GC = decltype(gc_tag)::value;
+            constexpr int m = popc8(M), mn = popc8(MN), NM = 2 * m, NR = 2 + m, NRN = 2 + mn;
+            constexpr int B0 = BUF * P1_BUFS, B1 = (BUF ^ 1) * P1_BUFS;
+            if constexpr (MN != 0) {  // the DMA addresses of chunk c + 2: scalar work in front of the first MFMAs
+                dma_setup(cf);
+                advance(cf);
+                TSVGP_SB();
+            }
+            constexpr int S0 = NR + (GC ? 5 : 0);
+            cfor<0, (NM > S0 ? NM : S0)>([&](auto i) TSVGP_AI {
+                constexpr int I = decltype(i)::value;
+                if constexpr (I < NM) mf(fx, i);
+                if constexpr (I < NR) rds(fy, i, TSVGP_IC(m), TSVGP_IC(1), B0);
+                else if constexpr (GC && I == NR) gg = *reinterpret_cast<const v2d*>(gsm + c_this * KC + 2 * glog);
+                else if constexpr (GC && I > NR && I < NR + 5) gx[I - NR - 1] = *reinterpret_cast<const v2d*>(lds + B0 + (I - NR - 1) * 512 + t * 2);
+                TSVGP_SB();
+            });
+            keep_set(fx, TSVGP_IC(m));
+            constexpr int S1 = NR + (GC ? 4 : 0);
+            cfor<0, (NM > S1 ? NM : S1)>([&](auto i) TSVGP_AI {
+                constexpr int I = decltype(i)::value;
+                if constexpr (I < NM) mf(fy, i);
+                if constexpr (I < NR) rds(fx, i, TSVGP_IC(m), TSVGP_IC(2), B0);
+                else if constexpr (GC && I < NR + 4) mpart[I - NR] += gx[I - NR][0] * gg[0] + gx[I - NR][1] * gg[1];
+                TSVGP_SB();
+            });
+            keep_set(fy, TSVGP_IC(m));
+            cfor<0, (NM > NR ? NM : NR)>([&](auto i) TSVGP_AI {
+                constexpr int I = decltype(i)::value;
+                if constexpr (I < NM) mf(fx, i);
+                if constexpr (I < NR) rds(fy, i, TSVGP_IC(m), TSVGP_IC(3), B0);
+                TSVGP_SB();
+            });
+            keep_set(fx, TSVGP_IC(m));
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            TSVGP_SB();
+            if constexpr (MN != 0) {
+                constexpr int S3 = 8 + NRN;
+                cfor<0, (NM > S3 ? NM : S3)>([&](auto i) TSVGP_AI {
+                    constexpr int I = decltype(i)::value;
+                    if constexpr (I < NM) mf(fy, i);
+                    if constexpr (I < 8) dma_piece(i, BUF);
+                    else if constexpr (I < S3) rds(fx, TSVGP_IC(I - 8), TSVGP_IC(mn), TSVGP_IC(0), B1);
+                    TSVGP_SB();
+                });
+            } else {
+                cfor<0, NM>([&](auto i) TSVGP_AI { mf(fy, i); });
+            }
+            keep_set(fy, TSVGP_IC(m));
+        };
+
+        // prologue: chunks (0, 0) and (0, 1) on their way into the two buffers, the first fragments read
+        dma_setup(cf);
+        cfor<0, 8>([&](auto i) TSVGP_AI { dma_piece(i, 0); });
+        advance(cf);
+        dma_setup(cf);
+        cfor<0, 8>([&](auto i) TSVGP_AI { dma_piece(i, 1); });
+        advance(cf);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();  // both chunks and gamma are in LDS for every wave
+        cfor<0, 3>([&](auto i) TSVGP_AI { rd1(fx, i, TSVGP_IC(0), 0); });  // a0, a1, b0 of chunk (0, 0)
+
+        for (int it = 0; it < ntile; ++it) {
+            const int cd = it * (TILE / KC);
+            const bool last_tile = it + 1 == ntile;
+            // an accumulator is zeroed in front of the diagonal chunk that first touches its column block
+#define TSVGP_ZACC(n_) { acc[0][n_] = acc_t{0, 0, 0, 0}; acc[1][n_] = acc_t{0, 0, 0, 0}; }
+            auto diag = [&](auto gc) TSVGP_AI {
+                TSVGP_ZACC(0) chunk(TSVGP_IC(0x01), TSVGP_IC(0x03), TSVGP_IC(0), gc, cd);
+                TSVGP_ZACC(1) chunk(TSVGP_IC(0x03), TSVGP_IC(0x07), TSVGP_IC(1), gc, cd + 1);
+                TSVGP_ZACC(2) chunk(TSVGP_IC(0x07), TSVGP_IC(0x0F), TSVGP_IC(0), gc, cd + 2);
+                TSVGP_ZACC(3) chunk(TSVGP_IC(0x0F), TSVGP_IC(0x1F), TSVGP_IC(1), gc, cd + 3);
+                TSVGP_ZACC(4) chunk(TSVGP_IC(0x1F), TSVGP_IC(0x3F), TSVGP_IC(0), gc, cd + 4);
+                TSVGP_ZACC(5) chunk(TSVGP_IC(0x3F), TSVGP_IC(0x7F), TSVGP_IC(1), gc, cd + 5);
+                TSVGP_ZACC(6) chunk(TSVGP_IC(0x7F), TSVGP_IC(0xFF), TSVGP_IC(0), gc, cd + 6);
+                TSVGP_ZACC(7)
+                if (!last_tile) chunk(TSVGP_IC(0xFF), TSVGP_IC(0xFF), TSVGP_IC(1), gc, cd + 7);
+                else chunk(TSVGP_IC(0xFF), TSVGP_IC(0), TSVGP_IC(1), gc, cd + 7);  // the end of the stream
+            };
+            auto full = [&](auto gc) TSVGP_AI {  // the full k-tiles behind the diagonal one; the next column tile's first chunk follows
+                const int c_last = nchunk - 1;
+                for (int c = cd + 8; c < c_last - 1; c += 2) {
+                    chunk(TSVGP_IC(0xFF), TSVGP_IC(0xFF), TSVGP_IC(0), gc, c);
+                    chunk(TSVGP_IC(0xFF), TSVGP_IC(0xFF), TSVGP_IC(1), gc, c + 1);
+                }
+                chunk(TSVGP_IC(0xFF), TSVGP_IC(0xFF), TSVGP_IC(0), gc, c_last - 1);
+                chunk(TSVGP_IC(0xFF), TSVGP_IC(0x01), TSVGP_IC(1), gc, c_last);
+            };
+#undef TSVGP_ZACC
+            if (it == 0) {
+                diag(TSVGP_BC(true));
+                if (!last_tile) full(TSVGP_BC(true));
+            } else {
+                diag(TSVGP_BC(false));
+                if (!last_tile) full(TSVGP_BC(false));
+            }
+            // the column tile is complete: squares of its entries, summed per row (as panel_kernel)
+            double keep = 0.0;
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    double q = 0.0;
+#pragma unroll
+                    for (int n = 0; n < 8; ++n) q += acc[s][n][r] * acc[s][n][r];
+                    q += __shfl_xor(q, 1);
+                    q += __shfl_xor(q, 2);
+                    q += __shfl_xor(q, 4);
+                    q += __shfl_xor(q, 8);
+                    keep = ((lane & 7) == s * 4 + r) ? q : keep;
+                }
+            rs_mine += keep;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the saturated re-fetches of the last two chunks have landed
+
+        // row sums and means to LDS, then the likelihood map of panel_kernel's epilogue (two threads per row)
+        if ((lane & 15) < 8) {
+            const int l8 = lane & 15;
+            rowq[row_block(w, l8 >> 2) * 16 + Mfma<double>::row(lane, l8 & 3)] = rs_mine;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            mpart[q] += __shfl_xor(mpart[q], 1);
+            mpart[q] += __shfl_xor(mpart[q], 2);
+            mpart[q] += __shfl_xor(mpart[q], 4);
+        }
+        if ((t & 7) == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rowm[q * 32 + (t >> 3)] = mpart[q];
+        }
+        __syncthreads();
+        {
+            const int64_t n = n0 + srow;
+            const bool live = n < a.N;
+            const double q = rowq[srow];
+            const double mu = rowm[srow];
+            const double v = a.kdiag[a.kdiag_uniform ? 0 : p] - q;
+            double g0 = 0.0, g1 = 0.0, ve = 0.0;
+            if ((a.lik & 0xFF) == TSVGP_LIK_BERNOULLI) {
+                double a0, a1, av;
+                const double sd = sqrt(live ? v : 1.0);
+                bern_sums(live ? mu : 0.0, sd, live && a.Y[n * a.P + p] == 1.0, skh * 5, skh * 5 + 5, a0, a1, av);
+                a0 += __shfl_xor(a0, 1);
+                a1 += __shfl_xor(a1, 1);
+                av += __shfl_xor(av, 1);
+                g0 = a0;
+                g1 = a1 / (2.0 * sd);
+                if (!(a.lik & TSVGP_LIK_NOCROP)) g1 = fmin(g1, -1e-8);  // reference tsvgp.py:262-263
+                ve = av;
+            } else if (a.lik != TSVGP_LIK_NONE && live) {
+                lik_eval(a.lik, a.lik_param, mu, v, a.Y[n * a.P + p], g0, g1, ve);
+            }
+            if (skh == 0) {
+                if (live) {
+                    if (!(v > 0.0)) nonpos += 1;
+                    if (a.mean) a.mean[n * a.P + p] = mu;
+                    if (a.var) a.var[n * a.P + p] = v;
+                    ve_acc += ve;
+                }
+                if (a.lik != TSVGP_LIK_NONE) {
+                    a.g0[n * a.P + p] = live ? g0 : 0.0;  // rows >= N: zeros (the padding contract of site_accum)
+                    a.g1[n * a.P + p] = live ? g1 : 0.0;
+                }
+            }
+        }
+    }  // p
+
+    double s = ve_acc;
+    int c = nonpos;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_xor(s, o);
+        c += __shfl_xor(c, o);
+    }
+    if (lane == 0) {
+        red[w] = s;
+        redi[w] = c;
+    }
+    __syncthreads();
+    if (t == 0) {
+        if (a.ve_partial) a.ve_partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+        if (a.nonpos_partial) a.nonpos_partial[blockIdx.x] = redi[0] + redi[1] + redi[2] + redi[3];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // mean_lik_kernel (TSVGP_LIK_MEANONLY): mean[n, p] = sum_j A[n, j] * gamma[j, p] and, for the Gaussian likelihood,
 // g0 = (y - mean) / s2, g1 = -1 / (2 s2) -- neither depends on the predictive variance.  HBM bound: one sweep of A.
 // One workgroup per 128-row panel (same grid as panel_kernel, so the per-workgroup partial buffers keep their
@@ -2236,6 +2590,16 @@ int moments(const T* A, int64_t strideA, const T* Tm, const T* gamma, const T* Y
                            (hipStream_t)stream, a);
     else if (mode == TSVGP_TRI_LOWER)
         hipLaunchKernelGGL((panel_kernel<T, MODE_MOMENTS, TSVGP_TRI_LOWER>), grid, block, 0, (hipStream_t)stream, a);
+#ifndef TSVGP_MOMENTS_OLD  // (-DTSVGP_MOMENTS_OLD: A/B builds keep round 2's panel_kernel on this path)
+    else if (mode == TSVGP_TRI_UPPER && sizeof(T) == 8 && (size_t)Mp * sizeof(T) <= P1_GAMMA_LDS_MAX) {
+        // fp64, upper form: one workgroup per CU with the hand-laid instruction stream (panel1_kernel)
+        if constexpr (sizeof(T) == 8) {
+            static DynLdsOptIn optin1;
+            if (optin1.ensure(reinterpret_cast<const void*>(&panel1_kernel), P1_GAMMA_LDS_MAX) != TSVGP_OK) return TSVGP_ELAUNCH;
+            hipLaunchKernelGGL(panel1_kernel, grid, block, (size_t)Mp * sizeof(T), (hipStream_t)stream, a);
+        }
+    }
+#endif
     else if (mode == TSVGP_TRI_UPPER && (size_t)Mp * sizeof(T) <= 8192)
         // gamma fits beside the staging buffers without costing the second workgroup per CU: fused mean
         hipLaunchKernelGGL((panel_kernel<T, MODE_MOMENTS, TSVGP_TRI_UPPER, true>), grid, block, (size_t)Mp * sizeof(T),

@@ -713,6 +713,282 @@ __global__ __launch_bounds__(NT, LAB_OCC) void moments_dma2(const double* __rest
     }
 }
 
+struct Cursor3 { int pn, it, c; };  // panel, column tile, k-chunk
+
+template <int DUMMY = 0>
+__global__ __launch_bounds__(NT, 1) void moments_p1(const double* __restrict__ A, const double* __restrict__ Tm,
+                                                      const double* __restrict__ gamma, double* __restrict__ qout,
+                                                      double* __restrict__ mout, int Mp, int npanel) {
+    extern __shared__ __attribute__((aligned(16))) double gsm[];
+    __shared__ __attribute__((aligned(1024))) double lds[4 * DBUFS];  // ring of four chunk buffers (128 KB): three chunks in flight
+    __shared__ double rowq[TILE];
+    const int t = threadIdx.x, lane = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int ntile = Mp / TILE, nchunk = Mp / KC;
+
+    const int drow = lane >> 3;
+    const int dlog = (lane & 7) ^ drow ^ (w & 1);
+    const unsigned dvoff = (unsigned)((drow * Mp + 2 * dlog) * sizeof(double));
+    const char* Abase = reinterpret_cast<const char*>(A + (size_t)8 * w * Mp);
+    const size_t panel_bytes = (size_t)TILE * Mp * sizeof(double);
+    const size_t grp = (size_t)32 * Mp * sizeof(double);
+
+    const int lr = lane & 15, lk = lane >> 4;
+    const int fr = (lr & 7) ^ (lr >> 3);
+    int offa0[4], offa1[4], offb[4], offa0_hi[4], offa1_hi[4], offb_hi[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const int o = lr * 16 + (((2 * ks + (lk >> 1)) ^ fr) << 1) + (lk & 1);
+        offb[ks] = o + DOPS;
+        offa0[ks] = o + w * 256;
+        offa1[ks] = o + (7 - w) * 256;
+        offb_hi[ks] = offb[ks] + 2 * DBUFS;
+        offa0_hi[ks] = offa0[ks] + 2 * DBUFS;
+        offa1_hi[ks] = offa1[ks] + 2 * DBUFS;
+    }
+    const int glog = (t & 7) ^ ((t >> 3) & 7) ^ (w & 1);
+
+    for (int j = t; j < Mp; j += NT) gsm[j] = gamma[j];
+
+    double mpart[4] = {0, 0, 0, 0};
+    const unsigned lds_base = (unsigned)(uintptr_t)(lds_void_t*)lds + (unsigned)(w * 1024);
+    // DMA piece i (0..7) of chunk `cu` into buffer `buf`: i even -> A piece q = i / 2, i odd -> T piece q
+    unsigned dma_vo = 0;
+    const char* dma_tb = nullptr;
+    const char* dma_ab = nullptr;
+    auto dma_setup = [&](const Cursor3 cu) __attribute__((always_inline)) {
+        dma_vo = dvoff + (unsigned)(cu.c * KC * sizeof(double));
+        dma_tb = reinterpret_cast<const char*>(Tm + ((size_t)cu.it * TILE + 8 * w) * Mp);
+        dma_ab = Abase + (size_t)cu.pn * panel_bytes;
+    };
+    auto dma_piece = [&](auto i_tag, const int buf) __attribute__((always_inline)) {
+        constexpr int I = decltype(i_tag)::value, q = I >> 1;
+        const unsigned la = lds_base + (unsigned)((buf * DBUFS + q * 512 + (I & 1) * DOPS) * sizeof(double));
+        const char* g = ((I & 1) ? dma_tb : dma_ab) + q * grp;
+        const unsigned vo_ = dma_vo;  // (an asm operand alone does not capture a variable in a generic lambda)
+        // the "s" constraint does not move a value the compiler keeps in vector registers: say that these are wave-uniform
+        const unsigned la_u = __builtin_amdgcn_readfirstlane(la);
+        const uint64_t gv = (uint64_t)(uintptr_t)g;
+        // (readfirstlane returns int: without the casts to unsigned the low half is SIGN-extended into the high one -- a wild
+        // address whenever bit 31 of the low half is set: the memory access fault of gpurun_out/r3c/lab2_1e6.txt)
+        const uint64_t g_u = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(gv >> 32)) << 32) |
+                             (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)gv);
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(la_u), "v"(vo_), "s"(g_u) : "memory");
+    };
+    auto advance = [&](Cursor3& cu) __attribute__((always_inline)) {  // saturates at the last chunk of the stream (a harmless re-fetch into a dead buffer)
+        if (cu.c + 1 == nchunk) {
+            if (cu.it + 1 < ntile) {
+                ++cu.it;
+                cu.c = cu.it * (TILE / KC);
+            } else if (cu.pn + (int)gridDim.x < npanel) {
+                cu.pn += (int)gridDim.x;
+                cu.it = 0;
+                cu.c = 0;
+            }
+        } else {
+            ++cu.c;
+        }
+    };
+
+    v4d acc[2][8];
+    Frag2 fx, fy;
+    Cursor3 cf{(int)blockIdx.x, 0, 0};
+    double rs_mine = 0.0;
+
+    // element E of the fragment set of k-step KS in buffer byte-offset-free form (doubles)
+    auto rd1 = [&](Frag2& f, auto e_tag, auto ks_tag, auto buf_tag) __attribute__((always_inline)) {
+        constexpr int E = decltype(e_tag)::value, KS = decltype(ks_tag)::value, RB = decltype(buf_tag)::value;
+        constexpr int boff = (RB & 1) * DBUFS;
+        if constexpr (RB < 2) {
+            if constexpr (E == 0) f.v[0] = lds[offa0[KS] + boff];
+            else if constexpr (E == 1) f.v[1] = lds[offa1[KS] + boff];
+            else f.v[E] = lds[offb[KS] + boff + (E - 2) * 256];
+        } else {
+            if constexpr (E == 0) f.v[0] = lds[offa0_hi[KS] + boff];
+            else if constexpr (E == 1) f.v[1] = lds[offa1_hi[KS] + boff];
+            else f.v[E] = lds[offb_hi[KS] + boff + (E - 2) * 256];
+        }
+    };
+    // MFMA number I (0 .. 2 m - 1) of a k-step on set f: column block I / 2, row block I % 2
+    auto mf = [&](const Frag2& f, auto i_tag) __attribute__((always_inline)) {
+        constexpr int I = decltype(i_tag)::value, n = I >> 1, sblk = I & 1;
+        acc[sblk][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.v[sblk], f.v[2 + n], acc[sblk][n], 0, 0, 0);
+    };
+
+    // slot i of a k-step's reads -> element of the set: the T fragments first (they were consumed early in the previous use of
+    // the set), the two A fragments -- operands of that step's LAST MFMAs -- last
+    auto rds = [&](Frag2& f, auto slot_tag, auto m_tag, auto ks_tag, auto boff) __attribute__((always_inline)) {
+        constexpr int S = decltype(slot_tag)::value, MM = decltype(m_tag)::value;
+        if constexpr (S < MM) rd1(f, IC(2 + S), ks_tag, boff);
+        else rd1(f, IC(S - MM), ks_tag, boff);
+    };
+    // keeps the registers of a set occupied up to this point (they are not handed to the reads issued during the step)
+    auto keep_set = [&](const Frag2& f, auto m_tag) __attribute__((always_inline)) {
+#ifndef LAB_NOKEEP
+        cfor<0, 2 + decltype(m_tag)::value>([&](auto e) __attribute__((always_inline)) {
+            const double x = f.v[decltype(e)::value];  // (an asm operand alone does not capture)
+            asm volatile("" ::"v"(x));
+        });
+#endif
+    };
+    v2d gx[4], gg;  // the mean's operands in flight (column tile 0)
+    auto chunk = [&](auto m_tag, auto mn_tag, auto buf_tag, auto gc_tag, const int c_this) __attribute__((always_inline)) {
+        constexpr int M = decltype(m_tag)::value, MN = decltype(mn_tag)::value, BUF = decltype(buf_tag)::value;
+        constexpr bool GC = decltype(gc_tag)::value;
+        constexpr int m = popc(M), mn = popc(MN), NM = 2 * m, NR = 2 + m, NRN = 2 + mn;
+        constexpr int B0 = BUF * DBUFS;
+        constexpr auto RB0 = IC(BUF);
+        constexpr auto RB1 = IC((BUF + 1) & 3);
+        // k-step 0 (the DMA addresses of chunk c + 2 are scalar work: in front of the first MFMAs, not behind the barrier)
+        if constexpr (MN != 0) {
+            dma_setup(cf);
+            advance(cf);
+            SB();
+        }
+        constexpr int S0 = NR + (GC ? 5 : 0);
+        cfor<0, (NM > S0 ? NM : S0)>([&](auto i) __attribute__((always_inline)) {
+            constexpr int I = decltype(i)::value;
+            if constexpr (I < NM) mf(fx, i);
+            if constexpr (I < NR) rds(fy, i, IC(m), IC(1), RB0);
+            else if constexpr (GC && I == NR) gg = *reinterpret_cast<const v2d*>(gsm + c_this * KC + 2 * glog);
+            else if constexpr (GC && I > NR && I < NR + 5) gx[I - NR - 1] = *reinterpret_cast<const v2d*>(lds + B0 + (I - NR - 1) * 512 + t * 2);
+            SB();
+        });
+        keep_set(fx, IC(m));
+        // k-step 1
+        constexpr int S1 = NR + (GC ? 4 : 0);
+        cfor<0, (NM > S1 ? NM : S1)>([&](auto i) __attribute__((always_inline)) {
+            constexpr int I = decltype(i)::value;
+            if constexpr (I < NM) mf(fy, i);
+            if constexpr (I < NR) rds(fx, i, IC(m), IC(2), RB0);
+            else if constexpr (GC && I < NR + 4) mpart[I - NR] += gx[I - NR][0] * gg[0] + gx[I - NR][1] * gg[1];
+            SB();
+        });
+        keep_set(fy, IC(m));
+        // k-step 2
+        cfor<0, (NM > NR ? NM : NR)>([&](auto i) __attribute__((always_inline)) {
+            constexpr int I = decltype(i)::value;
+            if constexpr (I < NM) mf(fx, i);
+            if constexpr (I < NR) rds(fy, i, IC(m), IC(3), RB0);
+            SB();
+        });
+        keep_set(fx, IC(m));
+        // chunk c + 1 has landed for this wave (c + 2, c + 3: up to 16 DMA pieces may still fly)
+        asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        SB();
+        // k-step 3
+        if constexpr (MN != 0) {
+            constexpr int S3 = 8 + NRN;
+            cfor<0, (NM > S3 ? NM : S3)>([&](auto i) __attribute__((always_inline)) {
+                constexpr int I = decltype(i)::value;
+                if constexpr (I < NM) mf(fy, i);
+                if constexpr (I < 8) dma_piece(i, BUF);
+                else if constexpr (I < S3) rds(fx, IC(I - 8), IC(mn), IC(0), RB1);
+                SB();
+            });
+        } else {
+            cfor<0, NM>([&](auto i) __attribute__((always_inline)) { mf(fy, i); });
+        }
+        keep_set(fy, IC(m));
+    };
+
+    // prologue
+    cfor<0, 4>([&](auto b) __attribute__((always_inline)) {
+        dma_setup(cf);
+        cfor<0, 8>([&](auto i) __attribute__((always_inline)) { dma_piece(i, decltype(b)::value); });
+        advance(cf);
+    });
+    asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    cfor<0, 3>([&](auto i) __attribute__((always_inline)) { rd1(fx, i, IC(0), IC(0)); });  // a0, a1, b0 of the first chunk
+
+    for (int pn = (int)blockIdx.x; pn < npanel; pn += (int)gridDim.x) {
+        const int64_t n0 = (int64_t)pn * TILE;
+        const bool last_panel = pn + (int)gridDim.x >= npanel;
+        rs_mine = 0.0;
+        for (int it = 0; it < ntile; ++it) {
+            const int cd = it * (TILE / KC);
+            const bool last_tile = it + 1 == ntile;
+#define ZACC(n_) { acc[0][n_] = v4d{0, 0, 0, 0}; acc[1][n_] = v4d{0, 0, 0, 0}; }
+            auto diag = [&](auto gc) __attribute__((always_inline)) {
+                ZACC(0) chunk(IC(0x01), IC(0x03), IC(0), gc, cd);
+                ZACC(1) chunk(IC(0x03), IC(0x07), IC(1), gc, cd + 1);
+                ZACC(2) chunk(IC(0x07), IC(0x0F), IC(2), gc, cd + 2);
+                ZACC(3) chunk(IC(0x0F), IC(0x1F), IC(3), gc, cd + 3);
+                ZACC(4) chunk(IC(0x1F), IC(0x3F), IC(0), gc, cd + 4);
+                ZACC(5) chunk(IC(0x3F), IC(0x7F), IC(1), gc, cd + 5);
+                ZACC(6) chunk(IC(0x7F), IC(0xFF), IC(2), gc, cd + 6);
+                ZACC(7)
+                if (!last_tile) chunk(IC(0xFF), IC(0xFF), IC(3), gc, cd + 7);
+                else if (!last_panel) chunk(IC(0xFF), IC(0x01), IC(3), gc, cd + 7);  // the next panel's first chunk follows
+                else chunk(IC(0xFF), IC(0), IC(3), gc, cd + 7);
+            };
+            auto full = [&](auto gc) __attribute__((always_inline)) {
+                const int c_last = nchunk - 1;
+                for (int c = cd + 8; c < c_last - 3; c += 4) {
+                    chunk(IC(0xFF), IC(0xFF), IC(0), gc, c);
+                    chunk(IC(0xFF), IC(0xFF), IC(1), gc, c + 1);
+                    chunk(IC(0xFF), IC(0xFF), IC(2), gc, c + 2);
+                    chunk(IC(0xFF), IC(0xFF), IC(3), gc, c + 3);
+                }
+                chunk(IC(0xFF), IC(0xFF), IC(0), gc, c_last - 3);
+                chunk(IC(0xFF), IC(0xFF), IC(1), gc, c_last - 2);
+                chunk(IC(0xFF), IC(0xFF), IC(2), gc, c_last - 1);
+                chunk(IC(0xFF), IC(0x01), IC(3), gc, c_last);  // the next column tile's first chunk follows
+            };
+            if (it == 0) {
+                diag(BC(true));
+                if (!last_tile) full(BC(true));
+            } else {
+                diag(BC(false));
+                if (!last_tile) full(BC(false));
+            }
+            double keep = 0.0;
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    double q = 0.0;
+#pragma unroll
+                    for (int n = 0; n < 8; ++n) q += acc[s][n][r] * acc[s][n][r];
+                    q += __shfl_xor(q, 1);
+                    q += __shfl_xor(q, 2);
+                    q += __shfl_xor(q, 4);
+                    q += __shfl_xor(q, 8);
+                    keep = ((lane & 7) == s * 4 + r) ? q : keep;
+                }
+            rs_mine += keep;
+        }
+        // end of the row panel: its outputs (the DMA ring keeps running: the next panel's first chunks are on their way)
+        if ((lane & 15) < 8) {
+            const int l8 = lane & 15;
+            rowq[((l8 >> 2) == 0 ? w : 7 - w) * 16 + (lane >> 4) + 4 * (l8 & 3)] = rs_mine;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            mpart[q] += __shfl_xor(mpart[q], 1);
+            mpart[q] += __shfl_xor(mpart[q], 2);
+            mpart[q] += __shfl_xor(mpart[q], 4);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t < TILE) qout[n0 + t] = rowq[t];
+        if ((t & 7) == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) mout[n0 + q * 32 + (t >> 3)] = mpart[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) mpart[q] = 0.0;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // rowq is free again
+        asm volatile("" ::: "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the saturated re-fetches of the last chunks
+}
+
 typedef int (*moments_fn)(const double*, const double*, const double*, const double*, double, int, double, double*, double*, double*,
                           double*, double*, int32_t*, int64_t, int64_t, int, int, int, void*);
 
@@ -754,6 +1030,8 @@ int main(int argc, char** argv) {
     auto run_alt = [&]() { int rc = alt(A, T, g, Y, 1e9, 1, 0.1, mean, var, g0, g1, vep, npp, rows, Np, M, 1, 1, nullptr); if (rc) { printf("alt rc %d\n", rc); exit(1); } };
     auto run_dma = [&]() { hipLaunchKernelGGL((moments_dma<0>), dim3((unsigned)(Np / 128)), dim3(NT), (size_t)M * 8, 0, A, T, g, q, m, M); };
     auto run_dma2 = [&]() { hipLaunchKernelGGL((moments_dma2<0>), dim3((unsigned)(Np / 128)), dim3(NT), (size_t)M * 8, 0, A, T, g, q, m, M); };
+    int p1_grid = getenv("LAB_P1_GRID") ? atoi(getenv("LAB_P1_GRID")) : 256;
+    auto run_p1 = [&]() { const int np = (int)(Np / 128); hipLaunchKernelGGL((moments_p1<0>), dim3((unsigned)std::min(np, p1_grid)), dim3(NT), (size_t)M * 8, 0, A, T, g, q, m, M, np); };
     auto run_pipe = [&]() { hipLaunchKernelGGL((moments_pipe<0>), dim3((unsigned)(Np / 128)), dim3(NT), (size_t)M * 8, 0, A, T, g, q, m, M); };
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
@@ -801,6 +1079,15 @@ int main(int argc, char** argv) {
         }
         printf("   rows off by more than 1e-6: %lld of %lld\n", bad, (long long)rows);
     }
+    CHECK(hipMemset(q, 0, Np * 8)); CHECK(hipMemset(m, 0, Np * 8));
+    run_p1(); CHECK(hipDeviceSynchronize()); CHECK(hipGetLastError());
+    CHECK(hipMemcpy(hq.data(), q, Np * 8, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(hm.data(), m, Np * 8, hipMemcpyDeviceToHost));
+    eq = em = 0;
+    for (int64_t n = 0; n < rows; ++n) {
+        eq = std::max(eq, std::fabs((1e9 - hq[n]) - hvar[n]));
+        em = std::max(em, std::fabs(hm[n] - hmean[n]));
+    }
+    printf("p1   rows %lld: max |q - q_prod| %.3e   max |mean - mean_prod| %.3e\n", (long long)rows, eq, em);
     const double flop = (double)rows * M * (M + 1) + 2.0 * rows * M;
     if (alt) {
         std::vector<double> hm2(Np), hv2(Np);
@@ -817,9 +1104,9 @@ int main(int argc, char** argv) {
         return 0;
     }
     for (int round = 0; round < 4; ++round) {
-        const float tp = timeit(run_prod, 5), td = timeit(run_dma, 5), t2 = timeit(run_dma2, 5);
-        printf("round %d: production %.3f ms (%.2f TFLOP/s, %.3f of 78.6)   dma %.3f ms (%.3f)   dma2 %.3f ms (%.2f TFLOP/s, %.3f)\n", round, tp,
-               flop / tp / 1e9, flop / tp / 1e9 / 78.6, td, flop / td / 1e9 / 78.6, t2, flop / t2 / 1e9, flop / t2 / 1e9 / 78.6);
+        const float tp = timeit(run_prod, 5), td = timeit(run_dma, 5), t2 = timeit(run_dma2, 5), t3 = timeit(run_p1, 5);
+        printf("round %d: production %.3f ms (%.3f of 78.6)   dma %.3f ms (%.3f)   dma2 %.3f ms (%.3f)   p1 %.3f ms (%.2f TFLOP/s, %.3f)\n", round, tp,
+               flop / tp / 1e9 / 78.6, td, flop / td / 1e9 / 78.6, t2, flop / t2 / 1e9 / 78.6, t3, flop / t3 / 1e9, flop / t3 / 1e9 / 78.6);
     }
     return 0;
 }
