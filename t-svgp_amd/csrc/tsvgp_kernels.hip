@@ -1423,8 +1423,17 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 #define TSVGP_SYRK_DIAG_NUM 23
 #define TSVGP_SYRK_DIAG_DEN 32
 #endif
-__host__ __device__ inline int syrk_ns_diag(int ns_off) {
-    const int d = (TSVGP_SYRK_DIAG_NUM * ns_off + TSVGP_SYRK_DIAG_DEN - 1) / TSVGP_SYRK_DIAG_DEN;
+#ifndef TSVGP_SYRK1_DIAG_NUM  // syrk1_kernel (fp64, round 3): 19/32 .. 23/32 measured within 1 % of each other; 20/32 best
+#define TSVGP_SYRK1_DIAG_NUM 20
+#endif
+// (esize: sizeof of the N-sized arrays' type -- the fp64 path runs syrk1_kernel unless the build keeps the old one)
+__host__ __device__ inline int syrk_ns_diag(int ns_off, int esize) {
+#ifndef TSVGP_SYRK_OLD
+    const int num = esize == 8 ? TSVGP_SYRK1_DIAG_NUM : TSVGP_SYRK_DIAG_NUM;
+#else
+    const int num = TSVGP_SYRK_DIAG_NUM;
+#endif
+    const int d = (num * ns_off + TSVGP_SYRK_DIAG_DEN - 1) / TSVGP_SYRK_DIAG_DEN;
     return d < 1 ? 1 : d;
 }
 
@@ -1609,6 +1618,310 @@ __global__ __launch_bounds__(NTHREADS, 2) void syrk_kernel(SyrkArgs<T> a) {
         syrk_body<T, true, 2>(a, lds, g0s, p, it, jt, sidx, slab, per_p, w);
     } else {
         syrk_body<T, true, 3>(a, lds, g0s, p, it, jt, sidx, slab, per_p, w);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// syrk1_kernel (round 3, fp64): syrk_kernel's work -- one lower 128 x 128 tile of  sum_n g1[n] b_n b_n^T  over one N-slice, and
+// the first-order sum on diagonal tiles -- with the recipe of panel1_kernel: ONE workgroup per CU (512 registers per wave, no
+// scratch), the instruction stream of a chunk laid out by hand and pinned with sched_barrier(0), operands global -> LDS by
+// LDS-DMA.  A chunk is 16 rows n of the operand; its two LDS images are [16 k-rows][144 doubles] (the k stride of syrk_kernel:
+// conflict free for the fragment reads), and ONE DMA instruction moves one k-row (128 columns = 1 KiB lane-linear).  The
+// weights no longer ride on the staging (there is none): a lane multiplies the two A fragments of a k-step by
+// g1[n = 16 c + 4 ks + lk], which it loads itself two chunks ahead (four 8-byte loads per chunk).  First-order sum (diagonal
+// tiles): lane (w, lr, lk) owns columns 32 w + 2 lr, + 1 and the k-rows of its MFMA role; reduced over lk at the end.
+//     k-step 0: MFMAs on set X | reads of k-step 1 -> set Y   (tail: Y's A fragments times their weight)
+//     k-step 1: MFMAs on set Y | reads of k-step 2 -> set X
+//     k-step 2: MFMAs on set X | reads of k-step 3 -> set Y
+//     s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier
+//     k-step 3: MFMAs on set Y | LDS-DMA of chunk c + 2 into this chunk's buffer, its weights, reads of (c + 1, 0) -> set X
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int S1_IMG = KC * LDS_KS;   // doubles per image (16 k-rows of 144)
+constexpr int S1_BUF = 2 * S1_IMG;    // doubles per chunk buffer (image I + image J)
+
+template <bool DIAG, int W>
+__device__ __forceinline__ void syrk1_body(const SyrkArgs<double>& a, double* lds, double* wl, int p, int it, int jt, int sidx, int slab,
+                                           int per_p, int w) {
+    typedef v4d acc_t;
+    const int t = threadIdx.x, lane = t & 63;
+    const int Mp = a.Mp, P = a.P;
+    const int64_t total_chunks = a.Np / KC;
+    const int64_t per = DIAG ? a.chunks_diag : a.chunks_off;
+    int64_t c_lo = (int64_t)sidx * per;
+    int64_t c_hi = c_lo + per;
+    if (c_lo > total_chunks) c_lo = total_chunks;
+    if (c_hi > total_chunks) c_hi = total_chunks;
+    const int nch = (int)(c_hi - c_lo);
+
+    // column blocks the wave's MFMAs touch: all eight, or on a diagonal tile n <= W for row block W and n <= 7 - W for row
+    // block 7 - W (9 of the 16 pairs); MB = T-side fragments needed per k-step
+    constexpr int MB = DIAG ? 8 - W : 8;
+    constexpr int NM = DIAG ? 9 : 16;
+    constexpr int NR = 2 + MB;
+
+    const int lr = lane & 15, lk = lane >> 4;
+    const int offa0 = lk * LDS_KS + w * 16 + lr;
+    const int offa1 = lk * LDS_KS + (7 - w) * 16 + lr;
+    const int offb = lk * LDS_KS + lr + (DIAG ? 0 : S1_IMG);  // diagonal tile: both sides come from the one image
+    const int off1 = lk * LDS_KS + w * 32 + lr * 2;            // first-order sum: the lane's column pair
+
+    auto uni64 = [](const void* ptr) TSVGP_AI {
+        const uint64_t v = (uint64_t)(uintptr_t)ptr;
+        return ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+               (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+    };
+    // DMA: piece i (0..7): image i & 1 (0: columns of tile it, 1: of tile jt), k-row 4 (i >> 1) + w; a lane moves 16 bytes
+    const unsigned lds_u = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(uintptr_t)(lds_void_t*)lds + (unsigned)(w * LDS_KS * 8)));
+    const unsigned dvo = (unsigned)(lane * 16);
+    const double* Bp = a.B + (size_t)p * a.strideB + (int64_t)w * Mp;
+    const uint64_t bi_u = uni64(Bp + it * TILE), bj_u = uni64(Bp + jt * TILE);
+    const uint64_t row4 = (uint64_t)4 * Mp * sizeof(double), chunkb = (uint64_t)KC * Mp * sizeof(double);
+    uint64_t ci_u = 0, cj_u = 0;  // bases of the chunk being fetched
+    auto dma_setup = [&](const int64_t c) TSVGP_AI {
+        ci_u = bi_u + (uint64_t)c * chunkb;
+        cj_u = bj_u + (uint64_t)c * chunkb;
+    };
+    auto dma_piece = [&](auto i_tag, const int buf) TSVGP_AI {
+        constexpr int I = decltype(i_tag)::value, rq = I >> 1;
+        const unsigned la = lds_u + (unsigned)((buf * S1_BUF + (I & 1) * S1_IMG + rq * 4 * LDS_KS) * sizeof(double));
+        const uint64_t g = ((I & 1) ? cj_u : ci_u) + rq * row4;
+        const unsigned vo_ = dvo;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(la), "v"(vo_), "s"(g) : "memory");
+    };
+    constexpr int NDMA = DIAG ? 4 : 8;  // diagonal tile: image I only (pieces 0, 2, 4, 6)
+
+    // Weights of a chunk: the 16 P doubles g1[16 c .. 16 c + 15][0 .. P) (P <= 8: at most 1 KiB) travel by ONE more LDS-DMA
+    // instruction, issued by wave 0 with the chunk's operand pieces (wave 1: g0, diagonal tiles), lanes beyond the 16 P doubles
+    // switched off in EXEC so that nothing is read behind the end of the array; behind the barrier every lane takes the weights
+    // of its four k-rows from LDS.  (Loading them with ordinary global loads made the compiler wait -- s_waitcnt vmcnt(small) in
+    // front of their first use -- for the LDS-DMA pieces in flight, which it cannot see: the whole memory latency, every chunk.)
+    const unsigned wl_u = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(lds_void_t*)wl);
+    const uint64_t wmask = (P >= 8) ? ~0ull : ((1ull << (8 * P)) - 1);
+    const uint64_t g1_u = uni64(a.g1), g0_u = uni64(a.g0);
+    const uint64_t wchunk = (uint64_t)KC * P * sizeof(double);
+    auto dma_weights = [&](const int64_t c, const int buf) TSVGP_AI {  // wl: [buffer][g1 | g0][128 doubles]
+        if (w == 0 || (DIAG && w == 1)) {
+            const unsigned la = wl_u + (unsigned)((buf * 256 + (w == 1 ? 128 : 0)) * sizeof(double));
+            const uint64_t g = (w == 1 ? g0_u : g1_u) + (uint64_t)c * wchunk;
+            const unsigned vo_ = dvo;
+            uint64_t saved;
+            asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                         "global_load_lds_dwordx4 %3, %4\n\ts_mov_b64 exec, %0"
+                         : "=&s"(saved)
+                         : "s"(wmask), "s"(la), "v"(vo_), "s"(g)
+                         : "memory");
+        }
+    };
+    double w1r[4], w0r[4];  // the lane's weights of the chunk being computed: k-rows 4 ks + lk
+    const int woff = lk * P + p;
+    auto read_weight = [&](auto i_tag, const int buf) TSVGP_AI {  // I < 4: g1 of k-step I; I >= 4: g0 of k-step I - 4
+        constexpr int I = decltype(i_tag)::value;
+        if constexpr (I < 4) w1r[I] = wl[buf * 256 + woff + I * 4 * P];
+        else w0r[I - 4] = wl[buf * 256 + 128 + woff + (I - 4) * 4 * P];
+    };
+    constexpr int NW = DIAG ? 8 : 4;
+
+    acc_t acc[2][8];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int n = 0; n < 8; ++n) acc[s][n] = acc_t{0, 0, 0, 0};
+    double acc1v[2] = {0.0, 0.0};
+    Frag1 fx, fy;
+
+    auto rd1 = [&](Frag1& f, auto e_tag, auto ks_tag, const int boff) TSVGP_AI {
+        constexpr int E = decltype(e_tag)::value, KS_ = decltype(ks_tag)::value;
+        if constexpr (E == 0) f.v[0] = lds[offa0 + boff + KS_ * 4 * LDS_KS];
+        else if constexpr (E == 1) f.v[1] = lds[offa1 + boff + KS_ * 4 * LDS_KS];
+        else f.v[E] = lds[offb + boff + KS_ * 4 * LDS_KS + (E - 2) * 16];
+    };
+    auto rds = [&](Frag1& f, auto slot_tag, auto ks_tag, const int boff) TSVGP_AI {  // T-side fragments first, A-side last
+        constexpr int S = decltype(slot_tag)::value;
+        if constexpr (S < MB) rd1(f, TSVGP_IC(2 + S), ks_tag, boff);
+        else rd1(f, TSVGP_IC(S - MB), ks_tag, boff);
+    };
+    auto keep_set = [&](const Frag1& f) TSVGP_AI {
+        cfor<0, NR>([&](auto e) TSVGP_AI {
+            const double x = f.v[decltype(e)::value];
+            asm volatile("" ::"v"(x));
+        });
+    };
+    // MFMA number I of a k-step.  Off-diagonal: column block I / 2, row block I % 2.  Diagonal tile, wave W: the pairs
+    // (row block s, column block n) with n <= W (s = 0) or n <= 7 - W (s = 1), ordered by n
+    auto mf = [&](const Frag1& f, auto i_tag) TSVGP_AI {
+        constexpr int I = decltype(i_tag)::value;
+        if constexpr (!DIAG) {
+            constexpr int n = I >> 1, sblk = I & 1;
+            acc[sblk][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.v[sblk], f.v[2 + n], acc[sblk][n], 0, 0, 0);
+        } else {
+            // n <= W: both row blocks (pairs 2 n, 2 n + 1); W < n <= 7 - W: row block 1 only
+            constexpr int n = (I < 2 * (W + 1)) ? (I >> 1) : (I - (W + 1));
+            constexpr int sblk = (I < 2 * (W + 1)) ? (I & 1) : 1;
+            acc[sblk][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.v[sblk], f.v[2 + n], acc[sblk][n], 0, 0, 0);
+        }
+    };
+    v2d f1[4];  // first-order sum: the lane's column pair in its four k-rows
+    // one chunk of the slice; on entry set X holds the (weighted) fragments of its k-step 0
+    auto chunk = [&](auto buf_tag, auto next_tag, const int64_t c_fetch) TSVGP_AI {
+        constexpr int BUF = decltype(buf_tag)::value;
+        constexpr bool NEXT = decltype(next_tag)::value;  // a chunk follows in this slice
+        constexpr int B0 = BUF * S1_BUF, B1 = (BUF ^ 1) * S1_BUF;
+        if constexpr (NEXT) {
+            dma_setup(c_fetch);
+            TSVGP_SB();
+        }
+        // k-steps 0..2: MFMAs on one set, the next k-step's reads into the other, then its A fragments times their weight
+        cfor<0, 3>([&](auto ks) TSVGP_AI {
+            constexpr int KS_ = decltype(ks)::value;
+            Frag1& cur = (KS_ & 1) ? fy : fx;
+            Frag1& nxt = (KS_ & 1) ? fx : fy;
+            constexpr int S = NR + ((DIAG && KS_ == 0) ? 4 : 0);
+            cfor<0, (NM > S ? NM : S)>([&](auto i) TSVGP_AI {
+                constexpr int I = decltype(i)::value;
+                if constexpr (I < NM) mf(cur, i);
+                if constexpr (I < NR) rds(nxt, i, TSVGP_IC(KS_ + 1), B0);
+                else if constexpr (DIAG && KS_ == 0 && I < NR + 4)
+                    f1[I - NR] = *reinterpret_cast<const v2d*>(lds + off1 + B0 + (I - NR) * 4 * LDS_KS);
+                TSVGP_SB();
+            });
+            nxt.v[0] *= w1r[KS_ + 1];
+            nxt.v[1] *= w1r[KS_ + 1];
+            if constexpr (DIAG && KS_ == 1) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    acc1v[0] += w0r[q] * f1[q][0];
+                    acc1v[1] += w0r[q] * f1[q][1];
+                }
+            }
+            TSVGP_SB();
+            keep_set(cur);
+        });
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        TSVGP_SB();
+        if constexpr (NEXT) {
+            // slots: the operand pieces of chunk c + 2, then the weights of chunk c + 1 (landed with it; this chunk's are all
+            // consumed), then the fragments of (c + 1, k-step 0)
+            constexpr int S3 = NDMA + NW + NR;
+            cfor<0, (NM > S3 ? NM : S3)>([&](auto i) TSVGP_AI {
+                constexpr int I = decltype(i)::value;
+                if constexpr (I < NM) mf(fy, i);
+                if constexpr (I < NDMA) dma_piece(TSVGP_IC(DIAG ? 2 * I : I), BUF);
+                else if constexpr (I < NDMA + NW) read_weight(TSVGP_IC(I - NDMA), BUF ^ 1);
+                else if constexpr (I < S3) rds(fx, TSVGP_IC(I - NDMA - NW), TSVGP_IC(0), B1);
+                TSVGP_SB();
+            });
+            dma_weights(c_fetch, BUF);
+            fx.v[0] *= w1r[0];
+            fx.v[1] *= w1r[0];
+            TSVGP_SB();
+        } else {
+            cfor<0, NM>([&](auto i) TSVGP_AI { mf(fy, i); });
+        }
+        keep_set(fy);
+    };
+
+    if (nch > 0) {
+        // prologue: the first two chunks and their weights on their way, then the first weights and fragments
+        dma_setup(c_lo);
+        cfor<0, NDMA>([&](auto i) TSVGP_AI { dma_piece(TSVGP_IC(DIAG ? 2 * decltype(i)::value : decltype(i)::value), 0); });
+        dma_weights(c_lo, 0);
+        const int64_t c1 = (nch > 1) ? c_lo + 1 : c_lo;  // a slice of one chunk fetches it twice (the second copy is never read)
+        dma_setup(c1);
+        cfor<0, NDMA>([&](auto i) TSVGP_AI { dma_piece(TSVGP_IC(DIAG ? 2 * decltype(i)::value : decltype(i)::value), 1); });
+        dma_weights(c1, 1);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        cfor<0, NW>([&](auto i) TSVGP_AI { read_weight(i, 0); });
+        cfor<0, NR>([&](auto i) TSVGP_AI { rds(fx, i, TSVGP_IC(0), 0); });
+        fx.v[0] *= w1r[0];
+        fx.v[1] *= w1r[0];
+        // chunk i of the slice sits in buffer i & 1 and fetches chunk i + 2 (clamped to the last one: a harmless re-fetch
+        // into a dead buffer) while a chunk follows it
+        int i = 0;
+        const int64_t c_last = c_hi - 1;
+        auto fetch_of = [&](int idx) TSVGP_AI { const int64_t c = c_lo + idx + 2; return c < c_last ? c : c_last; };
+        if (nch >= 3) {
+            // The first pair of chunks stands in front of the loop: the accumulators then enter the loop as MFMA results.
+            // (With the zero-initialised values as the loop's incoming ones the compiler kept all 128 accumulator registers in
+            // VGPRs across the back edge and copied them into and out of the AGPRs the MFMAs run on in EVERY iteration:
+            // 256 v_accvgpr moves per 128 MFMAs, 19.7 instead of 16.8 ms for the launch.)
+            chunk(TSVGP_IC(0), TSVGP_BC(true), fetch_of(0));
+            chunk(TSVGP_IC(1), TSVGP_BC(true), fetch_of(1));
+            for (i = 2; i + 2 < nch; i += 2) {
+                chunk(TSVGP_IC(0), TSVGP_BC(true), fetch_of(i));
+                chunk(TSVGP_IC(1), TSVGP_BC(true), fetch_of(i + 1));
+            }
+        }
+        if (nch - i == 2) {
+            chunk(TSVGP_IC(0), TSVGP_BC(true), fetch_of(i));
+            chunk(TSVGP_IC(1), TSVGP_BC(false), 0);
+        } else {
+            chunk(TSVGP_IC(0), TSVGP_BC(false), 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped re-fetches have landed before the LDS is given back
+    }
+
+    double* out = a.part2 + ((size_t)p * per_p + slab) * (TILE * TILE) + (lane & 15);
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double* orow = out + (row_block(w, s) * 16 + Mfma<double>::row(lane, r)) * TILE;
+#pragma unroll
+            for (int n = 0; n < 8; ++n)
+                if (!DIAG || n <= (s == 0 ? W : 7 - W)) orow[n * 16] = acc[s][n][r];
+        }
+    if constexpr (DIAG) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            acc1v[q] += __shfl_xor(acc1v[q], 16);
+            acc1v[q] += __shfl_xor(acc1v[q], 32);
+        }
+        if (lk == 0) {
+            double* o1 = a.part1 + ((size_t)p * a.ns_diag + sidx) * Mp + it * TILE + w * 32 + lr * 2;
+            o1[0] = acc1v[0];
+            o1[1] = acc1v[1];
+        }
+    }
+}
+
+__global__ __launch_bounds__(NTHREADS, 1) void syrk1_kernel(SyrkArgs<double> a) {
+    __shared__ __attribute__((aligned(1024))) double lds[2 * S1_BUF];
+    __shared__ __attribute__((aligned(1024))) double wl[2 * 256];  // per chunk buffer: 128 doubles of g1, 128 of g0
+
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nt = a.nt, n_off = nt * (nt - 1) / 2;
+    const int per_p = n_off * a.ns_off + nt * a.ns_diag;
+    int lin = xcd_remap(blockIdx.x, gridDim.x);
+    const int p = lin / per_p;
+    lin -= p * per_p;
+    int it, jt, sidx;
+    if (lin < n_off * a.ns_off) {
+        sidx = lin / n_off;
+        const int idx = lin - sidx * n_off;  // idx-th pair (it, jt) with jt < it
+        it = 1;
+        while (it * (it + 1) / 2 <= idx) ++it;
+        jt = idx - it * (it - 1) / 2;
+    } else {
+        lin -= n_off * a.ns_off;
+        sidx = lin / nt;
+        it = jt = lin - sidx * nt;
+    }
+    const int tri = it * (it + 1) / 2 + jt;
+    const int slab = (tri - it) * a.ns_off + it * a.ns_diag + sidx;
+    if (it != jt) {
+        syrk1_body<false, 0>(a, lds, wl, p, it, jt, sidx, slab, per_p, w);
+    } else if (w == 0) {
+        syrk1_body<true, 0>(a, lds, wl, p, it, jt, sidx, slab, per_p, w);
+    } else if (w == 1) {
+        syrk1_body<true, 1>(a, lds, wl, p, it, jt, sidx, slab, per_p, w);
+    } else if (w == 2) {
+        syrk1_body<true, 2>(a, lds, wl, p, it, jt, sidx, slab, per_p, w);
+    } else {
+        syrk1_body<true, 3>(a, lds, wl, p, it, jt, sidx, slab, per_p, w);
     }
 }
 
@@ -2615,7 +2928,7 @@ template <typename T>
 int64_t site_accum_work_bytes(int Mp, int P, int nsplit) {
     if (Mp <= 0 || (Mp % TILE) || P <= 0 || nsplit <= 0) return -1;
     const int64_t nt = Mp / TILE, n_off = nt * (nt - 1) / 2;
-    const int64_t ns_diag = syrk_ns_diag(nsplit);
+    const int64_t ns_diag = syrk_ns_diag(nsplit, (int)sizeof(T));
     const int64_t per_p = n_off * nsplit + nt * ns_diag;
     return (int64_t)P * (per_p * TILE * TILE + ns_diag * Mp) * (int64_t)sizeof(T);
 }
@@ -2638,7 +2951,7 @@ int site_accum(const T* B, int64_t strideB, const T* g0, const T* g1, double* ac
     a.P = P;
     a.nt = nt;
     a.ns_off = nsplit;
-    a.ns_diag = syrk_ns_diag(nsplit);
+    a.ns_diag = syrk_ns_diag(nsplit, (int)sizeof(T));
     a.chunks_off = (total_chunks + a.ns_off - 1) / a.ns_off;
     a.chunks_diag = (total_chunks + a.ns_diag - 1) / a.ns_diag;
     const int64_t per_p = (int64_t)n_off * a.ns_off + (int64_t)nt * a.ns_diag;
@@ -2646,7 +2959,16 @@ int site_accum(const T* B, int64_t strideB, const T* g0, const T* g1, double* ac
     a.part1 = a.part2 + (size_t)P * per_p * TILE * TILE;
     const int64_t nwg = (int64_t)P * per_p;
     if (nwg > 0x7fffffff) return TSVGP_EINVAL;
-    hipLaunchKernelGGL(syrk_kernel<T>, dim3((unsigned)nwg), dim3(NTHREADS), 0, (hipStream_t)stream, a);
+#ifndef TSVGP_SYRK_OLD  // (-DTSVGP_SYRK_OLD: A/B builds keep round 2's syrk_kernel for fp64 too)
+    if (sizeof(T) == 8 && P <= 8) {  // (the weights of a chunk travel as one 1-KiB LDS-DMA piece: 16 P doubles)
+      if constexpr (sizeof(T) == 8) {
+        static DynLdsOptIn optin_s1;  // 72 KB of static LDS: above the 64 KB a kernel gets without asking
+        if (optin_s1.ensure(reinterpret_cast<const void*>(&syrk1_kernel), 0) != TSVGP_OK) return TSVGP_ELAUNCH;
+        hipLaunchKernelGGL(syrk1_kernel, dim3((unsigned)nwg), dim3(NTHREADS), 0, (hipStream_t)stream, a);
+      }
+    } else
+#endif
+        hipLaunchKernelGGL(syrk_kernel<T>, dim3((unsigned)nwg), dim3(NTHREADS), 0, (hipStream_t)stream, a);
     if (launch_status() != TSVGP_OK) return TSVGP_ELAUNCH;
     const int extra = (Mp + NTHREADS - 1) / NTHREADS;
     hipLaunchKernelGGL(syrk_reduce_kernel<T>, dim3((unsigned)(ntri * 64 + extra), (unsigned)P), dim3(NTHREADS), 0,
@@ -2659,6 +2981,9 @@ int site_accum_slots() {
     int dev = 0, cus = 0, nb = 0;
     if (hipGetDevice(&dev) != hipSuccess) return -1;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return -1;
+#ifndef TSVGP_SYRK_OLD
+    if (sizeof(T) == 8) return cus;  // syrk1_kernel: one workgroup per CU by construction (512 registers per wave)
+#endif
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&syrk_kernel<T>), NTHREADS,
                                                      0) != hipSuccess)
         return -1;

@@ -66,7 +66,7 @@ class EStepEngine:
         self._buf = {}
         self._slots = None
         self.nsplit_override = None
-        self.syrk_oversubscribe = 8
+        self.syrk_oversubscribe = None  # None: by kernel (see choose_nsplit)
         self._b_tag = None  # identifies the contents of the cached whitened buffer B
         self._side = None  # side stream of start_fill
         self.last_batched = False  # the last pass over separate kernels ran as batched launches
@@ -138,19 +138,28 @@ class EStepEngine:
             self._slots = s
         return self._slots
 
-    def choose_nsplit(self, Mp: int, P: int) -> int:
-        """Largest number of N-slices (for off-diagonal tiles) whose workgroups all fit in one resident round:
-        n_off * ns + nt * ceil(23 ns / 32) <= slots / P  (diagonal tiles cost ~0.71 of an off-diagonal tile per row
-        and get correspondingly longer slices; the same rule as syrk_ns_diag in the kernel source)."""
+    def choose_nsplit(self, Mp: int, P: int, Np: int = None) -> int:
+        """Number of N-slices per off-diagonal tile.  ns = the largest number whose workgroups all fit in ONE resident round,
+        n_off * ns + nt * ns_diag <= slots / P (diagonal tiles cost less per row and get correspondingly longer slices: the rule
+        of syrk_ns_diag in the kernel source), times an oversubscription factor:
+        fp32 (syrk_kernel, two workgroups per CU): 8 rounds of shorter slices keep two workgroups resident on every CU until the
+        very end (a workgroup left alone on a CU runs its MFMA pipe at ~60 %): 18.3 -> 17.2 ms at N = 1e6;
+        fp64 (syrk1_kernel, one workgroup per CU): 32 -- at N = 1e6, M = 1024 the launch takes 17.0 / 15.75 / 15.5 ms with 56 /
+        120 / 224 slices (gpurun_out/r3e/kb4_*.txt) -- but never slices shorter than ~96 chunks of 16 rows (at 125 000 rows
+        80 slices: 2.16 ms, 120: 2.18, 32: 2.36)."""
         nt = Mp // B.TILE
         n_off = nt * (nt - 1) // 2
         budget = max(1, self.slots() // P)
+        f64 = self.dtype == torch.float64
+        num = 20 if f64 else 23  # TSVGP_SYRK1_DIAG_NUM / TSVGP_SYRK_DIAG_NUM
         ns = 1
-        while n_off * (ns + 1) + nt * ((23 * (ns + 1) + 31) // 32) <= budget:
+        while n_off * (ns + 1) + nt * ((num * (ns + 1) + 31) // 32) <= budget:
             ns += 1
-        # 8 rounds of shorter slices: the hardware dispatcher then keeps two workgroups resident on every CU until the
-        # very end (a workgroup left alone on a CU runs its MFMA pipe at ~60 %), measured 18.3 -> 17.2 ms at N = 1e6.
-        return ns * self.syrk_oversubscribe
+        over = self.syrk_oversubscribe if self.syrk_oversubscribe is not None else (32 if f64 else 8)
+        nsplit = ns * over
+        if f64 and Np is not None:
+            nsplit = max(ns, min(nsplit, (Np // 16) // 96))
+        return nsplit
 
     def _pad_square(self, A: torch.Tensor, Mp: int, key: str = None) -> torch.Tensor:
         """[.., M, M] fp64 -> zero-padded contiguous [.., Mp, Mp] in the compute dtype (a cached buffer per key)."""
@@ -491,7 +500,7 @@ class EStepEngine:
         if want_grads and need_g:
             stats.g0, stats.g1 = g0[:N].to(torch.float64), g1[:N].to(torch.float64)
         if sites:
-            nsplit = self.nsplit_override or self.choose_nsplit(Mp, P)
+            nsplit = self.nsplit_override or self.choose_nsplit(Mp, P, Np)
             nsplit = max(1, min(nsplit, Np // 16))
             nbytes = int(self._fn("tsvgp_site_accum_work_bytes")(Mp, P, nsplit))
             work = self._get("work", (nbytes,), torch.uint8)
@@ -742,7 +751,7 @@ class EStepEngine:
             self.trmm(A, self._pad_square(project_T, Mp, "pad_proj"), Aproj, project_mode)
             A = Aproj
         if sites:
-            nsplit = self.nsplit_override or self.choose_nsplit(Mp, P)
+            nsplit = self.nsplit_override or self.choose_nsplit(Mp, P, Np)
             nsplit = max(1, min(nsplit, Np // 16))
             nbytes = int(self._fn("tsvgp_site_accum_work_bytes")(Mp, P, nsplit))
             work = self._get("work", (nbytes,), torch.uint8)

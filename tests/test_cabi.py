@@ -35,7 +35,9 @@ def test_argument_validation_needs_no_gpu():
     assert lib.tsvgp_moments_f64(None, None, None, None, 1.0, 0, 0.0, None, None, None, None, None, None, 1, 128, 128, 1, 0, None) == 1
     assert lib.tsvgp_site_accum_f64(None, None, None, None, None, None, 128, 128, 1, 1, None) == 1
     assert lib.tsvgp_potrf_f64(None, 128, 128, 1, 0, None, None, 0, None) == 1
-    assert lib.tsvgp_site_accum_work_bytes_f64(1024, 1, 15) == (28 * 15 + 8 * 11) * 128 * 128 * 8 + 11 * 1024 * 8
+    # diagonal tiles get ceil(20 ns / 32) slices in fp64 (syrk1_kernel) and ceil(23 ns / 32) in fp32 (syrk_kernel)
+    assert lib.tsvgp_site_accum_work_bytes_f64(1024, 1, 15) == (28 * 15 + 8 * 10) * 128 * 128 * 8 + 10 * 1024 * 8
+    assert lib.tsvgp_site_accum_work_bytes_f32(1024, 1, 15) == (28 * 15 + 8 * 11) * 128 * 128 * 4 + 11 * 1024 * 4
     assert lib.tsvgp_site_accum_work_bytes_f32(1000, 1, 15) == -1
 
 

@@ -32,7 +32,7 @@ def moments(r0, r1, stream):
 bufs = {}
 def sums(r0, r1, stream, key):
     rows = r1 - r0
-    ns = max(1, min(eng.choose_nsplit(M, P), rows // 16))
+    ns = max(1, min(eng.choose_nsplit(M, P, rows), rows // 16))
     if key not in bufs:
         bufs[key] = (torch.empty(int(wb(M, P, ns)), dtype=torch.uint8, device=dev), torch.empty(P, M, M, dtype=torch.float64, device=dev),
                      torch.empty(P, M, dtype=torch.float64, device=dev))

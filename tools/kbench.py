@@ -33,7 +33,7 @@ gam = rnd(Mp, P)
 Y = rnd(N, P)
 g0 = torch.empty(Np, P, dtype=dt, device="cuda:0"); g1 = torch.empty(Np, P, dtype=dt, device="cuda:0")
 vep = torch.empty(Np // 128, dtype=torch.float64, device="cuda:0"); npp = torch.empty(Np // 128, dtype=torch.int32, device="cuda:0")
-nsplit = min(eng.choose_nsplit(Mp, P), Np // 16)
+nsplit = min(eng.choose_nsplit(Mp, P, Np), Np // 16)
 work = torch.empty(int(eng._fn("tsvgp_site_accum_work_bytes")(Mp, P, nsplit)), dtype=torch.uint8, device="cuda:0")
 acc2 = torch.empty(P, Mp, Mp, dtype=torch.float64, device="cuda:0"); acc1 = torch.empty(P, Mp, dtype=torch.float64, device="cuda:0")
 st = eng._stream()
