@@ -16,9 +16,11 @@
  *     state is one "dynamic-LDS opt-in done" flag per (kernel, device) for the two
  *     kernels that use more than 64 KB of LDS (set on first use, thread-safe; any
  *     device of the process may be current).
- *   - Input dimension limits: D <= 32 for the fused fill (tsvgp_kernel_fill_*; beyond that the distance is a
- *     library GEMM finished by tsvgp_gram_to_kernel_*), D <= 16 for the M-step gradient contraction
- *     (tsvgp_kernel_grad_*); larger D returns 1.
+ *   - Input dimension policy (one for the fill and for the M-step gradient): the fused kernels pad D to a compile-time
+ *     size -- D <= 32 for the fill (tsvgp_kernel_fill_*), D <= 16 for the gradient contraction (tsvgp_kernel_grad_*);
+ *     larger D returns 1 from them.  Beyond that the scaled distance is a GEMM, r2 = |x~|^2 + |z~|^2 - 2 x~ z~^T,
+ *     taken from the BLAS library by the host, and an elementwise kernel finishes it in place:
+ *     tsvgp_gram_to_kernel_* (K(X, Z)) and tsvgp_gram_to_gradw_* (the gradient's weight matrix W); any D.
  *   - Suffix _f64 / _f32 selects the arithmetic type T of the N-sized arrays.
  *   - "Padded" dimensions: Np = N rounded up to 128, Mp = M rounded up to 128.  Work
  *     buffers (Kfu, B) are [Np x Mp] row-major with the padding ZERO-filled by the
@@ -115,6 +117,20 @@ int tsvgp_gram_to_kernel_f64(int kind, double *K, const double *xx, const double
                              int64_t ldk, void *stream);
 int tsvgp_gram_to_kernel_f32(int kind, float *K, const float *xx, const float *zz, float variance, int64_t N, int M,
                              int64_t ldk, void *stream);
+
+/* (1c) M-step gradient for D beyond tsvgp_kernel_grad_*'s sizes, GEMM form (replaces TensorFlow autodiff through Kuf [ext],
+ *     reference experiments/uci_regression.py:159-160, docs/notebooks/mnist.py:117-192 with D = 784).  G [N x ldk] holds the
+ *     Gram block x~ z~^T on entry; on return W = -2 variance V * k'(r2) with V = g0 beta^T - 2 g1 * U (padding zero), and
+ *     vpart [tsvgp_gram_to_gradw_parts(N, M)] one partial sum of V k(r2) per workgroup (d ELBO / d variance = their sum).
+ *     g0, g1: element stride gstride; beta: element stride bstride; U [N x ldu].  The caller finishes in M x D:
+ *     dZ = (W^T x~ - z~ * colsum W) / l,  d l_d = (sum_n x~_nd^2 rowsum_n - 2 sum_m z~_md (W^T x~)_md + sum_m z~_md^2 colsum_m) / l_d. */
+int64_t tsvgp_gram_to_gradw_parts(int64_t N, int M);
+int tsvgp_gram_to_gradw_f64(int kind, double *G, const double *xx, const double *zz, double variance, const double *U,
+                            int64_t ldu, const double *g0, const double *g1, int gstride, const double *beta, int bstride,
+                            int64_t N, int M, int64_t ldk, double *vpart, void *stream);
+int tsvgp_gram_to_gradw_f32(int kind, float *G, const float *xx, const float *zz, float variance, const float *U, int64_t ldu,
+                            const float *g0, const float *g1, int gstride, const float *beta, int bstride, int64_t N, int M,
+                            int64_t ldk, double *vpart, void *stream);
 
 /* (2) Blocked triangular solve with an N-sized right-hand side, in inverted-factor form:
  *        C[n, i] = sum_{j in range(i)} A[n, j] * Tm[i, j],   range = j<=i | j>=i | all j   (mode)

@@ -71,6 +71,11 @@ _PROTOTYPES = {
                                               c_int64, c_int, c_void_p]),
     "tsvgp_gram_to_kernel_f64": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_double, c_int64, c_int, c_int64, c_void_p]),
     "tsvgp_gram_to_kernel_f32": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_float, c_int64, c_int, c_int64, c_void_p]),
+    "tsvgp_gram_to_gradw_parts": (c_int64, [c_int64, c_int]),
+    "tsvgp_gram_to_gradw_f64": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_double, c_void_p, c_int64, c_void_p, c_void_p, c_int,
+                                        c_void_p, c_int, c_int64, c_int, c_int64, c_void_p, c_void_p]),
+    "tsvgp_gram_to_gradw_f32": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_void_p, c_void_p, c_int,
+                                        c_void_p, c_int, c_int64, c_int, c_int64, c_void_p, c_void_p]),
     "tsvgp_kernel_grad_rows": (c_int, []),
     "tsvgp_kernel_grad_dpad": (c_int, [c_int]),
     "tsvgp_kernel_grad_f64": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_double, c_void_p, c_int64, c_void_p, c_void_p, c_int,

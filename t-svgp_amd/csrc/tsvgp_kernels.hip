@@ -2763,6 +2763,78 @@ int gram_to_kernel(int kind, T* K, const T* xx, const T* zz, T variance, int64_t
     return launch_status();
 }
 
+// M-step gradient for input dimensions beyond kgrad_kernel's compile-time sizes (D > 16): the contraction with dK/d(theta, Z)
+// in the same GEMM form as the fill above.  With s = |x~|^2 + |z~|^2 - 2 G (G = x~ z~^T from the BLAS library), V = g0 beta^T -
+// 2 g1 * U and W = -2 variance V * k'(s), everything N-sized that is left is
+//     d variance = sum V k(s);    W^T x~ [M, D], the row and column sums of W     (BLAS GEMM + two reductions, on the host side)
+// and dZ, d lengthscales follow in M x D (estep.kernel_grad).  This kernel turns G into W IN PLACE (padding zero) and writes
+// one partial sum of V k(s) per workgroup.  One thread per two adjacent columns, one row per blockIdx.y.
+template <typename T, int KIND>
+__global__ __launch_bounds__(NTHREADS) void gram_to_gradw_kernel(T* __restrict__ G, const T* __restrict__ xx,
+                                                                 const T* __restrict__ zz, T variance, const T* __restrict__ U,
+                                                                 int64_t ldu, const T* __restrict__ g0, const T* __restrict__ g1,
+                                                                 int gstride, const T* __restrict__ beta, int bstride, int64_t N,
+                                                                 int M, int64_t ldk, int64_t rows_pad, int cols_pad,
+                                                                 double* __restrict__ vpart) {
+    typedef typename Mfma<T>::pair_t pair_t;
+    __shared__ double red[NTHREADS / 64];
+    const int64_t n = blockIdx.y;
+    const int m = (blockIdx.x * NTHREADS + threadIdx.x) * 2;
+    double va = 0.0;
+    if (n < rows_pad && m < cols_pad) {
+        pair_t* p = reinterpret_cast<pair_t*>(G + n * ldk + m);
+        pair_t out;
+        out[0] = out[1] = T(0);
+        if (n < N) {
+            const pair_t g = *p;
+            const pair_t u = *reinterpret_cast<const pair_t*>(U + n * ldu + m);
+            const T x = xx[n], gg0 = g0[n * gstride], gg1 = g1[n * gstride];
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                if (m + q < M) {
+                    T f, df;
+                    kernel_profile_grad<KIND>(x + zz[m + q] - T(2) * g[q], f, df);
+                    const T v = gg0 * beta[(int64_t)(m + q) * bstride] - T(2) * gg1 * u[q];
+                    va += (double)(v * f);
+                    out[q] = T(-2) * variance * v * df;
+                }
+        }
+        *p = out;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) va += __shfl_xor(va, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = va;
+    __syncthreads();
+    if (threadIdx.x == 0) vpart[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+template <typename T>
+int gram_to_gradw(int kind, T* G, const T* xx, const T* zz, T variance, const T* U, int64_t ldu, const T* g0, const T* g1,
+                  int gstride, const T* beta, int bstride, int64_t N, int M, int64_t ldk, double* vpart, void* stream) {
+    if (!G || !xx || !zz || !U || !g0 || !g1 || !beta || !vpart || N <= 0 || M <= 0 || gstride <= 0 || bstride <= 0 ||
+        (kind != TSVGP_KERNEL_SE && kind != TSVGP_KERNEL_MATERN32 && kind != TSVGP_KERNEL_MATERN52))
+        return TSVGP_EINVAL;
+    const int64_t rows_pad = (N + TILE - 1) / TILE * TILE;
+    const int cols_pad = (M + TILE - 1) / TILE * TILE;
+    if (ldk < cols_pad || (ldk % 2) != 0 || ldu < cols_pad || (ldu % 2) != 0 || rows_pad > 0x7fffffff) return TSVGP_EINVAL;
+    const dim3 block(NTHREADS);
+    const unsigned gx = (unsigned)((cols_pad / 2 + NTHREADS - 1) / NTHREADS);
+    for (int64_t r0 = 0; r0 < rows_pad; r0 += 65535) {
+        const unsigned gy = (unsigned)((rows_pad - r0 < 65535) ? rows_pad - r0 : 65535);
+        const int64_t Nr = N - r0 > 0 ? N - r0 : 0;
+        const int64_t ro = r0 < N ? r0 : 0;  // rows past N are only zero-filled: no per-row operand is read
+#define TSVGP_G2W(KIND_)                                                                                                         \
+    hipLaunchKernelGGL((gram_to_gradw_kernel<T, KIND_>), dim3(gx, gy), block, 0, (hipStream_t)stream, G + r0 * ldk, xx + ro, zz,  \
+                       variance, U + ro * ldu, ldu, g0 + ro * gstride, g1 + ro * gstride, gstride, beta, bstride, Nr, M, ldk,      \
+                       (int64_t)gy, cols_pad, vpart + r0 * gx)
+        if (kind == TSVGP_KERNEL_SE) TSVGP_G2W(TSVGP_KERNEL_SE);
+        else if (kind == TSVGP_KERNEL_MATERN32) TSVGP_G2W(TSVGP_KERNEL_MATERN32);
+        else TSVGP_G2W(TSVGP_KERNEL_MATERN52);
+#undef TSVGP_G2W
+    }
+    return launch_status();
+}
+
 // P latents in one launch: inv_ls [P x D] (device), variance [P] (HOST: the scalars travel as kernel arguments, like the
 // single-latent entry point's `variance`), K + p * strideK.
 template <typename T>
@@ -3130,6 +3202,23 @@ int tsvgp_gram_to_kernel_f64(int kind, double* K, const double* xx, const double
 int tsvgp_gram_to_kernel_f32(int kind, float* K, const float* xx, const float* zz, float variance, int64_t N, int M,
                              int64_t ldk, void* stream) {
     return gram_to_kernel<float>(kind, K, xx, zz, variance, N, M, ldk, stream);
+}
+// vpart: one double per workgroup = ceil(Mp / 512) * Np of them (tsvgp_gram_to_gradw_parts)
+int64_t tsvgp_gram_to_gradw_parts(int64_t N, int M) {
+    if (N <= 0 || M <= 0) return -1;
+    const int64_t rows_pad = (N + TILE - 1) / TILE * TILE;
+    const int64_t cols_pad = (M + TILE - 1) / TILE * TILE;
+    return rows_pad * ((cols_pad / 2 + NTHREADS - 1) / NTHREADS);
+}
+int tsvgp_gram_to_gradw_f64(int kind, double* G, const double* xx, const double* zz, double variance, const double* U, int64_t ldu,
+                            const double* g0, const double* g1, int gstride, const double* beta, int bstride, int64_t N, int M,
+                            int64_t ldk, double* vpart, void* stream) {
+    return gram_to_gradw<double>(kind, G, xx, zz, variance, U, ldu, g0, g1, gstride, beta, bstride, N, M, ldk, vpart, stream);
+}
+int tsvgp_gram_to_gradw_f32(int kind, float* G, const float* xx, const float* zz, float variance, const float* U, int64_t ldu,
+                            const float* g0, const float* g1, int gstride, const float* beta, int bstride, int64_t N, int M,
+                            int64_t ldk, double* vpart, void* stream) {
+    return gram_to_gradw<float>(kind, G, xx, zz, variance, U, ldu, g0, g1, gstride, beta, bstride, N, M, ldk, vpart, stream);
 }
 
 int tsvgp_trmm_f64(const double* A, const double* Tm, double* C, int64_t Np, int Mp, int mode, void* stream) {

@@ -29,7 +29,7 @@ from .distributed import world_size
 from .kernels import SeparateIndependent
 
 MAX_INPUT_DIM = 32  # the fill kernel pads D to a compile-time size (1, 2, 4, 8, 16, 32)
-MAX_INPUT_DIM_GRAD = 16  # tsvgp_kernel_grad_* (M-step): 1, 2, 4, 8, 16
+MAX_INPUT_DIM_GRAD = 16  # tsvgp_kernel_grad_* (M-step): 1, 2, 4, 8, 16; beyond: GEMM form (tsvgp_gram_to_gradw_*)
 
 
 @dataclass
@@ -341,9 +341,7 @@ class EStepEngine:
         N, D = X.shape
         M = Z.shape[0]
         if D > MAX_INPUT_DIM_GRAD:
-            raise ValueError(f"input dimension D = {D} exceeds the limit of {MAX_INPUT_DIM_GRAD} of the M-step gradient kernel "
-                             "(include/tsvgp_hip.h: tsvgp_kernel_grad_*); the E-step and the ELBO take D <= "
-                             f"{MAX_INPUT_DIM}")
+            return self._kernel_grad_gemm(X, Z, kernel, U, g0, g1, beta)
         Mp = B.round_up(M)
         inv_ls = kernel.inv_lengthscales(D, T, dev)
         rows, Dp = int(self.lib.tsvgp_kernel_grad_rows()), int(self.lib.tsvgp_kernel_grad_dpad(D))
@@ -359,6 +357,40 @@ class EStepEngine:
                 g0.data_ptr(), g1.data_ptr(), g0.stride(0), bt.data_ptr(), 1, N, M, D, zpart.data_ptr(), lpart.data_ptr(),
                 vpart.data_ptr(), self._stream()))
         return vpart.sum(), lpart.sum(dim=(0, 1))[:D], zpart.sum(dim=0)[:M, :D]
+
+    def _kernel_grad_gemm(self, X, Z, kernel, U, g0, g1, beta):
+        """``kernel_grad`` for D beyond the fused kernel's sizes, in the GEMM form of the large-D fill (reference
+        docs/notebooks/mnist.py:117-192, D = 784): G = x~ z~^T from the BLAS library, ``tsvgp_gram_to_gradw_*`` turns it into
+        W = -2 variance V * k'(r2) in place and sums V k(r2); what is left is one [Mp, N] x [N, D] GEMM and the row / column
+        sums of W.  X, Z already in the compute dtype on the device."""
+        T, dev = self.dtype, self.device
+        N, D = X.shape
+        M = Z.shape[0]
+        Np, Mp = B.round_up(N), B.round_up(M)
+        inv_ls = kernel.inv_lengthscales(D, T, dev)
+        Xs = X * inv_ls
+        Zs = torch.zeros((Mp, D), dtype=T, device=dev)
+        Zs[:M] = Z * inv_ls
+        W = self._get("gradW", (Np, Mp), T)
+        torch.mm(Xs, Zs.t(), out=W[:N])
+        xx = (Xs * Xs).sum(dim=1).contiguous()
+        zz = (Zs[:M] * Zs[:M]).sum(dim=1).contiguous()
+        vpart = torch.empty(int(self.lib.tsvgp_gram_to_gradw_parts(N, M)), dtype=torch.float64, device=dev)
+        bt = beta.to(device=dev, dtype=T).contiguous()
+        assert g0.dim() == 1 and g1.dim() == 1 and g0.stride(0) == g1.stride(0)
+        with torch.cuda.device(dev):
+            self._launch("tsvgp_kernel_grad", lambda: self._fn("tsvgp_gram_to_gradw")(
+                kernel.kind, W.data_ptr(), xx.data_ptr(), zz.data_ptr(), kernel.variance.item(), U.data_ptr(), U.shape[1],
+                g0.data_ptr(), g1.data_ptr(), g0.stride(0), bt.data_ptr(), 1, N, M, Mp, vpart.data_ptr(), self._stream()))
+        f64 = torch.float64
+        colsum = W.sum(dim=0, dtype=f64)[:M]  # [M]
+        rowsum = W[:N].sum(dim=1, dtype=f64)  # [N]
+        WtX = torch.mm(W[:N, :M].t(), Xs).to(f64)  # [M, D]
+        Zs64, Xs64, il = Zs[:M].to(f64), Xs.to(f64), inv_ls.to(f64)
+        dZ = (WtX - Zs64 * colsum[:, None]) * il
+        dl = (torch.einsum("nd,n->d", Xs64 * Xs64, rowsum) - 2.0 * (Zs64 * WtX).sum(dim=0)
+              + torch.einsum("md,m->d", Zs64 * Zs64, colsum)) * il
+        return vpart.sum(), dl, dZ
 
     def selftest_mfma(self, dtype=None):
         """Runs one MFMA and returns (a, b, c) for a host-side check of the fragment maps."""

@@ -259,14 +259,18 @@ class t_SVGP(base_SVGP):
                      for k in latent_kernels(self.kernel, self.num_latent_gps))
 
     # Route gates on cond(K_uu + jitter I), per latent GP.  direct: K^-1 (sum g k k^T) K^-1 cancels two factors of K, so its
-    # error grows faster than cond.  Measured against the CPU restatement of the reference at the benchmark's M = 1024, D = 8 (tools/route_gate.py,
-    # profiles/r02_route_gate_m1024.txt; max rel err of lambda_1 / Lambda_2 after two steps): 5e-13 at cond 5e2, 2e-11 at
-    # 4e3, 4e-11 at 1e4, 2e-10 at 2e4, 8e-10 at 5e4, 1.1e-8 at 2.5e5, 1.5e-7 at 1.8e6 -- it reaches 1e-9, a tenth of the
-    # stated 1e-8, near cond 6e4: that is the fp64 gate (round 1 had 1e3, set from M <= 64 fixtures).  fp32: cond <= 30
+    # error grows faster than cond.  Measured against the CPU restatement of the reference at the benchmark's M = 1024, D = 8
+    # (tools/route_gate.py; max rel err of lambda_1 / Lambda_2): round 2 over two steps (profiles/r02_route_gate_m1024.txt), round 3
+    # over EIGHT steps -- what the reference's loop runs per M-step -- for the Gaussian AND the Bernoulli likelihood
+    # (profiles/r03_route_gate_8steps.txt): the error settles by the second step and stays there: 7.5e-13 at cond 5e2, 2e-11 at
+    # 4e3, 7e-11 at 1e4, 2e-10 at 2e4, 9.5e-10 / 6.4e-10 (Gaussian / Bernoulli) at 5.4e4, 1.2e-8 / 7e-9 at 2.5e5.  It reaches
+    # 1e-9 -- a tenth of the stated 1e-8 -- near cond 6e4; the estimate the gate sees (util.cond2_estimate) is a LOWER bound whose
+    # test accepts 10 % under, so the fp64 gate is 5e4 (round 1 had 1e3, set from M <= 64 fixtures; round 2 6e4 without the
+    # slack).  tests/test_gpu_benchshape.py::test_direct_route_at_the_gate_holds_1e8_over_eight_steps pins it.  fp32: cond <= 30
     # keeps it <= ~1e-4.  whitened: the sums over b b^T carry an ABSOLUTE error ~eps |acc2| that U9^-T (.) U9^-1 amplifies
     # by |K9^-1| (measured 4e-10 at cond 1e7, 2e-8 at 1e9, and the final factorisation loses definiteness beyond):
     # cond <= 1e7.  projected: any cond.
-    DIRECT_MAX_COND = {torch.float64: 6.0e4, torch.float32: 30.0}
+    DIRECT_MAX_COND = {torch.float64: 5.0e4, torch.float32: 30.0}
     WHITENED_MAX_COND = {torch.float64: 1.0e7, torch.float32: float("inf")}
     _DEMOTE = {"direct": "whitened", "whitened": "projected"}
 

@@ -142,3 +142,26 @@ def test_c3_full_size_row_sample_matches_oracle():
     e_h = float(hip.elbo((Xd[sel], Yd[sel])))
     e_o = float(O.elbo_chunked(ora, (X[idx], Y[idx]), chunk_rows=1024))
     assert abs(e_h - e_o) / abs(e_o) < 1e-4
+
+
+@pytest.mark.parametrize("lik", ["gaussian", "bernoulli"])
+def test_direct_route_at_the_gate_holds_1e8_over_eight_steps(lik):
+    """The direct projection pinned at its gate: `ns` geometry (M = 1024, D = 8) with lengthscale 1.5, where
+    cond(K_uu + 1e-9 I) = 5.4e4 sits just ABOVE t_SVGP.DIRECT_MAX_COND (5e4): the route forced, EIGHT E-steps (one E-block of
+    the reference's loop, experiments/uci_regression.py:17), state against the oracle after every step at the stated 1e-8."""
+    X, Y, Z = _ns_problem(3000, lik)
+    p = pkg()
+    mk = (lambda mod: mod.Gaussian(0.1)) if lik == "gaussian" else (lambda mod: mod.Bernoulli())
+    hip = p.t_SVGP(p.SquaredExponential(1.0, 1.5), mk(p), Z, projection="direct")
+    ora = O.t_SVGP(O.SquaredExponential(1.0, 1.5), mk(O), Z)
+    auto = p.t_SVGP(p.SquaredExponential(1.0, 1.5), mk(p), Z)
+    assert auto._routes(1e-9) == ["whitened"]  # beyond the gate "auto" no longer takes the direct route
+    cond = auto._cond_cache[1][0]
+    assert hip.DIRECT_MAX_COND[torch.float64] < cond < 1.2 * hip.DIRECT_MAX_COND[torch.float64]
+    for _ in range(8):
+        hip.natgrad_step((X, Y), lr=0.8)
+        ora.natgrad_step((X, Y), lr=0.8)
+        assert relerr(hip.lambda_1.numpy(), ora.lambda_1) < 1e-8
+        assert relerr(hip.lambda_2.cpu().numpy(), ora.lambda_2) < 1e-8
+    e_h, e_o = float(hip.elbo((X, Y))), float(ora.elbo((X, Y)))
+    assert abs(e_h - e_o) / abs(e_o) < 1e-9

@@ -218,3 +218,45 @@ def test_elbo_gradients_separate_kernels(lik):
     for k in range(P):
         assert abs(float(hip.kernel.kernels[k].variance.value) - var0[k]) > 1e-3
     assert float(hip.elbo((X, Y))) > before
+
+
+@pytest.mark.parametrize("kname,lik", [("SquaredExponential", "gaussian"), ("Matern52", "bernoulli")])
+def test_elbo_gradients_large_input_dimension(kname, lik):
+    """D = 784 (the reference's MNIST loop, docs/notebooks/mnist.py:117-192): beyond the fused gradient kernel's sizes the
+    contraction runs in GEMM form (``tsvgp_gram_to_gradw_*``); d ELBO / d (variance, lengthscale, Z, noise) against central
+    differences of the ORACLE's ELBO, same tolerance as at small D."""
+    rng = np.random.RandomState(43)
+    N, M, D = 400, 40, 784
+    X = rng.randn(N, D) * 0.3
+    w = rng.randn(D, 1) / np.sqrt(D)
+    f_lat = np.sin(3.0 * X @ w)
+    Y = f_lat + 0.3 * rng.randn(N, 1) if lik == "gaussian" else (f_lat + 0.3 * rng.randn(N, 1) > 0).astype(np.float64)
+    Z = X[:M] + 0.05 * rng.randn(M, D)
+    ls, var, noise = 6.0, 1.2, 0.2  # |x - z| ~ 0.3 sqrt(2 D) ~ 12: a lengthscale at which the kernel matrix is informative
+    hip, ora = _models(kname, lik, 1, Z, ls, var, noise, N)
+    for _ in range(2):
+        hip.natgrad_step((X, Y), lr=0.7)
+        ora.natgrad_step((X, Y), lr=0.7)
+    state = (ora.lambda_1.copy(), ora.lambda_2_sqrt.copy())
+    elbo, grads = hip.elbo_and_grads((X, Y))
+    f = lambda **kw: _oracle_elbo(kname, lik, 1, kw.get("Z", Z), kw.get("ls", ls), kw.get("var", var), kw.get("noise", noise), N,
+                                  state, (X, Y))
+    assert abs(float(elbo) - f()) < 1e-9 * abs(f())
+    h = 1e-5
+    ref_var = (f(var=var + h) - f(var=var - h)) / (2 * h)
+    ref_ls = (f(ls=ls + h * ls) - f(ls=ls - h * ls)) / (2 * h * ls)
+    scale = max(abs(ref_var), 1.0)
+    assert abs(float(grads["variance"]) - ref_var) < 2e-6 * scale
+    assert grads["lengthscales"].dim() == 0
+    assert abs(float(grads["lengthscales"]) - ref_ls) < 2e-6 * max(abs(ref_ls), scale)
+    g_Z = grads["Z"].cpu().numpy()
+    assert g_Z.shape == (M, D)
+    for (m_, d) in [(0, 0), (7, 391), (M - 1, D - 1), (19, 100)]:
+        Zu, Zd = Z.copy(), Z.copy()
+        Zu[m_, d] += h
+        Zd[m_, d] -= h
+        ref = (f(Z=Zu) - f(Z=Zd)) / (2 * h)
+        assert abs(g_Z[m_, d] - ref) < 2e-6 * max(abs(ref), scale), (m_, d, g_Z[m_, d], ref)
+    if lik == "gaussian":
+        ref = (f(noise=noise + h) - f(noise=noise - h)) / (2 * h)
+        assert abs(float(grads["likelihood_variance"]) - ref) < 2e-6 * max(abs(ref), scale)
