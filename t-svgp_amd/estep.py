@@ -488,7 +488,7 @@ class EStepEngine:
                 raise RuntimeError("prefill ticket does not belong to this pass")
             torch.cuda.current_stream(dev).wait_event(prefill["event"])
         else:
-            if self._side is not None:
+            if self._side is not None and not torch.cuda.is_current_stream_capturing():
                 torch.cuda.current_stream(dev).wait_stream(self._side)
             self._fill_batched(X, Z, kernel, KfuP)
         # whitening in place, one launch per run of consecutive whitened latents: B_p = K_p U9_p^-T (upper form)
@@ -604,8 +604,13 @@ class EStepEngine:
         nothing to overlap: separate kernels on the per-latent path (one fill per latent), an operand ``run`` would reuse
         (warm E-steps), a stream capture in progress.  ``routes``: the projection route of every latent (separate kernels:
         the batched pass, whose fill this starts, needs all of them direct or whitened)."""
-        if self.device.type != "cuda" or X.shape[0] == 0 or torch.cuda.is_current_stream_capturing():
+        if self.device.type != "cuda" or X.shape[0] == 0:
             return None
+        # Under stream capture (hipGraph) the side stream JOINS the capture: it waits for an event recorded on the capturing
+        # stream (a fork) and the consumer waits for its event (the join) inside the same capture, so a replayed step runs the
+        # fill beside the prelude exactly as an eager one.  Allocator bookkeeping (record_stream) is skipped there: a graph owns
+        # its buffers for its lifetime.
+        capturing = torch.cuda.is_current_stream_capturing()
         T, dev = self.dtype, self.device
         N, D = X.shape
         M = Z.shape[0]
@@ -631,8 +636,9 @@ class EStepEngine:
                 self._fill_batched(Xc, Zc, kernel, KfuP)
                 done = torch.cuda.Event()
                 done.record(side)
-            for t in (Xc, Zc, KfuP):
-                t.record_stream(side)
+            if not capturing:
+                for t in (Xc, Zc, KfuP):
+                    t.record_stream(side)
             return dict(event=done, KfuP=KfuP)
         if (b_tag is not None and self._b_tag == (want, b_tag) and self._buf.get(want) is not None
                 and tuple(self._buf[want].shape) == (Np, Mp)):
@@ -652,8 +658,9 @@ class EStepEngine:
             self.se_fill(Xc, Zc, inv_ls, variance, Kfu, kernel.kind)
             done = torch.cuda.Event()
             done.record(side)
-        for t in (Xc, Zc, inv_ls, Kfu):  # blocks of the main stream's allocator pool that the side stream touches
-            t.record_stream(side)
+        if not capturing:
+            for t in (Xc, Zc, inv_ls, Kfu):  # blocks of the main stream's allocator pool that the side stream touches
+                t.record_stream(side)
         return dict(event=done, key=(X.data_ptr(), tuple(X.shape), Z.data_ptr(), tuple(Z.shape), id(kernel)), Kfu=Kfu)
 
     # ------------------------------------------------------------------ one N-pass
@@ -738,7 +745,8 @@ class EStepEngine:
                     raise RuntimeError("prefill ticket does not belong to this pass")
                 torch.cuda.current_stream(dev).wait_event(prefill["event"])
             else:
-                if self._side is not None:  # a fill started for a pass that never ran must not land on top of this one
+                # a fill started for a pass that never ran must not land on top of this one (a capture begins synchronised)
+                if self._side is not None and not torch.cuda.is_current_stream_capturing():
                     torch.cuda.current_stream(dev).wait_stream(self._side)
                 self.se_fill(X, Z, inv_ls, variance, Kfu, kernel.kind)
             A = Kfu

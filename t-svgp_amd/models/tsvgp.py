@@ -383,7 +383,8 @@ class t_SVGP(base_SVGP):
                 ops["K9inv"] = Uinv9.transpose(-1, -2) @ Uinv9
 
         side = getattr(eng, "_side", None)
-        if (self.overlap_fill and side is not None and Kzz.is_cuda and not torch.cuda.is_current_stream_capturing()):
+        if self.overlap_fill and side is not None and Kzz.is_cuda:
+            capturing = torch.cuda.is_current_stream_capturing()  # the side stream then joins the capture (fork / join by events)
             main = torch.cuda.current_stream(self.device)
             ready = torch.cuda.Event()
             ready.record(main)
@@ -392,11 +393,12 @@ class t_SVGP(base_SVGP):
                 epilogue_operands()
                 done = torch.cuda.Event()
                 done.record(side)
-            for t in (L, Kzz, beta) + ((Uinv9,) if want_k9inv else ()):
-                t.record_stream(side)  # blocks of the main stream's pool read on the side stream
-            for k in ("LLt", "meanZ", "K9inv"):
-                if k in ops:
-                    ops[k].record_stream(main)  # and the other way round
+            if not capturing:
+                for t in (L, Kzz, beta) + ((Uinv9,) if want_k9inv else ()):
+                    t.record_stream(side)  # blocks of the main stream's pool read on the side stream
+                for k in ("LLt", "meanZ", "K9inv"):
+                    if k in ops:
+                        ops[k].record_stream(main)  # and the other way round
             ops["epi_event"] = done
         else:
             epilogue_operands()
@@ -710,14 +712,18 @@ class t_SVGP(base_SVGP):
         return self._apply_site_update(st, ops, lr, jitter, inplace=inplace)
 
     # -- hipGraph replay of the step (launch-bound problem sizes) -------------------------------------------------
-    GRAPH_AUTO_MAX_NM = 4_000_000  # "auto": replay when N * M is at most this (tools/bench_graph.py)
+    GRAPH_AUTO_MAX_NM = 200_000_000  # "auto": replay when N * M is at most this (tools/bench_graph_sizes.py, below)
 
     def _wants_graph(self, X) -> bool:
-        """use_graph = True / False, or "auto" (the default): replay from a captured graph where the step is launch
-        bound.  Measured eager -> replay, E-steps/s (tools/bench_graph.py): N=1000, M=32: 981 -> 1765; 2000 x 64:
-        1102 -> 2483; 5000 x 128: 1206 -> 2035; 20000 x 128: 1124 -> 1492; 20000 x 256: 702 -> 755; 50000 x 512:
-        518 -> 534 -- beyond a few million kernel-matrix entries the GPU time dominates and a graph (which owns its
-        work buffers, K(X, Z) among them) only costs memory."""
+        """use_graph = True / False, or "auto" (the default): replay from a captured graph where that is faster.
+        Enqueueing a step eagerly costs the host ~5.9 ms of Python and launch calls (about 120 dispatches), so below that much
+        GPU time the step is host bound: eager -> replay at M = 1024, D = 8, fp64 (tools/bench_graph_sizes.py,
+        profiles/r03_graph_vs_eager_by_shard_size.txt): 62 500 rows 5.94 -> 4.09 ms, 125 000 (one rank's share of an 8-way
+        shard of the headline workload) 6.26 -> 6.15, 250 000 10.22 -> 10.25, 500 000 18.28 -> 18.27, 1e6 34.11 -> 34.00;
+        small problems: N = 1000, M = 32: 981 -> 1765 E-steps/s, 5000 x 128: 1206 -> 2035.  Since round 3 a captured step
+        forks the K(X, Z) fill and the epilogue's operands onto the side stream INSIDE the capture (event fork / join), so a
+        replay no longer serialises what an eager step overlaps and never loses; "auto" still stops at N * M = 2e8 because a
+        graph owns its work buffers (K(X, Z) among them: 1.6 GB there) beside the eager path's."""
         if self.use_graph == "auto":
             return X.shape[0] * self.num_inducing <= self.GRAPH_AUTO_MAX_NM
         return bool(self.use_graph)
@@ -772,6 +778,9 @@ class t_SVGP(base_SVGP):
                         bl1.copy_(sl1)
                         bL.copy_(sL)
                         st, ops = self._step_front(X, Y, lr, jitter, routes)
+                        if ops.get("epi_event") is not None:  # the side stream's branch ends inside THIS graph
+                            torch.cuda.current_stream(self.device).wait_event(ops["epi_event"])
+                            ops["epi_event"] = None
                         packed = D_.pack_stats(st, True, eng)
                     tail = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(tail, pool=graph.pool()):

@@ -5,7 +5,7 @@ import collections, csv, re, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 step = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 4
-idx = [i for i, r in enumerate(rows) if "panel_kernel<double, 1, 1" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(rows) if "panel1_kernel" in r["Kernel_Name"] or "panel_kernel<double, 1, 1" in r["Kernel_Name"]]
 i = idx[step]
 a = max(j for j in range(i) if "syrk_reduce" in rows[j]["Kernel_Name"])
 def short(n):

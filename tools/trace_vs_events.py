@@ -9,7 +9,14 @@ b = json.loads(line)
 W, K = b["warmup"], b["steps"]
 print(f"rocprofv3 --kernel-trace of bench.py --steps {K} --warmup {W} (workload {b['config']['workload'][:40]}): per-launch durations from the")
 print("trace against the HIP-event means bench.py printed in the SAME run (timed launches = launches W+1 .. W+K of each kernel).\n")
-for pat, key, extra in (("panel_kernel<double, 1, 1, true>", "tsvgp_moments", None), ("syrk_kernel<double>", "tsvgp_site_accum", "syrk_reduce_kernel<double>")):
+# round 3: the fp64 moments / site sums run panel1_kernel / syrk1_kernel; older builds panel_kernel<double, 1, 1, true> / syrk_kernel<double>
+def first_present(*pats):
+    for pat in pats:
+        if any(pat in r["Kernel_Name"] for r in rows):
+            return pat
+    return pats[0]
+for pat, key, extra in ((first_present("panel1_kernel", "panel_kernel<double, 1, 1, true>"), "tsvgp_moments", None),
+                        (first_present("syrk1_kernel", "syrk_kernel<double>"), "tsvgp_site_accum", "syrk_reduce_kernel<double>")):
     ms = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows if pat in r["Kernel_Name"]]
     timed = ms[W:W + K]
     ex = 0.0
