@@ -131,3 +131,34 @@ def broadcast_from_rank0(t: torch.Tensor) -> torch.Tensor:
     if collectives_on():
         dist.broadcast(t, src=0)
     return t
+
+
+def all_reduce_max(t: torch.Tensor) -> torch.Tensor:
+    """In-place maximum over ranks (status words of a latent-split step: every rank raises or retries together)."""
+    if collectives_on():
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return t
+
+
+def all_gather_flat(send: torch.Tensor) -> torch.Tensor:
+    """[world * n] <- every rank's [n] (same n on every rank), in rank order; a single process gets its own back."""
+    if not collectives_on():
+        return send
+    out = torch.empty(dist.get_world_size() * send.numel(), dtype=send.dtype, device=send.device)
+    dist.all_gather_into_tensor(out, send.contiguous())
+    return out
+
+
+def reduce_scatter_sum(packed: torch.Tensor, world: int) -> torch.Tensor:
+    """This rank's [n / world] slice of the sum over ranks of ``packed`` [n] (slices in rank order).  RCCL: one
+    reduce_scatter; gloo (CPU tests, rehearsals) has none: an all-reduce and a slice, the same numbers."""
+    if not collectives_on():
+        return packed
+    n = packed.numel() // world
+    if dist.get_backend() == "nccl":
+        out = torch.empty(n, dtype=packed.dtype, device=packed.device)
+        dist.reduce_scatter_tensor(out, packed.contiguous(), op=dist.ReduceOp.SUM)
+        return out
+    dist.all_reduce(packed, op=dist.ReduceOp.SUM)
+    r = dist.get_rank()
+    return packed[r * n:(r + 1) * n]

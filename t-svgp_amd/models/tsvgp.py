@@ -164,7 +164,7 @@ class t_SVGP(base_SVGP):
     def __init__(self, kernel, likelihood, inducing_variable, *, mean_function=None, num_latent_gps: int = 1,
                  lambda_1=None, lambda_2_sqrt=None, num_data=None, force=False, compute_dtype=None, device=None,
                  cache_whitened=False, projection="auto", use_graph="auto", skip_unused_variance=False,
-                 overlap_fill=True):
+                 overlap_fill=True, latent_split=None):
         super().__init__(kernel, likelihood, inducing_variable, mean_function=mean_function,
                          num_latent_gps=num_latent_gps, num_data=num_data, compute_dtype=compute_dtype, device=device)
         self.num_inducing = self.inducing_variable.num_inducing
@@ -202,6 +202,8 @@ class t_SVGP(base_SVGP):
         self.skip_unused_variance = skip_unused_variance
         # natgrad_step starts the K(X, Z) fill on a side stream before the M x M prelude (EStepEngine.start_fill)
         self.overlap_fill = overlap_fill
+        # one kernel per latent on several ranks: split the latents' M x M algebra over the ranks (see _latent_split)
+        self.latent_split = latent_split
         self.name = "t_svgp"  # tf.Module derives this from the class name (experiments/uci_regression.py:150)
 
     def _init_variational_parameters(self, num_inducing, lambda_1, lambda_2_sqrt, **kwargs):
@@ -300,7 +302,7 @@ class t_SVGP(base_SVGP):
     def _use_direct(self, jitter) -> list:
         return [r == "direct" for r in self._routes(jitter)]
 
-    def _site_operands(self, whiten_jitter=None, warm_key=None, routes=None):
+    def _site_operands(self, whiten_jitter=None, warm_key=None, routes=None, latents=None):
         """Everything the N-pass needs that depends only on (theta, Z, lambda): O(M^3), fp64, replicated.
         No host synchronisation happens here: Cholesky statuses are collected in ops["infos"] and checked once per
         call by ``_check_step`` (TF raises immediately; here the raise comes at the end of the same call).
@@ -314,12 +316,19 @@ class t_SVGP(base_SVGP):
         M = Z.shape[0]
         infos = []
         warm = self._warm if (warm_key is not None and self._warm is not None and self._warm[0] == warm_key) else None
-        Kzz = warm[1]["Kzz"] if warm else eng.kuu(Z, self.kernel)  # HIP fill kernel, no jitter
+        kernel = self.kernel
+        l1 = self.lambda_1.value
+        L = self.lambda_2_sqrt.value
+        if latents is not None:
+            # the latent GPs this rank owns (one kernel per latent, several ranks: ``_step_device_split``): everything below is
+            # per latent, so the subset is a smaller batch of the same algebra.  ``routes`` is already the subset's.
+            idx = torch.as_tensor(list(latents), device=l1.device)
+            kernel = SeparateIndependent([self.kernel.kernels[p] for p in latents])
+            l1, L = l1.index_select(1, idx), L.index_select(0, idx)
+        Kzz = warm[1]["Kzz"] if warm else eng.kuu(Z, kernel)  # HIP fill kernel, no jitter
         Id = self._eye(M)
         K6 = Kzz.clone()
         K6.diagonal(dim1=-2, dim2=-1).add_(default_jitter())  # tsvgp.py:209-211
-        l1 = self.lambda_1.value
-        L = self.lambda_2_sqrt.value
         P_ = L.shape[0]
         potrf = getattr(eng, "cholesky", None)  # HIP blocked Cholesky (tsvgp_potrf_f64)
         if potrf is not None and routes is not None and any(r == "projected" for r in routes):
@@ -364,7 +373,7 @@ class t_SVGP(base_SVGP):
         DKl = bmv(Dm, _kmv(K6, l1))  # [M, P]
         beta = l1 - bmv(Dm, DKl, transpose=True)  # K6^-1 m = l1 - D^T D K6 l1
         ops = dict(Z=Z, Kzz=Kzz, K6=K6, D=Dm, U_W=U_W, beta=beta, Id=Id, infos=infos, potrf=potrf,
-                   routes=["whitened"] * self.num_latent_gps, moment_mode=B.TRI_UPPER, whiten_mode=B.TRI_UPPER,
+                   routes=["whitened"] * P_, moment_mode=B.TRI_UPPER, whiten_mode=B.TRI_UPPER,
                    whiten_T=None, project_T=None)
         if whiten_jitter is None:
             return ops
@@ -411,7 +420,7 @@ class t_SVGP(base_SVGP):
             return ops
         if warm_key is not None and not warm:
             self._warm = (warm_key, dict(Kzz=Kzz, U9=U9, Uinv9=Uinv9))
-        routes = list(routes) if routes is not None else ["whitened"] * self.num_latent_gps
+        routes = list(routes) if routes is not None else ["whitened"] * P_
         ops["routes"] = routes
         if all(r == "direct" for r in routes):
             # direct projection: the moments act on K_fu with D itself, the sums are mapped by K9^-1 (.) K9^-1
@@ -708,8 +717,118 @@ class t_SVGP(base_SVGP):
         """The whole E-step as device work, no host synchronisation: M x M prelude, N-pass, all-reduce, epilogue, state
         assignment.  Returns the status flags (device).  With ``inplace`` the state tensors are overwritten in place
         (what a captured graph needs) instead of being replaced."""
+        if not inplace and self._latent_split(routes):
+            return self._step_device_split(X, Y, lr, jitter, routes)
         st, ops = self._step_front(X, Y, lr, jitter, routes)
         return self._apply_site_update(st, ops, lr, jitter, inplace=inplace)
+
+    # -- one kernel per latent over several ranks: the M x M work split over the latents (SURVEY 8(e), BASELINE configs[4]) ----
+    def _latent_split(self, routes) -> bool:
+        """With one kernel per latent (K_uu [P, M, M]) the replicated M x M prelude / epilogue is P factorisation pairs and a
+        dozen GEMMs per latent -- ~20 ms of a 34 ms 8-way shard step at P = 8, M = 1024 -- so with several ranks every latent
+        gets ONE owner (p mod world).  ``latent_split``: None = whenever that applies, False = never."""
+        if self.latent_split is False or not isinstance(self.kernel, SeparateIndependent) or not self._reduce():
+            return False
+        if D_.world_size() < 2 and not D_.FORCE_COLLECTIVES:
+            return False
+        # "projected" latents factor K9 in the reference's elimination order inside a uniformly projected batch: not split
+        return self.num_latent_gps >= 2 and all(r in ("direct", "whitened") for r in routes) and not self.cache_whitened
+
+    def _step_device_split(self, X, Y, lr, jitter, routes) -> torch.Tensor:
+        """One E-step with the latents' M x M algebra split over the ranks (reference src/models/tsvgp.py:249-254, 268-303 with
+        K_uu [P, M, M]; docs/notebooks/heteroskedastic.py:62-76):
+          1. prelude for the OWNED latents only (factorisations, D_p, beta_p, and U9_p^-1 where the latent is whitened);
+          2. all-gather of what the N-pass needs of every latent: [D_p | gamma_p (| U9_p^-1)];
+          3. the N-pass over this rank's rows for ALL latents (the batched launches);
+          4. reduce-scatter of the packed accumulators BY LATENT (the owner receives the sums over all ranks' rows) + one
+             tiny all-reduce of (sum ve, #var <= 0, rows);
+          5. epilogue for the owned latents; all-gather of the new (lambda_1[:, p], lambda_2_sqrt[p]); the status words are
+             max-reduced so that every rank raises or retries together.
+        Returns the status flags (device); the state is assigned on every rank."""
+        eng = self._get_engine()
+        P, M = self.num_latent_gps, self.num_inducing
+        G, r = max(D_.world_size(), 1), D_.rank()
+        own = [p for p in range(P) if p % G == r]
+        per = (P + G - 1) // G  # latents per rank, the last ranks padded with empty slots
+        owner_order = [p for q in range(G) for p in range(q, P, G)]
+        dev, f64 = self.device, torch.float64
+        tri = M * (M + 1) // 2
+        pre = None
+        if self.overlap_fill and hasattr(eng, "start_fill"):
+            pre = eng.start_fill(X, self._Z(), self.kernel, want="B", routes=routes)
+        # 1. prelude of the owned latents (a rank without latents still takes part in the collectives)
+        ops = self._site_operands(whiten_jitter=jitter, routes=[routes[p] for p in own], latents=own) if own else None
+        # 2. all-gather of the N-pass operands, one fixed-size slot per latent: D | gamma | U9^-1 (zeros when direct)
+        slot = 2 * M * M + M
+        send = torch.zeros(per * slot, dtype=f64, device=dev)
+        for i, p in enumerate(own):
+            o = i * slot
+            send[o:o + M * M] = ops["moment_Tm"][i].reshape(-1)
+            send[o + M * M:o + M * M + M] = ops["gamma"][:, i]
+            wt = eng._per_latent(ops["whiten_T"], i) if hasattr(eng, "_per_latent") else (
+                None if ops["whiten_T"] is None else (ops["whiten_T"][i] if isinstance(ops["whiten_T"], (list, tuple)) else
+                                                      (ops["whiten_T"][i] if ops["whiten_T"].dim() == 3 else ops["whiten_T"])))
+            if routes[p] != "direct" and wt is not None:
+                send[o + M * M + M:o + slot] = wt.reshape(-1)
+        allops = D_.all_gather_flat(send).reshape(G, per, slot)
+        Tm_full = torch.empty((P, M, M), dtype=f64, device=dev)
+        gamma_full = torch.empty((M, P), dtype=f64, device=dev)
+        whiten_full = [None] * P
+        for p in range(P):
+            blk = allops[p % G, p // G]
+            Tm_full[p] = blk[:M * M].reshape(M, M)
+            gamma_full[:, p] = blk[M * M:M * M + M]
+            if routes[p] != "direct":
+                whiten_full[p] = blk[M * M + M:].reshape(M, M)
+        if all(wt is None for wt in whiten_full):
+            whiten_full = None
+        # 3. the N-pass: every latent over this rank's rows
+        st = eng.run(X, Y, self._Z(), self.kernel, moment_Tm=Tm_full, prefill=pre, moment_mode=B.TRI_UPPER, gamma=gamma_full,
+                     lik_id=self.likelihood.lik_id, lik_param=self.likelihood.lik_param, whiten_T=whiten_full,
+                     whiten_mode=B.TRI_UPPER, project_T=None, sites=True,
+                     mean_only=self.skip_unused_variance and self.likelihood.lik_id == B.LIK_GAUSSIAN)
+        # 4. reduce-scatter by latent (slots in owner order) + the three scalars
+        blk = tri + M
+        packed = torch.zeros(G * per * blk, dtype=f64, device=dev)
+        acc2, acc1 = st.acc2.to(f64), st.acc1.to(f64)
+        i_, j_ = torch.tril_indices(M, M, device=dev)
+        for q in range(G):
+            for i, p in enumerate(range(q, P, G)):
+                o = (q * per + i) * blk
+                packed[o:o + tri] = acc2[p][i_, j_]
+                packed[o + tri:o + blk] = acc1[p]
+        mine = D_.reduce_scatter_sum(packed, G)
+        scal = torch.stack([st.ve_sum.reshape(()).to(f64), st.nonpos.reshape(()).to(f64),
+                            torch.full((), float(st.n_rows), dtype=f64, device=dev)])
+        D_.all_reduce_sum(scal)
+        nonpos, rows = scal[1], scal[2]
+        # 5. epilogue of the owned latents, then the new state to every rank
+        state = torch.zeros(per * blk, dtype=f64, device=dev)
+        flags = torch.zeros(3, dtype=f64, device=dev)
+        if own:
+            a2 = torch.zeros((len(own), M, M), dtype=f64, device=dev)
+            a1 = torch.empty((len(own), M), dtype=f64, device=dev)
+            for i in range(len(own)):
+                v = mine[i * blk:i * blk + tri]
+                a2[i][i_, j_] = v
+                a2[i][j_, i_] = v
+                a1[i] = mine[i * blk + tri:(i + 1) * blk]
+            flags, l1_new, L_new = self._apply_site_update(None, ops, lr, jitter, reduced=(a2, a1, nonpos, rows), latents=own)
+            for i in range(len(own)):
+                state[i * blk:i * blk + tri] = L_new[i][i_, j_]
+                state[i * blk + tri:(i + 1) * blk] = l1_new[:, i]
+        else:
+            flags[1] = nonpos
+        allstate = D_.all_gather_flat(state).reshape(G, per, blk)
+        L_full = torch.zeros((P, M, M), dtype=f64, device=dev)
+        l1_full = torch.empty((M, P), dtype=f64, device=dev)
+        for p in range(P):
+            sb = allstate[p % G, p // G]
+            L_full[p][i_, j_] = sb[:tri]
+            l1_full[:, p] = sb[tri:]
+        self.lambda_1.assign_owned(l1_full)
+        self.sites.assign_lambda_2_sqrt(L_full, lower_and_owned=True)
+        return D_.all_reduce_max(flags.abs())
 
     # -- hipGraph replay of the step (launch-bound problem sizes) -------------------------------------------------
     GRAPH_AUTO_MAX_NM = 200_000_000  # "auto": replay when N * M is at most this (tools/bench_graph_sizes.py, below)
@@ -828,7 +947,7 @@ class t_SVGP(base_SVGP):
         Lp.version += 1
         return True
 
-    def _apply_site_update(self, st, ops, lr, jitter, inplace=False, reduced=None):
+    def _apply_site_update(self, st, ops, lr, jitter, inplace=False, reduced=None, latents=None):
         """All-reduce of the packed accumulators (RCCL) + the replicated M x M epilogue (tsvgp.py:278-303).
         Returns the status flags (device tensor, see ``_status_flags``).  ``reduced``: the already summed
         (acc2, acc1, nonpos, rows) when the caller did the collective itself (the two-graph replay)."""
@@ -875,10 +994,15 @@ class t_SVGP(base_SVGP):
             target = (1.0 - lr) * ops["LLt"] + (-2.0 * lr * scale) * G1
             target.diagonal(dim1=-2, dim2=-1).add_(jitter)
         grad_mu = gradient_transformation_mean_var_to_expectation(ops["meanZ"], [G0, G1])  # tsvgp.py:284
-        lambda_1 = (1 - lr) * self.lambda_1.value + lr * scale * grad_mu[0]  # tsvgp.py:296
+        l1_old = self.lambda_1.value
+        if latents is not None:
+            l1_old = l1_old.index_select(1, torch.as_tensor(list(latents), device=l1_old.device))
+        lambda_1 = (1 - lr) * l1_old + lr * scale * grad_mu[0]  # tsvgp.py:296
         final_info = []
         # tsvgp.py:300; the leading minus rides on the factorisation's triangle copy, which also leaves exact zeros above
         lambda_2_sqrt = cholesky_deferred(target, final_info, ops["potrf"], overwrite=True, scale=-1.0)
+        if latents is not None:  # the owner's part of a latent-split step: the caller gathers and assigns
+            return self._status_flags(ops, nonpos, final_info), lambda_1, lambda_2_sqrt
         if inplace:
             self.lambda_1.value.copy_(lambda_1)
             self.lambda_2_sqrt.value.copy_(lambda_2_sqrt)

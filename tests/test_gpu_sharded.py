@@ -199,3 +199,54 @@ def test_rccl_single_rank_drives_the_collective_path(tmp_path):
         assert relerr(got[tag + "_L2"], ora.lambda_2) < 1e-8
         assert abs(float(got[tag + "_elbo"]) - e) < 1e-9 * abs(e)
         assert abs(float(got[tag + "_elbo2"]) - e) < 1e-9 * abs(e)
+
+
+def _worker_split(rank, world, port, out, backend):
+    """One kernel per latent on several ranks: the latents' M x M algebra split over the ranks (t_SVGP._step_device_split)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        p = pkg()
+        if world == 1:
+            p.distributed.FORCE_COLLECTIVES = True
+        P = 3
+        X, Y, Z = synthetic(N=3001, M=130, D=3, P=P, lik="gaussian", seed=13)
+        ls = (0.9, 1.6, 1.2)  # the middle latent's K_uu is beyond the direct route's gate at this geometry: mixed routes
+        kern = lambda mod: mod.SeparateIndependent([mod.SquaredExponential(1.0, l) for l in ls])
+        m = p.t_SVGP(kern(p), p.Gaussian(0.1), p.SharedIndependentInducingVariables(Z), num_latent_gps=P, num_data=3001,
+                     device="cuda:0")
+        Xs, Ys = p.distributed.shard_rows(X, Y)
+        Xd, Yd = torch.as_tensor(Xs, device="cuda:0"), torch.as_tensor(Ys, device="cuda:0")
+        routes = m._routes(1e-9)
+        assert m._latent_split(routes)
+        for _ in range(3):
+            m.natgrad_step((Xd, Yd), lr=0.8)
+        e = float(m.elbo((Xd, Yd)))
+        if rank == 0:
+            np.savez(out, l1=m.lambda_1.numpy(), L2=m.lambda_2.cpu().numpy(), elbo=e, routes=np.array(routes))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,backend", [(2, "gloo"), (1, "nccl")])
+def test_latent_split_over_ranks_matches_oracle(tmp_path, world, backend):
+    """BASELINE configs[4] across GPUs: every latent's prelude / epilogue has one owner, the N-pass operands
+    are all-gathered, the accumulators reduce-scattered by latent, the new state all-gathered.  Two ranks on the one GPU
+    over gloo, and one rank over RCCL with the collectives forced (all_gather_into_tensor / reduce_scatter_tensor on device
+    buffers); against the oracle (reference src/models/tsvgp.py:249-254, 268-303 with K_uu [P, M, M])."""
+    out = str(tmp_path / "r0.npz")
+    port = 21500 + (os.getpid() % 2000) + world
+    mp.spawn(_worker_split, args=(world, port, out, backend), nprocs=world, join=True)
+    got = np.load(out)
+    X, Y, Z = synthetic(N=3001, M=130, D=3, P=3, lik="gaussian", seed=13)
+    ora = O.t_SVGP(O.SeparateIndependent([O.SquaredExponential(1.0, l) for l in (0.9, 1.6, 1.2)]), O.Gaussian(0.1),
+                   O.SharedIndependentInducingVariables(Z), num_latent_gps=3, num_data=3001)
+    for _ in range(3):
+        ora.natgrad_step((X, Y), lr=0.8)
+    assert relerr(got["l1"], ora.lambda_1) < 1e-8
+    assert relerr(got["L2"], ora.lambda_2) < 1e-8
+    assert abs(float(got["elbo"]) - ora.elbo((X, Y))) < 1e-9 * abs(ora.elbo((X, Y)))

@@ -191,6 +191,7 @@ def _worker(rank, world, port, lik, P, out, kind="plain"):
         Xs, Ys = p.distributed.shard_rows(X, Y)
         hip, _ = _pair(Z, lik, P, num_data=401, kind=kind)
         assert hip._reduce()
+        assert hip._latent_split(hip._routes(1e-9)) == (kind == "separate")  # one kernel per latent: the M x M work is split
         for _ in range(3):
             hip.natgrad_step((Xs, Ys), lr=0.8)
         elbo = float(hip.elbo((Xs, Ys)))
@@ -216,9 +217,11 @@ def test_sharded_estep_gloo_world2_matches_single_process_oracle(tmp_path, lik, 
     assert abs(float(got["elbo"]) - ora.elbo((X, Y))) < 1e-9 * abs(ora.elbo((X, Y)))
 
 
-@pytest.mark.parametrize("kind,lik,P", [("white", "bernoulli", 1), ("separate", "gaussian", 2)])
+@pytest.mark.parametrize("kind,lik,P", [("white", "bernoulli", 1), ("separate", "gaussian", 2), ("separate", "bernoulli", 3)])
 def test_sharded_variants_gloo_world2(tmp_path, kind, lik, P):
-    """The same world_size-2 shard + all-reduce path for t_SVGP_white and for separate per-latent kernels."""
+    """The same world_size-2 shard + all-reduce path for t_SVGP_white, and separate per-latent kernels, whose M x M algebra is
+    SPLIT over the ranks by latent (``t_SVGP._step_device_split``: all-gather of the N-pass operands, reduce-scatter of the sums
+    by latent, all-gather of the new state; P = 3 on two ranks leaves rank 1 a padded slot)."""
     out = str(tmp_path / "r0.npz")
     port = 31500 + (os.getpid() % 2000)
     mp.spawn(_worker, args=(2, port, lik, P, out, kind), nprocs=2, join=True)
