@@ -214,15 +214,15 @@ def _worker_split(rank, world, port, out, backend):
         if world == 1:
             p.distributed.FORCE_COLLECTIVES = True
         P = 3
-        X, Y, Z = synthetic(N=3001, M=130, D=3, P=P, lik="gaussian", seed=13)
-        ls = (0.9, 1.6, 1.2)  # the middle latent's K_uu is beyond the direct route's gate at this geometry: mixed routes
+        X, Y, Z = synthetic(N=3001, M=130, D=5, P=P, lik="gaussian", seed=13)
+        ls = (0.9, 1.6, 1.2)  # cond(K_uu + 1e-9 I) = 9e2, 1.8e5, 1.1e4: the middle latent is beyond the direct route's gate
         kern = lambda mod: mod.SeparateIndependent([mod.SquaredExponential(1.0, l) for l in ls])
         m = p.t_SVGP(kern(p), p.Gaussian(0.1), p.SharedIndependentInducingVariables(Z), num_latent_gps=P, num_data=3001,
                      device="cuda:0")
         Xs, Ys = p.distributed.shard_rows(X, Y)
         Xd, Yd = torch.as_tensor(Xs, device="cuda:0"), torch.as_tensor(Ys, device="cuda:0")
         routes = m._routes(1e-9)
-        assert m._latent_split(routes)
+        assert routes == ["direct", "whitened", "direct"] and m._latent_split(routes)
         for _ in range(3):
             m.natgrad_step((Xd, Yd), lr=0.8)
         e = float(m.elbo((Xd, Yd)))
@@ -242,7 +242,7 @@ def test_latent_split_over_ranks_matches_oracle(tmp_path, world, backend):
     port = 21500 + (os.getpid() % 2000) + world
     mp.spawn(_worker_split, args=(world, port, out, backend), nprocs=world, join=True)
     got = np.load(out)
-    X, Y, Z = synthetic(N=3001, M=130, D=3, P=3, lik="gaussian", seed=13)
+    X, Y, Z = synthetic(N=3001, M=130, D=5, P=3, lik="gaussian", seed=13)
     ora = O.t_SVGP(O.SeparateIndependent([O.SquaredExponential(1.0, l) for l in (0.9, 1.6, 1.2)]), O.Gaussian(0.1),
                    O.SharedIndependentInducingVariables(Z), num_latent_gps=3, num_data=3001)
     for _ in range(3):
