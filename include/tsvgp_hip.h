@@ -172,6 +172,16 @@ int tsvgp_moments_f32(const float *A, const float *Tm, const float *gamma, const
                       double lik_param, float *mean, float *var, float *g0, float *g1, double *ve_partial,
                       int32_t *nonpos_partial, int64_t N, int64_t Np, int Mp, int P, int mode, void *stream);
 
+/* (4) The likelihood-gradient map on its own (reference src/models/tsvgp.py:256-263: GPflow variational_expectations [ext] +
+ *     tf.GradientTape): mean, var, Y [N x P] -> g0 = d ve / d mean, g1 = d ve / d var [Np x P] (rows >= N zero; g1 cropped at
+ *     -1e-8 unless TSVGP_LIK_NOCROP), ve_partial / nonpos_partial [Np / 128] as tsvgp_moments_*.  lik = TSVGP_LIK_GAUSSIAN
+ *     (lik_param = noise variance) or TSVGP_LIK_BERNOULLI.  The moments kernels run this map in their epilogue; this entry
+ *     point serves a caller that assembled the moments itself (t_SVGP_white's two-product variance). */
+int tsvgp_lik_map_f64(const double *mean, const double *var, const double *Y, int lik, double lik_param, double *g0, double *g1,
+                      double *ve_partial, int32_t *nonpos_partial, int64_t N, int64_t Np, int P, void *stream);
+int tsvgp_lik_map_f32(const float *mean, const float *var, const float *Y, int lik, double lik_param, float *g0, float *g1,
+                      double *ve_partial, int32_t *nonpos_partial, int64_t N, int64_t Np, int P, void *stream);
+
 /* (3b) The moments for P latents with one kernel each: latent p has its own operand A + p*strideA ([Np x Mp] each; strideA = 0
  *     is the shared operand of tsvgp_moments_*) and its own prior variance kdiag_host[p] (HOST array of P doubles, passed
  *     as kernel arguments).  1 <= P <= TSVGP_MAX_BATCH.  Everything else as tsvgp_moments_*; one launch, each workgroup

@@ -96,6 +96,10 @@ _PROTOTYPES = {
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_void_p]),
     "tsvgp_moments_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_int, c_double, c_void_p, c_void_p,
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_void_p]),
+    "tsvgp_lik_map_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
+                                  c_int, c_void_p]),
+    "tsvgp_lik_map_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
+                                  c_int, c_void_p]),
     "tsvgp_site_accum_work_bytes_f64": (c_int64, [c_int, c_int, c_int]),
     "tsvgp_site_accum_work_bytes_f32": (c_int64, [c_int, c_int, c_int]),
     "tsvgp_site_accum_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),

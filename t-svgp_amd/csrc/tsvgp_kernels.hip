@@ -1329,6 +1329,71 @@ __global__ __launch_bounds__(NTHREADS, 1) void panel1_kernel(PanelArgs<double> a
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// lik_map_kernel: the likelihood-gradient map on its own: (mean, var, Y) -> g0 = d ve / d mean,
+// g1 = d ve / d var (cropped at -1e-8 unless TSVGP_LIK_NOCROP), per-128-row sums of ve and counts of non-positive variances --
+// what the moments kernels do in their epilogue, for a caller that assembled the moments itself (t_SVGP_white's two-product
+// variance).  Reference src/models/tsvgp.py:256-263.  One workgroup per 128 rows, two threads per row (the Bernoulli
+// quadrature split as in panel_kernel).  O(N P): microseconds.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(NTHREADS) void lik_map_kernel(const T* __restrict__ mean, const T* __restrict__ var,
+                                                           const T* __restrict__ Y, int lik, double lik_param,
+                                                           T* __restrict__ g0o, T* __restrict__ g1o, double* __restrict__ ve_partial,
+                                                           int32_t* __restrict__ nonpos_partial, int64_t N, int P) {
+    __shared__ double red[NTHREADS / 64];
+    __shared__ int redi[NTHREADS / 64];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int srow = t >> 1, skh = t & 1;
+    const int64_t n = (int64_t)blockIdx.x * TILE + srow;
+    const bool live = n < N;
+    double ve_acc = 0.0;
+    int nonpos = 0;
+    for (int p = 0; p < P; ++p) {
+        const double mu = live ? (double)mean[n * P + p] : 0.0;
+        const double v = live ? (double)var[n * P + p] : 1.0;
+        double g0 = 0.0, g1 = 0.0, ve = 0.0;
+        if ((lik & 0xFF) == TSVGP_LIK_BERNOULLI) {
+            double a0, a1, av;
+            const double sd = sqrt(v);
+            bern_sums(mu, sd, live && (double)Y[n * P + p] == 1.0, skh * 5, skh * 5 + 5, a0, a1, av);
+            a0 += __shfl_xor(a0, 1);
+            a1 += __shfl_xor(a1, 1);
+            av += __shfl_xor(av, 1);
+            g0 = a0;
+            g1 = a1 / (2.0 * sd);
+            if (!(lik & TSVGP_LIK_NOCROP)) g1 = fmin(g1, -1e-8);
+            ve = av;
+        } else if (live) {
+            lik_eval(lik, lik_param, mu, v, (double)Y[n * P + p], g0, g1, ve);
+        }
+        if (skh == 0) {
+            if (live) {
+                if (!(v > 0.0)) nonpos += 1;
+                ve_acc += ve;
+            }
+            g0o[n * P + p] = (T)(live ? g0 : 0.0);  // rows >= N of the [Np x P] outputs: zeros
+            g1o[n * P + p] = (T)(live ? g1 : 0.0);
+        }
+    }
+    double s = ve_acc;
+    int c = nonpos;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_xor(s, o);
+        c += __shfl_xor(c, o);
+    }
+    if (lane == 0) {
+        red[w] = s;
+        redi[w] = c;
+    }
+    __syncthreads();
+    if (t == 0) {
+        ve_partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+        nonpos_partial[blockIdx.x] = redi[0] + redi[1] + redi[2] + redi[3];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // mean_lik_kernel (TSVGP_LIK_MEANONLY): mean[n, p] = sum_j A[n, j] * gamma[j, p] and, for the Gaussian likelihood,
 // g0 = (y - mean) / s2, g1 = -1 / (2 s2) -- neither depends on the predictive variance.  HBM bound: one sweep of A.
 // One workgroup per 128-row panel (same grid as panel_kernel, so the per-workgroup partial buffers keep their
@@ -2921,6 +2986,20 @@ int trmm(const T* A, int64_t strideA, const T* Tm, int64_t strideT, T* C, int64_
     return launch_status();
 }
 
+template <typename T>
+int lik_map(const T* mean, const T* var, const T* Y, int lik, double lik_param, T* g0, T* g1, double* ve_partial,
+            int32_t* nonpos_partial, int64_t N, int64_t Np, int P, void* stream) {
+    if (!mean || !var || !Y || !g0 || !g1 || !ve_partial || !nonpos_partial || N <= 0 || Np < N || (Np % TILE) || P <= 0)
+        return TSVGP_EINVAL;
+    if (lik & ~(0xFF | TSVGP_LIK_NOCROP)) return TSVGP_EINVAL;
+    const int base = lik & 0xFF;
+    if (base != TSVGP_LIK_GAUSSIAN && base != TSVGP_LIK_BERNOULLI) return TSVGP_EINVAL;
+    if (base == TSVGP_LIK_GAUSSIAN && !(lik_param > 0.0)) return TSVGP_EINVAL;
+    hipLaunchKernelGGL(lik_map_kernel<T>, dim3((unsigned)(Np / TILE)), dim3(NTHREADS), 0, (hipStream_t)stream, mean, var, Y, lik,
+                       lik_param, g0, g1, ve_partial, nonpos_partial, N, P);
+    return launch_status();
+}
+
 // kdiag: HOST array of P values (one kernel variance per latent), or of ONE value with kdiag_uniform (a shared kernel, any P).
 template <typename T>
 int moments(const T* A, int64_t strideA, const T* Tm, const T* gamma, const T* Y, const double* kdiag, bool kdiag_uniform,
@@ -3236,6 +3315,14 @@ int tsvgp_trmm_batched_f32(const float* A, int64_t strideA, const float* Tm, int
     return trmm<float>(A, strideA, Tm, strideT, C, strideC, Np, Mp, mode, batch, stream);
 }
 
+int tsvgp_lik_map_f64(const double* mean, const double* var, const double* Y, int lik, double lik_param, double* g0, double* g1,
+                      double* ve_partial, int32_t* nonpos_partial, int64_t N, int64_t Np, int P, void* stream) {
+    return lik_map<double>(mean, var, Y, lik, lik_param, g0, g1, ve_partial, nonpos_partial, N, Np, P, stream);
+}
+int tsvgp_lik_map_f32(const float* mean, const float* var, const float* Y, int lik, double lik_param, float* g0, float* g1,
+                      double* ve_partial, int32_t* nonpos_partial, int64_t N, int64_t Np, int P, void* stream) {
+    return lik_map<float>(mean, var, Y, lik, lik_param, g0, g1, ve_partial, nonpos_partial, N, Np, P, stream);
+}
 int tsvgp_moments_f64(const double* A, const double* Tm, const double* gamma, const double* Y, double kdiag, int lik,
                       double lik_param, double* mean, double* var, double* g0, double* g1, double* ve_partial,
                       int32_t* nonpos_partial, int64_t N, int64_t Np, int Mp, int P, int mode, void* stream) {

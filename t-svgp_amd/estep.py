@@ -791,16 +791,59 @@ class EStepEngine:
             self.trmm(A, self._pad_square(project_T, Mp, "pad_proj"), Aproj, project_mode)
             A = Aproj
         if sites:
-            nsplit = self.nsplit_override or self.choose_nsplit(Mp, P, Np)
-            nsplit = max(1, min(nsplit, Np // 16))
-            nbytes = int(self._fn("tsvgp_site_accum_work_bytes")(Mp, P, nsplit))
-            work = self._get("work", (nbytes,), torch.uint8)
-            acc2 = torch.empty((P, Mp, Mp), dtype=torch.float64, device=dev)
-            acc1 = torch.empty((P, Mp), dtype=torch.float64, device=dev)
+            stats.acc2, stats.acc1 = self._site_sums(A, g0, g1, P, M)
+        return stats
+
+    def _site_sums(self, A, g0, g1, P, M):
+        """(sum_n g1 a a^T [P, M, M], sum_n g0 a [P, M]) over the rows of one operand A [Np, Mp] shared by the P latents
+        (``tsvgp_site_accum_*``); g0, g1 [Np, P] with zero padding rows."""
+        dev = self.device
+        Np, Mp = A.shape
+        nsplit = self.nsplit_override or self.choose_nsplit(Mp, P, Np)
+        nsplit = max(1, min(nsplit, Np // 16))
+        nbytes = int(self._fn("tsvgp_site_accum_work_bytes")(Mp, P, nsplit))
+        work = self._get("work", (nbytes,), torch.uint8)
+        acc2 = torch.empty((P, Mp, Mp), dtype=torch.float64, device=dev)
+        acc1 = torch.empty((P, Mp), dtype=torch.float64, device=dev)
+        with torch.cuda.device(dev):
+            self._launch("tsvgp_site_accum", lambda: self._fn("tsvgp_site_accum")(
+                A.data_ptr(), g0.data_ptr(), g1.data_ptr(), acc2.data_ptr(), acc1.data_ptr(), work.data_ptr(), Np,
+                Mp, P, nsplit, self._stream()))
+        return acc2[:, :M, :M], acc1[:, :M]
+
+    def run_two_product(self, X, Y, Z, kernel, *, whiten_T, moment_Tm, gamma, lik_id=B.LIK_NONE, lik_param=0.0, sites=False,
+                        want_moments=False) -> EStepStats:
+        """The pass of ``t_SVGP_white`` with the reference's OWN two-product variance (src/util.py:76-86):
+            var = kff - |LA^-1 k|^2 + |LR^-1 k|^2 = kff - |b|^2 + |T2 b|^2,   b = U6^-1 k (whiten_T = U6^-1, upper form),
+        T2 = U_R^-1 U6 (``moment_Tm``, upper triangular), mean = b^T gamma.  Used when Lambda_2 + 1e-9 I is not positive definite
+        (the single triangular product of ``run`` needs its factor; the reference only needs K + Lambda_2 + 1e-9 I).  Sequence:
+        fill -> trmm (B) -> moments with NO likelihood (mean, kff - |T2 b|^2) -> |b|^2 by a row reduction of B -> the
+        likelihood map on the assembled moments (``tsvgp_lik_map_*``) -> site sums over B.  One shared kernel, one latent."""
+        T, dev = self.dtype, self.device
+        st = self.run(X, None, Z, kernel, moment_Tm=moment_Tm, moment_mode=B.TRI_UPPER, gamma=gamma, lik_id=B.LIK_NONE,
+                      whiten_T=whiten_T, whiten_mode=B.TRI_UPPER, want_moments=True)
+        N, M = X.shape[0], Z.shape[0]
+        Np, Mp = B.round_up(N), B.round_up(M)
+        Bw = self._buf["B"]  # the whitened operand of the pass just run
+        kff = kernel.variance.item()
+        bn = torch.linalg.vector_norm(Bw[:N], dim=1).to(torch.float64)
+        var = (2.0 * kff - bn * bn)[:, None] - st.var  # st.var = kff - |T2 b|^2
+        stats = EStepStats(n_rows=N, ve_sum=torch.zeros((), dtype=torch.float64, device=dev), nonpos=(~(var > 0)).sum().to(torch.float64))
+        if want_moments:
+            stats.mean, stats.var = st.mean, var
+        if lik_id != B.LIK_NONE:
+            Yc = Y.to(device=dev, dtype=T).contiguous()
+            mean_t, var_t = st.mean.to(T).contiguous(), var.to(T).contiguous()
+            nblk = Np // B.TILE
+            ve_partial = self._get("ve_partial", (nblk,), torch.float64)
+            nonpos_partial = self._get("nonpos_partial", (nblk,), torch.int32)
+            g0, g1 = self._get("g0", (Np, 1), T), self._get("g1", (Np, 1), T)
             with torch.cuda.device(dev):
-                self._launch("tsvgp_site_accum", lambda: self._fn("tsvgp_site_accum")(
-                    A.data_ptr(), g0.data_ptr(), g1.data_ptr(), acc2.data_ptr(), acc1.data_ptr(), work.data_ptr(), Np,
-                    Mp, P, nsplit, self._stream()))
-            stats.acc2 = acc2[:, :M, :M]
-            stats.acc1 = acc1[:, :M]
+                B.check(self._fn("tsvgp_lik_map")(mean_t.data_ptr(), var_t.data_ptr(), Yc.data_ptr(), lik_id, float(lik_param),
+                                                   g0.data_ptr(), g1.data_ptr(), ve_partial.data_ptr(), nonpos_partial.data_ptr(),
+                                                   N, Np, 1, self._stream()), "tsvgp_lik_map")
+            stats.ve_sum = ve_partial.sum()
+            stats.nonpos = nonpos_partial.sum().to(torch.float64)
+            if sites:
+                stats.acc2, stats.acc1 = self._site_sums(Bw, g0, g1, 1, M)
         return stats

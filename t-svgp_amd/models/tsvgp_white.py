@@ -21,6 +21,13 @@ triangular product on K(X, Z) itself;  mean = k^T (U6^-T gamma);  the sums run o
 N M^2 product fewer (56 -> 40 ms at N = 1e6, M = 1024); forming Q squares cond(K6), hence the gate, and a failed
 factorisation of Q sends the call back to the whitened route.
 
+Two-product form (round 3): when Lambda_2 + 1e-9 I has no Cholesky factor -- the class does not crop d ve / d var
+(tsvgp_white.py:188-191), so Lambda_2 can lose definiteness -- the table's single-product variance does not exist, while the
+reference, which only factors K6 and R, goes on.  The call is then repeated (and the model stays) on the reference's own form:
+var = kff - |b|^2 + |T2 b|^2 with T2 = U_R^-1 U6 (upper triangular), mean = b^T U6^T R^-1 lambda_1; |T2 b|^2 is one triangular
+product of the moments kernel, |b|^2 a row reduction of B, and the likelihood map runs on the assembled moments
+(``tsvgp_lik_map_*``, ``EStepEngine.run_two_product``).
+
 The whitened table rests on  |LA^-1 k|^2 - |LR^-1 k|^2 = b^T (I - (I + G)^-1) b  with  G = U6^-1 E U6^-T = H H^T  and
 I - (I + H H^T)^-1 = H (I + H^T H)^-1 H^T.  The reference's util functions take element [0] of a latent-batched product
 (util.py:87, :425), so the class is only defined for ONE latent GP; more raise NotImplementedError.
@@ -45,6 +52,12 @@ class _DirectRouteFailed(Exception):
     """The direct projection's own M x M factorisation failed: the caller repeats the call on the whitened route."""
 
 
+class _SingleProductFailed(Exception):
+    """Lambda_2 + 1e-9 I (or I + H^T H built on its factor) is not positive definite while K_uu's factorisations went through:
+    the single-product variance does not exist; the caller repeats the call with the reference's own two-product form, which
+    only needs K + Lambda_2 + 1e-9 I (src/util.py:73-86)."""
+
+
 class t_SVGP_white(base_SVGP):
     """Class for the t-SVGP model with whitened parameterization (reference tsvgp_white.py:23-246)."""
 
@@ -62,6 +75,7 @@ class t_SVGP_white(base_SVGP):
         self.projection = projection
         self._cond_cache = None
         self._direct_failed = False
+        self._two_product = False  # set once Lambda_2 + 1e-9 I failed to factor: the reference's two-product variance from then on
         if isinstance(kernel, SeparateIndependent):
             raise NotImplementedError("t_SVGP_white takes one shared kernel (util.py:52-56 asserts Kuu [M, M])")
         self.num_inducing = self.inducing_variable.num_inducing
@@ -100,7 +114,7 @@ class t_SVGP_white(base_SVGP):
             return a.to(self.device)
         return torch.as_tensor(np.asarray(a)).to(self.device)
 
-    def _operands(self, jitter=None, *, kuu_jitter=None, lambda_1=None, lambda_2=None, direct=False):
+    def _operands(self, jitter=None, *, kuu_jitter=None, lambda_1=None, lambda_2=None, direct=False, two_product=False):
         """Everything the N-pass needs (see the table in the module docstring); with ``jitter`` also K9^-1 for the
         site update.  No host synchronisation: factorisation statuses go to ops["infos"].
         ``kuu_jitter`` (default: gpflow's default_jitter, as predict_f) is the jitter of the K_uu the conditional is built
@@ -120,17 +134,37 @@ class t_SVGP_white(base_SVGP):
         l1 = self.lambda_1.value if lambda_1 is None else lambda_1
         L2 = self.lambda_2.value if lambda_2 is None else lambda_2
         E = 0.5 * (L2 + L2.transpose(-1, -2)) + 1e-9 * Id  # util.py:76 (jitter argument default)
+        if two_product:
+            # The reference's own form (util.py:73-86): R = Lambda_2 + K6 + 1e-9 I = U_R U_R^T and K6 = U6 U6^T are all that is
+            # factored; var = kff - |U6^-1 k|^2 + |U_R^-1 k|^2 = kff - |b|^2 + |T2 b|^2 with T2 = U_R^-1 U6 (upper triangular),
+            # mean = k^T R^-1 lambda_1 = b^T gamma, gamma = U6^T R^-1 lambda_1.  Two N-sized reductions instead of one
+            # (EStepEngine.run_two_product), no factor of Lambda_2 + 1e-9 I anywhere.
+            mats = [K6[None], (E + K6)[None] if E.dim() == 2 else E + K6] + ([(Kzz + jitter * Id)[None]] if jitter is not None else [])
+            U, Uinv = rev_cholesky(torch.cat(mats, dim=0), infos, potrf, inverse=True)
+            U6, Uinv6, UinvR = U[0], Uinv[0], Uinv[1]
+            T2 = (UinvR @ U6).triu()
+            gamma = U6.transpose(-1, -2) @ (UinvR.transpose(-1, -2) @ (UinvR @ l1))
+            ops = dict(Z=Z, Kzz=Kzz, K6=K6, Id=Id, infos=infos, e_infos=[], U6=U6, Uinv6=Uinv6, moment_Tm=T2[None], gamma=gamma,
+                       moment_mode=B.TRI_UPPER, whiten_T=Uinv6, direct=False, direct_info=None, two_product=True)
+            if jitter is not None:
+                ops["K9inv"] = Uinv[2].transpose(-1, -2) @ Uinv[2]
+            return ops
+        # ONE batched factorisation call, its statuses in two lists: K_uu's (a failure there is the reference's failure too) and
+        # those that exist only for the single-product variance (Lambda_2 + 1e-9 I here, I + H^T H below): see _check
         mats = [K6[None], E] + ([(Kzz + jitter * Id)[None]] if jitter is not None else [])
-        U, Uinv = rev_cholesky(torch.cat(mats, dim=0), infos, potrf, inverse=True)
+        all_infos = []
+        U, Uinv = rev_cholesky(torch.cat(mats, dim=0), all_infos, potrf, inverse=True)
+        infos = [torch.cat([all_infos[0][:1], all_infos[0][2:]])]
+        e_infos = [all_infos[0][1:2]]
         U6, Uinv6, U_E = U[0], Uinv[0], U[1]
         H = (Uinv6 @ U_E).triu()
         Wm = Id + H.transpose(-1, -2) @ H
-        _, Cinv = cholesky_deferred(0.5 * (Wm + Wm.transpose(-1, -2))[None], infos, potrf, inverse=True, overwrite=True)
+        _, Cinv = cholesky_deferred(0.5 * (Wm + Wm.transpose(-1, -2))[None], e_infos, potrf, inverse=True, overwrite=True)
         Tm = (Cinv[0] @ H.transpose(-1, -2)).tril()
         v = Uinv6 @ l1
         gamma = v - Tm.transpose(-1, -2) @ (Tm @ v)
-        ops = dict(Z=Z, Kzz=Kzz, K6=K6, Id=Id, infos=infos, U6=U6, Uinv6=Uinv6, moment_Tm=Tm[None], gamma=gamma,
-                   moment_mode=B.TRI_LOWER, whiten_T=Uinv6, direct=False, direct_info=None)
+        ops = dict(Z=Z, Kzz=Kzz, K6=K6, Id=Id, infos=infos, e_infos=e_infos, U6=U6, Uinv6=Uinv6, moment_Tm=Tm[None], gamma=gamma,
+                   moment_mode=B.TRI_LOWER, whiten_T=Uinv6, direct=False, direct_info=None, two_product=False)
         if direct:
             # var = kff - k^T Q k with Q = U6^-T T^T T U6^-1 = K6^-1 - R^-1; Q = Lq Lq^T gives |Lq^T k|^2, an UPPER
             # triangular product on K(X, Z) itself; mean = k^T (U6^-T gamma)
@@ -145,19 +179,26 @@ class t_SVGP_white(base_SVGP):
         return ops
 
     def _run(self, X, Y, ops, lik_id, sites=False, want_moments=False):
+        if ops.get("two_product"):
+            return self._get_engine().run_two_product(X, Y, ops["Z"], self.kernel, whiten_T=ops["whiten_T"],
+                                                      moment_Tm=ops["moment_Tm"], gamma=ops["gamma"], lik_id=lik_id,
+                                                      lik_param=self.likelihood.lik_param, sites=sites, want_moments=want_moments)
         return self._get_engine().run(X, Y, ops["Z"], self.kernel, moment_Tm=ops["moment_Tm"], moment_mode=ops["moment_mode"],
                                       gamma=ops["gamma"], lik_id=lik_id, lik_param=self.likelihood.lik_param,
                                       whiten_T=ops["whiten_T"], whiten_mode=B.TRI_UPPER, sites=sites,
                                       want_moments=want_moments)
 
     def _check(self, ops, nonpos):
-        parts = [info_sum(ops["infos"]), nonpos.reshape(1).to(torch.float64)]
-        if ops.get("direct_info"):
-            parts.append(info_sum(ops["direct_info"]))
+        zero = torch.zeros(1, dtype=torch.float64, device=self.device)
+        parts = [info_sum(ops["infos"]), nonpos.reshape(1).to(torch.float64),
+                 info_sum(ops["direct_info"]) if ops.get("direct_info") else zero,
+                 info_sum(ops["e_infos"]) if ops.get("e_infos") else zero]
         flags = self._read_flags(torch.cat(parts))
-        if float(flags[0]) != 0:
+        if float(flags[0]) != 0:  # K_uu + jitter I (or, two-product form, K + Lambda_2 + 1e-9 I): the reference fails here too
             raise FloatingPointError("Cholesky decomposition was not successful (matrix not positive definite)")
-        if len(flags) > 2 and float(flags[2]) != 0:  # Q lost definiteness in M x M: not the reference's failure
+        if float(flags[3]) != 0:  # only the single-product variance needs these factors: the two-product form goes on
+            raise _SingleProductFailed()
+        if float(flags[2]) != 0:  # Q lost definiteness in M x M: not the reference's failure
             raise _DirectRouteFailed()
         if not (float(flags[1]) == 0):  # tsvgp_white.py:131
             if ops.get("direct") and self.projection == "auto":
@@ -190,15 +231,24 @@ class t_SVGP_white(base_SVGP):
         return self._cond_k6() <= self.DIRECT_MAX_COND[self.compute_dtype] and not self._direct_failed
 
     def _routed(self, fn):
-        """fn(direct) on the chosen route; a direct attempt that fails in its own M x M algebra is repeated whitened."""
-        if self._use_direct():
+        """fn(direct=..., two_product=...) on the chosen form.  A direct attempt that fails in its own M x M algebra is repeated
+        whitened; a single-product attempt whose factor of Lambda_2 + 1e-9 I does not exist is repeated with the reference's
+        two-product variance (and the model stays on that form: an indefinite Lambda_2 tends to stay indefinite)."""
+        if not self._two_product and self._use_direct():
             try:
-                return fn(True)
+                return fn(direct=True, two_product=False)
             except _DirectRouteFailed:
                 if self.projection != "auto":
                     raise FloatingPointError("the direct projection lost definiteness; use projection='whitened'")
                 self._direct_failed = True
-        return fn(False)
+            except _SingleProductFailed:
+                self._two_product = True
+        if not self._two_product:
+            try:
+                return fn(direct=False, two_product=False)
+            except _SingleProductFailed:
+                self._two_product = True
+        return fn(direct=False, two_product=True)
 
     # -- reference API -----------------------------------------------------------------------------------------
     def get_mean_chol_cov_inducing_posterior(self):
@@ -235,8 +285,8 @@ class t_SVGP_white(base_SVGP):
             raise NotImplementedError("full covariances are not on the E-step hot path")
         Xd = self._as_device(Xnew)
 
-        def go(direct):
-            ops = self._operands(direct=direct)
+        def go(direct, two_product):
+            ops = self._operands(direct=direct, two_product=two_product)
             st = self._run(Xd, None, ops, B.LIK_NONE, want_moments=True)
             self._check(ops, st.nonpos)
             return st.mean, st.var
@@ -251,8 +301,8 @@ class t_SVGP_white(base_SVGP):
         X, Y = self._as_device(data[0]), self._as_device(data[1])
         kl = self.prior_kl()
 
-        def go(direct):
-            ops = self._operands(direct=direct)
+        def go(direct, two_product):
+            ops = self._operands(direct=direct, two_product=two_product)
             st = self._run(X, Y, ops, self.likelihood.lik_id | B.LIK_NOCROP)
             _, _, ve_sum, nonpos, rows, _ = D_.reduce_stats(st, self.num_latent_gps, self.num_inducing, False,
                                                               self._reduce(), self._get_engine())
@@ -262,13 +312,13 @@ class t_SVGP_white(base_SVGP):
 
         return self._routed(go)
 
-    def _kuu_grad_mu(self, X, Y, jitter=1e-9, kuu_jitter=0.0, direct=False):
+    def _kuu_grad_mu(self, X, Y, jitter=1e-9, kuu_jitter=0.0, direct=False, two_product=False):
         """compute_data_natural_params (tsvgp_white.py:183-212) with K_uu + kuu_jitter I already applied, which is how both
         callers use it: returns (K grad_mu[0] [M, 1], K grad_mu[1] K [1, M, M], rows, nonpos, ops).
         With s1 = sum g0 k, S2 = sum g1 k k^T and K9 = K_uu + jitter I:  grad_mu[0] = K9^-1 (s1 - 2 S2 K9^-1 meanZ),
         grad_mu[1] = K9^-1 S2 K9^-1, so K grad_mu = (I - (jitter - kuu_jitter) K9^-1)(...): no product with an
         ill-conditioned inverse is ever formed."""
-        ops = self._operands(jitter=jitter, direct=direct)
+        ops = self._operands(jitter=jitter, direct=direct, two_product=two_product)
         # tsvgp_white.py:188-191: no crop of d ve / d var in this class
         st = self._run(X, Y, ops, self.likelihood.lik_id | B.LIK_NOCROP, sites=True)
         acc2, acc1, _, nonpos, rows, _ = D_.reduce_stats(st, self.num_latent_gps, self.num_inducing, True, self._reduce(),
@@ -290,8 +340,9 @@ class t_SVGP_white(base_SVGP):
         """One natural-gradient step on (lambda_1, Lambda_2) (tsvgp_white.py:183-248); returns None."""
         X, Y = self._as_device(dataset[0]), self._as_device(dataset[1])
 
-        def go(direct):
-            Kg0, KG1K, rows, nonpos, ops = self._kuu_grad_mu(X, Y, jitter=jitter, kuu_jitter=0.0, direct=direct)  # :231
+        def go(direct, two_product):
+            Kg0, KG1K, rows, nonpos, ops = self._kuu_grad_mu(X, Y, jitter=jitter, kuu_jitter=0.0, direct=direct,
+                                                             two_product=two_product)  # :231
             scale = (float(self.num_data) / rows) if self.num_data is not None else 1.0
             lambda_1 = (1.0 - lr) * self.lambda_1.value + lr * scale * Kg0  # :244
             lambda_2 = (1.0 - lr) * self.lambda_2.value - 2.0 * lr * scale * KG1K  # :241-248 (Lambda_2 = -2 lambda_2)
@@ -300,7 +351,7 @@ class t_SVGP_white(base_SVGP):
             self.sites.assign_lambda_2(0.5 * (lambda_2 + lambda_2.transpose(-1, -2)))
             try:
                 self._check(ops, nonpos)
-            except (FloatingPointError, _DirectRouteFailed):
+            except (FloatingPointError, _DirectRouteFailed, _SingleProductFailed):
                 self.lambda_1.assign(old_l1)  # the reference raises before its assigns: leave the state untouched
                 self.sites.assign_lambda_2(old_L2)
                 raise
@@ -316,11 +367,28 @@ class t_SVGP_white(base_SVGP):
         shard of the extra points."""
         jitter = default_jitter() if jitter is None else float(jitter)
         Xe, Ye = self._as_device(extra_data[0]), self._as_device(extra_data[1])
-        Kg0, KG1K, _, nonpos, ops = self._kuu_grad_mu(Xe, Ye, jitter=1e-9, kuu_jitter=jitter)  # :141
-        self._check(ops, nonpos)  # predict_f(X) inside compute_data_natural_params asserts positivity (:131)
-        lambda_1c = self.lambda_1.value + Kg0  # :148
-        lambda_2c = self.lambda_2.value - 2.0 * KG1K  # :149
-        ops_c = self._operands(kuu_jitter=jitter, lambda_1=lambda_1c, lambda_2=0.5 * (lambda_2c + lambda_2c.transpose(-1, -2)))
-        st = self._run(self._as_device(Xnew), None, ops_c, B.LIK_NONE, want_moments=True)
-        self._check(ops_c, torch.zeros(1, dtype=torch.float64, device=self.device))  # no assert_positive on this path (:155-158)
-        return st.mean, st.var
+        Xn = self._as_device(Xnew)
+
+        def go(direct, two_product):  # (the whitened forms only, as before: direct is not offered on this path)
+            Kg0, KG1K, _, nonpos, ops = self._kuu_grad_mu(Xe, Ye, jitter=1e-9, kuu_jitter=jitter, two_product=two_product)  # :141
+            self._check(ops, nonpos)  # predict_f(X) inside compute_data_natural_params asserts positivity (:131)
+            return self.lambda_1.value + Kg0, self.lambda_2.value - 2.0 * KG1K  # :148-149
+
+        def routed(fn):
+            if not self._two_product:
+                try:
+                    return fn(False, False)
+                except _SingleProductFailed:
+                    pass
+            return fn(False, True)
+
+        lambda_1c, lambda_2c = routed(go)
+        lambda_2c = 0.5 * (lambda_2c + lambda_2c.transpose(-1, -2))
+
+        def cond(direct, two_product):  # the conditioned sites may be indefinite even when the model's own are not
+            ops_c = self._operands(kuu_jitter=jitter, lambda_1=lambda_1c, lambda_2=lambda_2c, two_product=two_product)
+            st = self._run(Xn, None, ops_c, B.LIK_NONE, want_moments=True)
+            self._check(ops_c, torch.zeros(1, dtype=torch.float64, device=self.device))  # no assert_positive on this path (:155-158)
+            return st.mean, st.var
+
+        return routed(cond)

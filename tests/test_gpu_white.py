@@ -182,3 +182,44 @@ def test_white_auto_route_gate_and_fallback():
     h2.natgrad_step((X2, Y2), lr=0.8)
     o2.natgrad_step((X2, Y2), lr=0.8)
     assert relerr(h2.lambda_2.numpy(), o2.lambda_2) < 1e-8
+
+
+@pytest.mark.parametrize("lik", ["gaussian", "bernoulli"])
+def test_white_indefinite_lambda_2_takes_the_two_product_variance(lik):
+    """Lambda_2 + 1e-9 I NOT positive definite while K + Lambda_2 + 1e-9 I is: the reference goes on (its conditional only
+    factors the latter, src/util.py:73-86; the class does not crop d ve / d var, src/models/tsvgp_white.py:188-191, so the
+    probit link's far tails can drive Lambda_2 there), and so must the mirror -- round 2 raised FloatingPointError here because
+    its single-product variance needs the factor of Lambda_2 + 1e-9 I.  Sites with Lambda_2 = -0.45 K_uu (negative definite)
+    and a random lambda_1: predictions, ELBO, conditioning on extra data and natural-gradient steps against the oracle."""
+    p = pkg()
+    rng = np.random.RandomState(32)
+    N, M, D = 700, 40, 4
+    X, Y, _ = synthetic(N=N, M=M, D=D, P=1, lik=lik, seed=6)
+    Z = rng.randn(M, D) * 1.3
+    kern = O.SquaredExponential(1.2, 0.9)
+    Kuu = kern.K(Z)
+    lam2 = (-0.45 * Kuu)[None]
+    lam1 = 0.3 * rng.randn(M, 1)
+    assert np.linalg.eigvalsh(lam2[0] + 1e-9 * np.eye(M)).max() < 0  # no Cholesky factor of Lambda_2 + 1e-9 I
+    assert np.linalg.eigvalsh(lam2[0] + Kuu + (1e-6 + 1e-9) * np.eye(M)).min() > 0  # the reference's R is fine
+    mk = lambda mod: mod.t_SVGP_white(mod.SquaredExponential(1.2, 0.9), mod.Gaussian(0.2) if lik == "gaussian" else mod.Bernoulli(),
+                                      Z, num_data=N, lambda_1=lam1.copy(), lambda_2=lam2.copy())
+    hip, ora = mk(p), mk(O)
+    mu_h, var_h = hip.predict_f(X[:200] + 0.05)
+    assert hip._two_product  # the single-product form was tried, failed in its own factorisation, and the model moved over
+    mu_o, var_o = ora.predict_f(X[:200] + 0.05)
+    assert relerr(mu_h.cpu().numpy(), mu_o) < 1e-8 and relerr(var_h.cpu().numpy(), var_o) < 1e-8
+    assert abs(float(hip.elbo((X, Y))) - ora.elbo((X, Y))) < 1e-9 * abs(ora.elbo((X, Y)))
+    mu_h, var_h = hip.predict_f_extra_data(X[:100] - 0.1, (X[300:380], Y[300:380]))
+    mu_o, var_o = ora.predict_f_extra_data(X[:100] - 0.1, (X[300:380], Y[300:380]))
+    assert relerr(mu_h.cpu().numpy(), mu_o) < 1e-8 and relerr(var_h.cpu().numpy(), var_o) < 1e-8
+    for _ in range(3):
+        hip.natgrad_step((X, Y), lr=0.3)
+        ora.natgrad_step((X, Y), lr=0.3)
+        assert relerr(hip.lambda_1.numpy(), ora.lambda_1) < 1e-8
+        assert relerr(hip.lambda_2.numpy(), ora.lambda_2) < 1e-8
+    assert abs(float(hip.elbo((X, Y))) - ora.elbo((X, Y))) < 1e-9 * abs(ora.elbo((X, Y)))
+    # a fresh model on definite sites never leaves the single-product form
+    fresh = p.t_SVGP_white(p.SquaredExponential(1.2, 0.9), p.Gaussian(0.2), Z, num_data=N)
+    fresh.natgrad_step((X, Y if lik == "gaussian" else Y + 0.0), lr=0.5)
+    assert not fresh._two_product
