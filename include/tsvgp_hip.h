@@ -65,6 +65,11 @@ extern "C" {
 
 /* Library / build identification: returns a static string "tsvgp_hip gfx950 <version>". */
 const char *tsvgp_version(void);
+/* Number of this header's calling conventions: bumped whenever an entry point's argument list changes without a new symbol
+ * name.  A binding checks it against the TSVGP_ABI_VERSION it was written for before the first call (t-svgp_amd/_backend.py
+ * refuses a library whose number differs: a shifted argument would otherwise hand a kernel a garbage stream or pointer). */
+#define TSVGP_ABI_VERSION 3
+int tsvgp_abi_version(void);
 
 /* Upper bound on the number of workgroup slots the site-accumulation kernel can keep resident
  * (CUs x resident workgroups per CU for that kernel); used by the host to choose `nsplit`. */

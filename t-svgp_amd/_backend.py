@@ -26,6 +26,7 @@ LIK_MEANONLY = 0x200
 KERNEL_SE, KERNEL_MATERN32, KERNEL_MATERN52 = 0, 2, 3
 TRI_LOWER, TRI_UPPER, TRI_DENSE = 0, 1, 2
 POTRF_SUBST = 1  # TSVGP_POTRF_SUBST
+ABI_VERSION = 3  # TSVGP_ABI_VERSION of include/tsvgp_hip.h these prototypes were written for
 
 _lib = None
 
@@ -59,6 +60,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
 _PROTOTYPES = {
     # name: (restype, argtypes)
     "tsvgp_version": (c_char_p, []),
+    "tsvgp_abi_version": (c_int, []),
     "tsvgp_site_accum_slots_f64": (c_int, []),
     "tsvgp_site_accum_slots_f32": (c_int, []),
     "tsvgp_se_fill_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_double, c_void_p, c_int64, c_int, c_int, c_int64, c_void_p]),
@@ -138,6 +140,16 @@ def lib():
         handle = ctypes.CDLL(path)
     except OSError as e:  # pragma: no cover - depends on the box
         raise HipExtensionError(f"cannot load {path}: {e}") from e
+    # An older or newer build of the library (tools/ab_builds.sh builds other revisions; TSVGP_HIP_LIB points at them) may take
+    # different argument lists under the same symbol names: refuse it rather than hand a kernel a shifted stream or pointer.
+    try:
+        handle.tsvgp_abi_version.restype = c_int
+        abi = int(handle.tsvgp_abi_version())
+    except AttributeError:
+        abi = None
+    if abi != ABI_VERSION:
+        raise HipExtensionError(f"{path}: ABI version {abi}, these bindings are written for {ABI_VERSION} "
+                                "(include/tsvgp_hip.h: TSVGP_ABI_VERSION); rebuild the library from this tree")
     for name, (restype, argtypes) in _PROTOTYPES.items():
         fn = getattr(handle, name)
         fn.restype = restype

@@ -2069,7 +2069,7 @@ __device__ __forceinline__ double readlane_d(double v, int src) {
 // Lanes 0..15 of EVERY participating wave hold the sub-block's own rows (factored redundantly per wave, so that no wave
 // waits for another); lanes 16..63 of wave w hold 48 further rows: the rows below the sub-block and, behind them, the
 // 16 rows of the identity.  Four columns per step: the 4x4 pivot block is broadcast with v_readlane and factored
-// redundantly by every lane (reciprocal square roots by v_rsq_f64 + two Newton steps: no f64 divide / sqrt sequences on
+// redundantly by every lane (reciprocal square roots by v_rsq_f64 + one third-order step, rsqrt_nr: no f64 divide / sqrt sequences on
 // the critical path), each lane solves its own row against it, and the rank-4 update of the remaining columns takes
 // its second factor from a small per-wave LDS scratch (wave-uniform reads).  For a row below the sub-block that IS the
 // substitution x L_ss^T = a, and for row i of the identity it yields column i of inv(L_ss): the row solves and the
@@ -3242,7 +3242,8 @@ int kernel_grad(int kind, const T* X, const T* Z, const T* inv_ls, T variance, c
 
 extern "C" {
 
-const char* tsvgp_version(void) { return "tsvgp_hip gfx950 0.1.0"; }
+const char* tsvgp_version(void) { return "tsvgp_hip gfx950 0.3.0"; }
+int tsvgp_abi_version(void) { return TSVGP_ABI_VERSION; }
 
 int tsvgp_site_accum_slots_f64(void) { return site_accum_slots<double>(); }
 int tsvgp_site_accum_slots_f32(void) { return site_accum_slots<float>(); }

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collects the per-round evidence on the GPU box: bench lines of every workload, the rocprofv3 kernel trace and the PMC
 # passes of the headline workload, under gpurun_out/$EVIDENCE_DIR (copied into profiles/ by hand afterwards).
-# usage: EVIDENCE_DIR=r02 bash tools/run_evidence.sh <stage>     stage 1: ns, c2, c3, c1 bench lines; 2: c5, c5s, white,
+# usage: EVIDENCE_DIR=r02 bash tools/run_evidence.sh <stage>     stage 1: ns, c2, c3, c1 bench lines; 2: c5; 2b: c5s, white,
 #        125 000-row shard; 3: kernel trace + M x M timeline + PMC passes   (one gpurun call each: 20 minutes at most)
 set -e
 R=$PWD
