@@ -998,9 +998,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void panel_kernel(PanelArgs<T> a) {
 //     v_mfma_f64_16x16x4_f64 issued just before it corrupted results (the compiler's hazard recognizer does not know it).
 // ---------------------------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void lds_void_t;
-constexpr int P1_OPS = TILE * 16;    // doubles per operand image of a chunk (16 KB)
-constexpr int P1_BUFS = 2 * P1_OPS;  // doubles per chunk buffer (A image + T image, 32 KB)
-constexpr size_t P1_GAMMA_LDS_MAX = 64 * 1024;  // dynamic LDS for gamma_p beside the 64 KB ring: Mp <= 8192
+constexpr int P1_OPS = TILE * 16;    // 8-byte fragment units per operand image of a chunk (16 KB)
+constexpr int P1_BUFS = 2 * P1_OPS;  // fragment units per chunk buffer (A image + T image, 32 KB)
+constexpr size_t P1_GAMMA_LDS_MAX = 64 * 1024;  // dynamic LDS for gamma_p beside the 64 KB ring: Mp <= 8192 (fp32: 16384)
+#ifndef TSVGP_MOMENTS_OLD_F32  // (-DTSVGP_MOMENTS_OLD_F32=1: A/B builds keep round 2's panel_kernel for fp32)
+#define TSVGP_MOMENTS_OLD_F32 0
+#endif
 
 template <int I, int N, class F>
 __device__ __forceinline__ void cfor(F&& f) {
@@ -1010,24 +1013,46 @@ __device__ __forceinline__ void cfor(F&& f) {
     }
 }
 constexpr int popc8(int m) { return m ? (m & 1) + popc8(m >> 1) : 0; }
+// The same stream serves both types: a k-chunk is 128 bytes per row (16 doubles / 32 floats), a lane's fragment read is 8
+// bytes -- ONE fp64 operand, or the operands of TWO consecutive v_mfma_f32_16x16x4_f32 (half the cycles each: the same MFMA
+// time per read) -- so "k-step" below is 4 columns in fp64 and 8 in fp32, and the masks, buffers and DMA pieces do not change.
+template <typename T>
+struct P1Types;
+template <>
+struct P1Types<double> {
+    typedef double frag_t;
+    typedef v2d unit_t;  // 16-byte unit
+};
+template <>
+struct P1Types<float> {
+    typedef v2f frag_t;
+    typedef v4f unit_t;
+};
+template <typename F>
 struct Frag1 {
-    double v[10];  // v[0], v[1]: A fragments of the wave's two row blocks; v[2 + n]: T fragment of column block n
+    F v[10];  // v[0], v[1]: A fragments of the wave's two row blocks; v[2 + n]: T fragment of column block n
 };
 #define TSVGP_AI __attribute__((always_inline))
 #define TSVGP_IC(x) std::integral_constant<int, (x)>{}
 #define TSVGP_BC(x) std::integral_constant<bool, (x)>{}
 #define TSVGP_SB() __builtin_amdgcn_sched_barrier(0)
 
-__global__ __launch_bounds__(NTHREADS, 1) void panel1_kernel(PanelArgs<double> a) {
+template <typename T>
+__global__ __launch_bounds__(NTHREADS, 1) void panel1_kernel(PanelArgs<T> a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char panel_dyn_smem[];
-    double* const gsm = reinterpret_cast<double*>(panel_dyn_smem);  // gamma_p, Mp doubles
-    __shared__ __attribute__((aligned(1024))) double lds[2 * P1_BUFS];
+    typedef typename P1Types<T>::frag_t frag_t;
+    typedef typename P1Types<T>::unit_t unit_t;
+    typedef Frag1<frag_t> Frag;
+    T* const gsm = reinterpret_cast<T*>(panel_dyn_smem);  // gamma_p, Mp elements
+    __shared__ __attribute__((aligned(1024))) frag_t lds[2 * P1_BUFS];
     __shared__ double rowq[TILE];
     __shared__ double rowm[TILE];
     __shared__ double red[NTHREADS / 64];
     __shared__ int redi[NTHREADS / 64];
-    constexpr int KC = 16;
-    typedef v4d acc_t;
+    constexpr int KC = 128 / (int)sizeof(T), UE = 16 / (int)sizeof(T);  // elements per chunk row / per 16-byte unit
+    constexpr int CPT = TILE / KC;   // chunks of the diagonal k-tile: 8 (one more column block each) or 4 (two more each)
+    constexpr int BPC = 8 / CPT;     // column blocks a diagonal chunk adds
+    typedef typename Mfma<T>::acc_t acc_t;
 
     const int t = threadIdx.x, lane = t & 63;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -1040,11 +1065,12 @@ __global__ __launch_bounds__(NTHREADS, 1) void panel1_kernel(PanelArgs<double> a
     // at unit L & 7 of row (L >> 3) of the piece and fetches the global unit (L & 7) ^ f(row), f(row) = (L >> 3) ^ (w & 1)
     const int drow = lane >> 3;
     const int dlog = (lane & 7) ^ drow ^ (w & 1);
-    const unsigned dvoff = (unsigned)((drow * Mp + 2 * dlog) * sizeof(double));
-    const size_t grp = (size_t)32 * Mp * sizeof(double);
+    const unsigned dvoff = (unsigned)(drow * Mp * sizeof(T) + 16 * dlog);
+    const size_t grp = (size_t)32 * Mp * sizeof(T);
     const unsigned lds_base = (unsigned)(uintptr_t)(lds_void_t*)lds + (unsigned)(w * 1024);
 
-    // fragment reads: row r of a 16-row block, element k = 4 ks + lk of the chunk -> unit (2 ks + (lk >> 1)) ^ f(r), half lk & 1
+    // fragment reads: row r of a 16-row block, 8-byte piece 4 ks + lk of the chunk row -> unit (2 ks + (lk >> 1)) ^ f(r), half
+    // lk & 1 (fp64: element k = 4 ks + lk; fp32: elements 8 ks + 2 lk, + 1 -- any assignment of k to lanes that A and T share)
     const int lr = lane & 15, lk = lane >> 4;
     const int fr = (lr & 7) ^ (lr >> 3);
     int offa0[4], offa1[4], offb[4];
@@ -1063,7 +1089,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void panel1_kernel(PanelArgs<double> a
     int nonpos = 0;
 
     for (int p = 0; p < a.P; ++p) {
-        const double* Tp = a.Tm + (size_t)p * Mp * Mp;
+        const T* Tp = a.Tm + (size_t)p * Mp * Mp;
         const char* Ab = reinterpret_cast<const char*>(a.A + (size_t)p * a.strideA + (n0 + 8 * w) * (int64_t)Mp);
         __syncthreads();  // the previous latent's readers of gsm / rowq / rowm are done
         for (int j = t; j < Mp; j += NTHREADS) gsm[j] = a.gamma[(size_t)j * a.P + p];
@@ -1086,22 +1112,23 @@ __global__ __launch_bounds__(NTHREADS, 1) void panel1_kernel(PanelArgs<double> a
         unsigned dma_vo = 0;
         uint64_t tb_u = 0;
         auto dma_setup = [&](const Cursor cu) TSVGP_AI {
-            dma_vo = dvoff + (unsigned)(cu.c * KC * sizeof(double));
+            dma_vo = dvoff + (unsigned)(cu.c * KC * sizeof(T));
             tb_u = uni64(Tp + ((size_t)cu.it * TILE + 8 * w) * Mp);
         };
         auto dma_piece = [&](auto i_tag, const int buf) TSVGP_AI {  // piece I of a chunk: I even -> A piece I / 2, I odd -> T piece
             constexpr int I = decltype(i_tag)::value, q = I >> 1;
-            const unsigned la = lds_u + (unsigned)((buf * P1_BUFS + q * 512 + (I & 1) * P1_OPS) * sizeof(double));
+            const unsigned la = lds_u + (unsigned)((buf * P1_BUFS + q * 512 + (I & 1) * P1_OPS) * sizeof(frag_t));
             const uint64_t g = ((I & 1) ? tb_u : ab_u) + q * grp;
             const unsigned vo_ = dma_vo;  // (an asm operand alone does not capture a variable in a generic lambda)
-            // one wait state between the write of M0 and the LDS-DMA that reads it
+            // one wait state between the write of M0 and the LDS-DMA that reads it.  (Fetching only the T pieces a diagonal chunk
+            // reads -- the others issued with EXEC = 0 -- was 1.7 % SLOWER at M = 1024 and 512: profiles/r03_moments_lab_notes.txt)
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(la), "v"(vo_), "s"(g) : "memory");
         };
         auto advance = [&](Cursor& cu) TSVGP_AI {  // saturates at the last chunk (a harmless re-fetch into a dead buffer)
             if (cu.c + 1 == nchunk) {
                 if (cu.it + 1 < ntile) {
                     ++cu.it;
-                    cu.c = cu.it * (TILE / KC);
+                    cu.c = cu.it * CPT;
                 }
             } else {
                 ++cu.c;
@@ -1109,32 +1136,37 @@ __global__ __launch_bounds__(NTHREADS, 1) void panel1_kernel(PanelArgs<double> a
         };
 
         acc_t acc[2][8];
-        Frag1 fx, fy;
+        Frag fx, fy;
         double rs_mine = 0.0;
-        double mpart[4] = {0, 0, 0, 0};
-        v2d gx[4], gg;  // the mean's operands in flight (column tile 0)
+        T mpart[4] = {0, 0, 0, 0};
+        unit_t gx[4], gg;  // the mean's operands in flight (column tile 0)
 
-        auto rd1 = [&](Frag1& f, auto e_tag, auto ks_tag, const int boff) TSVGP_AI {
+        auto rd1 = [&](Frag& f, auto e_tag, auto ks_tag, const int boff) TSVGP_AI {
             constexpr int E = decltype(e_tag)::value, KS = decltype(ks_tag)::value;
             if constexpr (E == 0) f.v[0] = lds[offa0[KS] + boff];
             else if constexpr (E == 1) f.v[1] = lds[offa1[KS] + boff];
             else f.v[E] = lds[offb[KS] + boff + (E - 2) * 256];
         };
         // slot S of a k-step's reads -> element of the set: T fragments first, the two A fragments last (see the header)
-        auto rds = [&](Frag1& f, auto slot_tag, auto m_tag, auto ks_tag, const int boff) TSVGP_AI {
+        auto rds = [&](Frag& f, auto slot_tag, auto m_tag, auto ks_tag, const int boff) TSVGP_AI {
             constexpr int S = decltype(slot_tag)::value, MM = decltype(m_tag)::value;
             if constexpr (S < MM) rd1(f, TSVGP_IC(2 + S), ks_tag, boff);
             else rd1(f, TSVGP_IC(S - MM), ks_tag, boff);
         };
-        auto keep_set = [&](const Frag1& f, auto m_tag) TSVGP_AI {  // the set's registers stay occupied up to this point
+        auto keep_set = [&](const Frag& f, auto m_tag) TSVGP_AI {  // the set's registers stay occupied up to this point
             cfor<0, 2 + decltype(m_tag)::value>([&](auto e) TSVGP_AI {
-                const double x = f.v[decltype(e)::value];
+                const frag_t x = f.v[decltype(e)::value];
                 asm volatile("" ::"v"(x));
             });
         };
-        auto mf = [&](const Frag1& f, auto i_tag) TSVGP_AI {  // MFMA I of a k-step: column block I / 2, row block I % 2
+        auto mf = [&](const Frag& f, auto i_tag) TSVGP_AI {  // MFMA slot I of a k-step: column block I / 2, row block I % 2
             constexpr int I = decltype(i_tag)::value, n = I >> 1, sblk = I & 1;
-            acc[sblk][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.v[sblk], f.v[2 + n], acc[sblk][n], 0, 0, 0);
+            if constexpr (sizeof(T) == 8) {
+                acc[sblk][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.v[sblk], f.v[2 + n], acc[sblk][n], 0, 0, 0);
+            } else {  // the two halves of the 8-byte fragments: two MFMAs of half the cycles
+                acc[sblk][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.v[sblk][0], f.v[2 + n][0], acc[sblk][n], 0, 0, 0);
+                acc[sblk][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.v[sblk][1], f.v[2 + n][1], acc[sblk][n], 0, 0, 0);
+            }
         };
         // One chunk of the stream.  M: its column-block mask (upper form: blocks 0 .. m - 1); MN: the mask of the NEXT chunk of
         // the stream (0: none); BUF: its LDS buffer (parity of the chunk index); GC: it belongs to column tile 0 (its A image
@@ -1154,8 +1186,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void panel1_kernel(PanelArgs<double> a
                 constexpr int I = decltype(i)::value;
                 if constexpr (I < NM) mf(fx, i);
                 if constexpr (I < NR) rds(fy, i, TSVGP_IC(m), TSVGP_IC(1), B0);
-                else if constexpr (GC && I == NR) gg = *reinterpret_cast<const v2d*>(gsm + c_this * KC + 2 * glog);
-                else if constexpr (GC && I > NR && I < NR + 5) gx[I - NR - 1] = *reinterpret_cast<const v2d*>(lds + B0 + (I - NR - 1) * 512 + t * 2);
+                else if constexpr (GC && I == NR) gg = *reinterpret_cast<const unit_t*>(gsm + c_this * KC + UE * glog);
+                else if constexpr (GC && I > NR && I < NR + 5) gx[I - NR - 1] = *reinterpret_cast<const unit_t*>(lds + B0 + (I - NR - 1) * 512 + t * 2);
                 TSVGP_SB();
             });
             keep_set(fx, TSVGP_IC(m));
@@ -1164,7 +1196,12 @@ __global__ __launch_bounds__(NTHREADS, 1) void panel1_kernel(PanelArgs<double> a
                 constexpr int I = decltype(i)::value;
                 if constexpr (I < NM) mf(fy, i);
                 if constexpr (I < NR) rds(fx, i, TSVGP_IC(m), TSVGP_IC(2), B0);
-                else if constexpr (GC && I < NR + 4) mpart[I - NR] += gx[I - NR][0] * gg[0] + gx[I - NR][1] * gg[1];
+                else if constexpr (GC && I < NR + 4) {
+                    T dot = gx[I - NR][0] * gg[0];
+#pragma unroll
+                    for (int u = 1; u < UE; ++u) dot += gx[I - NR][u] * gg[u];
+                    mpart[I - NR] += dot;
+                }
                 TSVGP_SB();
             });
             keep_set(fy, TSVGP_IC(m));
@@ -1203,33 +1240,40 @@ __global__ __launch_bounds__(NTHREADS, 1) void panel1_kernel(PanelArgs<double> a
         advance(cf);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __syncthreads();  // both chunks and gamma are in LDS for every wave
-        cfor<0, 3>([&](auto i) TSVGP_AI { rd1(fx, i, TSVGP_IC(0), 0); });  // a0, a1, b0 of chunk (0, 0)
+        cfor<0, 2 + BPC>([&](auto i) TSVGP_AI { rd1(fx, i, TSVGP_IC(0), 0); });  // a0, a1, b0 (fp32: and b1) of chunk (0, 0)
 
         for (int it = 0; it < ntile; ++it) {
-            const int cd = it * (TILE / KC);
+            const int cd = it * CPT;
             const bool last_tile = it + 1 == ntile;
             // an accumulator is zeroed in front of the diagonal chunk that first touches its column block
 #define TSVGP_ZACC(n_) { acc[0][n_] = acc_t{0, 0, 0, 0}; acc[1][n_] = acc_t{0, 0, 0, 0}; }
             auto diag = [&](auto gc) TSVGP_AI {
-                TSVGP_ZACC(0) chunk(TSVGP_IC(0x01), TSVGP_IC(0x03), TSVGP_IC(0), gc, cd);
-                TSVGP_ZACC(1) chunk(TSVGP_IC(0x03), TSVGP_IC(0x07), TSVGP_IC(1), gc, cd + 1);
-                TSVGP_ZACC(2) chunk(TSVGP_IC(0x07), TSVGP_IC(0x0F), TSVGP_IC(0), gc, cd + 2);
-                TSVGP_ZACC(3) chunk(TSVGP_IC(0x0F), TSVGP_IC(0x1F), TSVGP_IC(1), gc, cd + 3);
-                TSVGP_ZACC(4) chunk(TSVGP_IC(0x1F), TSVGP_IC(0x3F), TSVGP_IC(0), gc, cd + 4);
-                TSVGP_ZACC(5) chunk(TSVGP_IC(0x3F), TSVGP_IC(0x7F), TSVGP_IC(1), gc, cd + 5);
-                TSVGP_ZACC(6) chunk(TSVGP_IC(0x7F), TSVGP_IC(0xFF), TSVGP_IC(0), gc, cd + 6);
-                TSVGP_ZACC(7)
-                if (!last_tile) chunk(TSVGP_IC(0xFF), TSVGP_IC(0xFF), TSVGP_IC(1), gc, cd + 7);
-                else chunk(TSVGP_IC(0xFF), TSVGP_IC(0), TSVGP_IC(1), gc, cd + 7);  // the end of the stream
+                if constexpr (CPT == 8) {
+                    TSVGP_ZACC(0) chunk(TSVGP_IC(0x01), TSVGP_IC(0x03), TSVGP_IC(0), gc, cd);
+                    TSVGP_ZACC(1) chunk(TSVGP_IC(0x03), TSVGP_IC(0x07), TSVGP_IC(1), gc, cd + 1);
+                    TSVGP_ZACC(2) chunk(TSVGP_IC(0x07), TSVGP_IC(0x0F), TSVGP_IC(0), gc, cd + 2);
+                    TSVGP_ZACC(3) chunk(TSVGP_IC(0x0F), TSVGP_IC(0x1F), TSVGP_IC(1), gc, cd + 3);
+                    TSVGP_ZACC(4) chunk(TSVGP_IC(0x1F), TSVGP_IC(0x3F), TSVGP_IC(0), gc, cd + 4);
+                    TSVGP_ZACC(5) chunk(TSVGP_IC(0x3F), TSVGP_IC(0x7F), TSVGP_IC(1), gc, cd + 5);
+                    TSVGP_ZACC(6) chunk(TSVGP_IC(0x7F), TSVGP_IC(0xFF), TSVGP_IC(0), gc, cd + 6);
+                    TSVGP_ZACC(7)
+                } else {  // 32-column chunks: two more column blocks each (the second one's first k-steps meet zeros of T)
+                    TSVGP_ZACC(0) TSVGP_ZACC(1) chunk(TSVGP_IC(0x03), TSVGP_IC(0x0F), TSVGP_IC(0), gc, cd);
+                    TSVGP_ZACC(2) TSVGP_ZACC(3) chunk(TSVGP_IC(0x0F), TSVGP_IC(0x3F), TSVGP_IC(1), gc, cd + 1);
+                    TSVGP_ZACC(4) TSVGP_ZACC(5) chunk(TSVGP_IC(0x3F), TSVGP_IC(0xFF), TSVGP_IC(0), gc, cd + 2);
+                    TSVGP_ZACC(6) TSVGP_ZACC(7)
+                }
+                if (!last_tile) chunk(TSVGP_IC(0xFF), TSVGP_IC(0xFF), TSVGP_IC(1), gc, cd + CPT - 1);
+                else chunk(TSVGP_IC(0xFF), TSVGP_IC(0), TSVGP_IC(1), gc, cd + CPT - 1);  // the end of the stream
             };
             auto full = [&](auto gc) TSVGP_AI {  // the full k-tiles behind the diagonal one; the next column tile's first chunk follows
                 const int c_last = nchunk - 1;
-                for (int c = cd + 8; c < c_last - 1; c += 2) {
+                for (int c = cd + CPT; c < c_last - 1; c += 2) {
                     chunk(TSVGP_IC(0xFF), TSVGP_IC(0xFF), TSVGP_IC(0), gc, c);
                     chunk(TSVGP_IC(0xFF), TSVGP_IC(0xFF), TSVGP_IC(1), gc, c + 1);
                 }
                 chunk(TSVGP_IC(0xFF), TSVGP_IC(0xFF), TSVGP_IC(0), gc, c_last - 1);
-                chunk(TSVGP_IC(0xFF), TSVGP_IC(0x01), TSVGP_IC(1), gc, c_last);
+                chunk(TSVGP_IC(0xFF), TSVGP_IC((1 << BPC) - 1), TSVGP_IC(1), gc, c_last);
             };
 #undef TSVGP_ZACC
             if (it == 0) {
@@ -1247,7 +1291,10 @@ __global__ __launch_bounds__(NTHREADS, 1) void panel1_kernel(PanelArgs<double> a
                 for (int r = 0; r < 4; ++r) {
                     double q = 0.0;
 #pragma unroll
-                    for (int n = 0; n < 8; ++n) q += acc[s][n][r] * acc[s][n][r];
+                    for (int n = 0; n < 8; ++n) {
+                        const double v = (double)acc[s][n][r];
+                        q += v * v;
+                    }
                     q += __shfl_xor(q, 1);
                     q += __shfl_xor(q, 2);
                     q += __shfl_xor(q, 4);
@@ -1261,7 +1308,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void panel1_kernel(PanelArgs<double> a
         // row sums and means to LDS, then the likelihood map of panel_kernel's epilogue (two threads per row)
         if ((lane & 15) < 8) {
             const int l8 = lane & 15;
-            rowq[row_block(w, l8 >> 2) * 16 + Mfma<double>::row(lane, l8 & 3)] = rs_mine;
+            rowq[row_block(w, l8 >> 2) * 16 + Mfma<T>::row(lane, l8 & 3)] = rs_mine;
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -1271,7 +1318,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void panel1_kernel(PanelArgs<double> a
         }
         if ((t & 7) == 0) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) rowm[q * 32 + (t >> 3)] = mpart[q];
+            for (int q = 0; q < 4; ++q) rowm[q * 32 + (t >> 3)] = (double)mpart[q];
         }
         __syncthreads();
         {
@@ -1284,7 +1331,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void panel1_kernel(PanelArgs<double> a
             if ((a.lik & 0xFF) == TSVGP_LIK_BERNOULLI) {
                 double a0, a1, av;
                 const double sd = sqrt(live ? v : 1.0);
-                bern_sums(live ? mu : 0.0, sd, live && a.Y[n * a.P + p] == 1.0, skh * 5, skh * 5 + 5, a0, a1, av);
+                bern_sums(live ? mu : 0.0, sd, live && (double)a.Y[n * a.P + p] == 1.0, skh * 5, skh * 5 + 5, a0, a1, av);
                 a0 += __shfl_xor(a0, 1);
                 a1 += __shfl_xor(a1, 1);
                 av += __shfl_xor(av, 1);
@@ -1293,18 +1340,18 @@ __global__ __launch_bounds__(NTHREADS, 1) void panel1_kernel(PanelArgs<double> a
                 if (!(a.lik & TSVGP_LIK_NOCROP)) g1 = fmin(g1, -1e-8);  // reference tsvgp.py:262-263
                 ve = av;
             } else if (a.lik != TSVGP_LIK_NONE && live) {
-                lik_eval(a.lik, a.lik_param, mu, v, a.Y[n * a.P + p], g0, g1, ve);
+                lik_eval(a.lik, a.lik_param, mu, v, (double)a.Y[n * a.P + p], g0, g1, ve);
             }
             if (skh == 0) {
                 if (live) {
                     if (!(v > 0.0)) nonpos += 1;
-                    if (a.mean) a.mean[n * a.P + p] = mu;
-                    if (a.var) a.var[n * a.P + p] = v;
+                    if (a.mean) a.mean[n * a.P + p] = (T)mu;
+                    if (a.var) a.var[n * a.P + p] = (T)v;
                     ve_acc += ve;
                 }
                 if (a.lik != TSVGP_LIK_NONE) {
-                    a.g0[n * a.P + p] = live ? g0 : 0.0;  // rows >= N: zeros (the padding contract of site_accum)
-                    a.g1[n * a.P + p] = live ? g1 : 0.0;
+                    a.g0[n * a.P + p] = (T)(live ? g0 : 0.0);  // rows >= N: zeros (the padding contract of site_accum)
+                    a.g1[n * a.P + p] = (T)(live ? g1 : 0.0);
                 }
             }
         }
@@ -1491,10 +1538,16 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 #ifndef TSVGP_SYRK1_DIAG_NUM  // syrk1_kernel (fp64, round 3): 19/32 .. 23/32 measured within 1 % of each other; 20/32 best
 #define TSVGP_SYRK1_DIAG_NUM 20
 #endif
-// (esize: sizeof of the N-sized arrays' type -- the fp64 path runs syrk1_kernel unless the build keeps the old one)
+#ifndef TSVGP_SYRK1F_DIAG_NUM  // syrk1f_kernel (fp32, round 3)
+#define TSVGP_SYRK1F_DIAG_NUM 22
+#endif
+#ifndef TSVGP_SYRK_OLD_F32  // (-DTSVGP_SYRK_OLD_F32=1: A/B builds keep round 2's syrk_kernel for fp32)
+#define TSVGP_SYRK_OLD_F32 0
+#endif
+// (esize: sizeof of the N-sized arrays' type -- syrk1_kernel / syrk1f_kernel run unless the build keeps the old one)
 __host__ __device__ inline int syrk_ns_diag(int ns_off, int esize) {
 #ifndef TSVGP_SYRK_OLD
-    const int num = esize == 8 ? TSVGP_SYRK1_DIAG_NUM : TSVGP_SYRK_DIAG_NUM;
+    const int num = esize == 8 ? TSVGP_SYRK1_DIAG_NUM : TSVGP_SYRK_OLD_F32 ? TSVGP_SYRK_DIAG_NUM : TSVGP_SYRK1F_DIAG_NUM;
 #else
     const int num = TSVGP_SYRK_DIAG_NUM;
 #endif
@@ -1792,20 +1845,20 @@ __device__ __forceinline__ void syrk1_body(const SyrkArgs<double>& a, double* ld
 #pragma unroll
         for (int n = 0; n < 8; ++n) acc[s][n] = acc_t{0, 0, 0, 0};
     double acc1v[2] = {0.0, 0.0};
-    Frag1 fx, fy;
+    Frag1<double> fx, fy;
 
-    auto rd1 = [&](Frag1& f, auto e_tag, auto ks_tag, const int boff) TSVGP_AI {
+    auto rd1 = [&](Frag1<double>& f, auto e_tag, auto ks_tag, const int boff) TSVGP_AI {
         constexpr int E = decltype(e_tag)::value, KS_ = decltype(ks_tag)::value;
         if constexpr (E == 0) f.v[0] = lds[offa0 + boff + KS_ * 4 * LDS_KS];
         else if constexpr (E == 1) f.v[1] = lds[offa1 + boff + KS_ * 4 * LDS_KS];
         else f.v[E] = lds[offb + boff + KS_ * 4 * LDS_KS + (E - 2) * 16];
     };
-    auto rds = [&](Frag1& f, auto slot_tag, auto ks_tag, const int boff) TSVGP_AI {  // T-side fragments first, A-side last
+    auto rds = [&](Frag1<double>& f, auto slot_tag, auto ks_tag, const int boff) TSVGP_AI {  // T-side fragments first, A-side last
         constexpr int S = decltype(slot_tag)::value;
         if constexpr (S < MB) rd1(f, TSVGP_IC(2 + S), ks_tag, boff);
         else rd1(f, TSVGP_IC(S - MB), ks_tag, boff);
     };
-    auto keep_set = [&](const Frag1& f) TSVGP_AI {
+    auto keep_set = [&](const Frag1<double>& f) TSVGP_AI {
         cfor<0, NR>([&](auto e) TSVGP_AI {
             const double x = f.v[decltype(e)::value];
             asm volatile("" ::"v"(x));
@@ -1813,7 +1866,7 @@ __device__ __forceinline__ void syrk1_body(const SyrkArgs<double>& a, double* ld
     };
     // MFMA number I of a k-step.  Off-diagonal: column block I / 2, row block I % 2.  Diagonal tile, wave W: the pairs
     // (row block s, column block n) with n <= W (s = 0) or n <= 7 - W (s = 1), ordered by n
-    auto mf = [&](const Frag1& f, auto i_tag) TSVGP_AI {
+    auto mf = [&](const Frag1<double>& f, auto i_tag) TSVGP_AI {
         constexpr int I = decltype(i_tag)::value;
         if constexpr (!DIAG) {
             constexpr int n = I >> 1, sblk = I & 1;
@@ -1838,8 +1891,8 @@ __device__ __forceinline__ void syrk1_body(const SyrkArgs<double>& a, double* ld
         // k-steps 0..2: MFMAs on one set, the next k-step's reads into the other, then its A fragments times their weight
         cfor<0, 3>([&](auto ks) TSVGP_AI {
             constexpr int KS_ = decltype(ks)::value;
-            Frag1& cur = (KS_ & 1) ? fy : fx;
-            Frag1& nxt = (KS_ & 1) ? fx : fy;
+            Frag1<double>& cur = (KS_ & 1) ? fy : fx;
+            Frag1<double>& nxt = (KS_ & 1) ? fx : fy;
             constexpr int S = NR + ((DIAG && KS_ == 0) ? 4 : 0);
             cfor<0, (NM > S ? NM : S)>([&](auto i) TSVGP_AI {
                 constexpr int I = decltype(i)::value;
@@ -1987,6 +2040,320 @@ __global__ __launch_bounds__(NTHREADS, 1) void syrk1_kernel(SyrkArgs<double> a) 
         syrk1_body<true, 2>(a, lds, wl, p, it, jt, sidx, slab, per_p, w);
     } else {
         syrk1_body<true, 3>(a, lds, wl, p, it, jt, sidx, slab, per_p, w);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// syrk1f_kernel (round 3, fp32): syrk1_kernel's recipe for the fp32 N-arrays.  A chunk is 32 rows n of the operand (the same
+// 16 KB per image and the same eight 1-KiB LDS-DMA pieces per wave as fp64: one piece = TWO k-rows of 128 floats), a k-step is
+// one v_mfma_f32_16x16x4_f32 per (row block, column block) -- half the cycles of the fp64 one, so a chunk of eight k-steps takes
+// the MFMA time of an fp64 chunk of four.  The images are unpadded [32 k-rows][128 floats] (a DMA piece lands lane-linear);
+// what the padding did in fp64 a swizzle does here: the 16-byte unit u of k-row k sits at unit u ^ 4 (k & 1) (applied to the
+// per-lane global source address of the DMA and to the reads), i.e. the 16-column block n of an odd k-row sits where block
+// n ^ 1 would: the two k-rows a half wave reads in one ds_read_b32 fall into different halves of the 32 banks.
+// The weights of a chunk (32 P floats <= 1 KiB) travel as one more DMA piece, as in syrk1_kernel.
+//     chunk start: weights of k-steps 4..7 (and g0's) from LDS
+//     k-steps 0..6: MFMAs on one set | reads of the next k-step -> the other set (tail: its A fragments times their weight)
+//                   diagonal tiles: the first-order operands in k-steps 0..3, their FMAs in k-steps 4, 5
+//     s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier
+//     k-step 7: MFMAs | LDS-DMA of chunk c + 2 into this chunk's buffer, weights of k-steps 0..3 and reads of (c + 1, 0)
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int S1F_KC = 32;              // rows n per chunk
+constexpr int S1F_IMG = S1F_KC * TILE;  // floats per image (16 KB)
+constexpr int S1F_BUF = 2 * S1F_IMG;    // floats per chunk buffer (image I + image J)
+constexpr int S1F_WL = 512;             // floats of weights per chunk buffer: 256 of g1, 256 of g0
+
+template <bool DIAG, int W>
+__device__ __forceinline__ void syrk1f_body(const SyrkArgs<float>& a, float* lds, float* wl, int p, int it, int jt, int sidx,
+                                            int slab, int per_p, int w) {
+    typedef v4f acc_t;
+    typedef Frag1<float> Frag;
+    const int t = threadIdx.x, lane = t & 63;
+    const int Mp = a.Mp, P = a.P;
+    const int64_t total_chunks = a.Np / S1F_KC;
+    const int64_t per = DIAG ? a.chunks_diag : a.chunks_off;  // (the launcher counts them in chunks of 32 rows for this kernel)
+    int64_t c_lo = (int64_t)sidx * per;
+    int64_t c_hi = c_lo + per;
+    if (c_lo > total_chunks) c_lo = total_chunks;
+    if (c_hi > total_chunks) c_hi = total_chunks;
+    const int nch = (int)(c_hi - c_lo);
+
+    constexpr int MB = DIAG ? 8 - W : 8;  // as syrk1_body
+    constexpr int NM = DIAG ? 9 : 16;
+    constexpr int NR = 2 + MB;
+    constexpr int NKS = S1F_KC / 4;  // k-steps per chunk
+
+    // fragment of k-row k = 4 ks + lk, column 16 n + lr: float k * 128 + 16 (n ^ (k & 1)) + lr, and k & 1 = lk & 1
+    const int lr = lane & 15, lk = lane >> 4, odd = lk & 1;
+    const int offa0 = lk * TILE + 16 * (w ^ odd) + lr;
+    const int offa1 = lk * TILE + 16 * ((7 - w) ^ odd) + lr;
+    const int offb_e = lk * TILE + lr + 16 * odd + (DIAG ? 0 : S1F_IMG);  // even column blocks: n ^ odd = n + odd
+    const int offb_o = lk * TILE + lr - 16 * odd + (DIAG ? 0 : S1F_IMG);  // odd ones:          n ^ odd = n - odd
+    // first-order sum: the lane's column pair 32 w + 2 lr, + 1 = floats 2 (lr & 1), + 1 of unit 8 w + (lr >> 1)
+    const int off1 = lk * TILE + 4 * ((8 * w + (lr >> 1)) ^ (4 * odd)) + 2 * (lr & 1);
+
+    auto uni64 = [](const void* ptr) TSVGP_AI {
+        const uint64_t v = (uint64_t)(uintptr_t)ptr;
+        return ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+               (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+    };
+    // DMA: piece i (0..7): image i & 1, k-row pair 4 (i >> 1) + w; lane L lands at unit L & 31 of k-row 2 pair + (L >> 5) and
+    // fetches the unit (L & 31) ^ 4 (L >> 5) of that row
+    const unsigned lds_u = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(uintptr_t)(lds_void_t*)lds + (unsigned)(w * 1024)));
+    const unsigned dvo = (unsigned)((lane >> 5) * Mp * (int)sizeof(float) + (((lane & 31) ^ ((lane >> 5) << 2)) << 4));
+    const unsigned dvw = (unsigned)(lane * 16);  // the weights piece is linear
+    const float* Bp = a.B + (size_t)p * a.strideB + (int64_t)(2 * w) * Mp;
+    const uint64_t bi_u = uni64(Bp + it * TILE), bj_u = uni64(Bp + jt * TILE);
+    const uint64_t row8 = (uint64_t)8 * Mp * sizeof(float), chunkb = (uint64_t)S1F_KC * Mp * sizeof(float);
+    uint64_t ci_u = 0, cj_u = 0;
+    auto dma_setup = [&](const int64_t c) TSVGP_AI {
+        ci_u = bi_u + (uint64_t)c * chunkb;
+        cj_u = bj_u + (uint64_t)c * chunkb;
+    };
+    auto dma_piece = [&](auto i_tag, const int buf) TSVGP_AI {
+        constexpr int I = decltype(i_tag)::value, rq = I >> 1;
+        const unsigned la = lds_u + (unsigned)((buf * S1F_BUF + (I & 1) * S1F_IMG + rq * 1024) * sizeof(float));
+        const uint64_t g = ((I & 1) ? cj_u : ci_u) + rq * row8;
+        const unsigned vo_ = dvo;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(la), "v"(vo_), "s"(g) : "memory");
+    };
+    constexpr int NDMA = DIAG ? 4 : 8;
+
+    const unsigned wl_u = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(lds_void_t*)wl);
+    const uint64_t wmask = (P >= 8) ? ~0ull : ((1ull << (8 * P)) - 1);  // 32 P floats = 8 P lanes of 16 bytes
+    const uint64_t g1_u = uni64(a.g1), g0_u = uni64(a.g0);
+    const uint64_t wchunk = (uint64_t)S1F_KC * P * sizeof(float);
+    auto dma_weights = [&](const int64_t c, const int buf) TSVGP_AI {  // wl: [buffer][g1 | g0][256 floats]
+        if (w == 0 || (DIAG && w == 1)) {
+            const unsigned la = wl_u + (unsigned)((buf * S1F_WL + (w == 1 ? 256 : 0)) * sizeof(float));
+            const uint64_t g = (w == 1 ? g0_u : g1_u) + (uint64_t)c * wchunk;
+            const unsigned vo_ = dvw;
+            uint64_t saved;
+            asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                         "global_load_lds_dwordx4 %3, %4\n\ts_mov_b64 exec, %0"
+                         : "=&s"(saved)
+                         : "s"(wmask), "s"(la), "v"(vo_), "s"(g)
+                         : "memory");
+        }
+    };
+    float w1r[NKS], w0r[NKS];  // the lane's weights of the chunk being computed: k-rows 4 ks + lk
+    const int woff = lk * P + p;
+    auto read_weight = [&](auto i_tag, const int buf) TSVGP_AI {  // I < 8: g1 of k-step I; I >= 8: g0 of k-step I - 8
+        constexpr int I = decltype(i_tag)::value;
+        if constexpr (I < NKS) w1r[I] = wl[buf * S1F_WL + woff + I * 4 * P];
+        else w0r[I - NKS] = wl[buf * S1F_WL + 256 + woff + (I - NKS) * 4 * P];
+    };
+    // weight slot J of a half (HALF 0: k-steps 0..3, read in front of the chunk; HALF 1: k-steps 4..7, read at its start)
+    constexpr int NWH = DIAG ? 8 : 4;
+    auto read_weight_half = [&](auto j_tag, auto half_tag, const int buf) TSVGP_AI {
+        constexpr int J = decltype(j_tag)::value, H = decltype(half_tag)::value;
+        if constexpr (J < 4) read_weight(TSVGP_IC(4 * H + J), buf);
+        else read_weight(TSVGP_IC(NKS + 4 * H + J - 4), buf);
+    };
+
+    acc_t acc[2][8];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int n = 0; n < 8; ++n) acc[s][n] = acc_t{0, 0, 0, 0};
+    float acc1v[2] = {0.f, 0.f};
+    Frag fx, fy;
+
+    auto rd1 = [&](Frag& f, auto e_tag, auto ks_tag, const int boff) TSVGP_AI {
+        constexpr int E = decltype(e_tag)::value, KS_ = decltype(ks_tag)::value;
+        if constexpr (E == 0) f.v[0] = lds[offa0 + boff + KS_ * 4 * TILE];
+        else if constexpr (E == 1) f.v[1] = lds[offa1 + boff + KS_ * 4 * TILE];
+        else f.v[E] = lds[(((E - 2) & 1) ? offb_o : offb_e) + boff + KS_ * 4 * TILE + (E - 2) * 16];
+    };
+    auto rds = [&](Frag& f, auto slot_tag, auto ks_tag, const int boff) TSVGP_AI {  // T-side fragments first, A-side last
+        constexpr int S = decltype(slot_tag)::value;
+        if constexpr (S < MB) rd1(f, TSVGP_IC(2 + S), ks_tag, boff);
+        else rd1(f, TSVGP_IC(S - MB), ks_tag, boff);
+    };
+    auto keep_set = [&](const Frag& f) TSVGP_AI {
+        cfor<0, NR>([&](auto e) TSVGP_AI {
+            const float x = f.v[decltype(e)::value];
+            asm volatile("" ::"v"(x));
+        });
+    };
+    auto mf = [&](const Frag& f, auto i_tag) TSVGP_AI {  // as syrk1_body
+        constexpr int I = decltype(i_tag)::value;
+        if constexpr (!DIAG) {
+            constexpr int n = I >> 1, sblk = I & 1;
+            acc[sblk][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.v[sblk], f.v[2 + n], acc[sblk][n], 0, 0, 0);
+        } else {
+            constexpr int n = (I < 2 * (W + 1)) ? (I >> 1) : (I - (W + 1));
+            constexpr int sblk = (I < 2 * (W + 1)) ? (I & 1) : 1;
+            acc[sblk][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.v[sblk], f.v[2 + n], acc[sblk][n], 0, 0, 0);
+        }
+    };
+    v2f f1[NKS];  // first-order sum: the lane's column pair in its eight k-rows
+    auto chunk = [&](auto buf_tag, auto next_tag, const int64_t c_fetch) TSVGP_AI {
+        constexpr int BUF = decltype(buf_tag)::value;
+        constexpr bool NEXT = decltype(next_tag)::value;
+        constexpr int B0 = BUF * S1F_BUF, B1 = (BUF ^ 1) * S1F_BUF;
+        if constexpr (NEXT) {
+            dma_setup(c_fetch);
+            TSVGP_SB();
+        }
+        cfor<0, NKS - 1>([&](auto ks) TSVGP_AI {
+            constexpr int KS_ = decltype(ks)::value;
+            Frag& cur = (KS_ & 1) ? fy : fx;
+            Frag& nxt = (KS_ & 1) ? fx : fy;
+            // extra slots behind the fragment reads: k-step 0 the second half of the weights; diagonal tiles, k-steps 0..3: two
+            // first-order operands each
+            constexpr int XW = KS_ == 0 ? NWH : 0;
+            constexpr int XF = (DIAG && KS_ < 4) ? 2 : 0;
+            constexpr int S = NR + XW + XF;
+            cfor<0, (NM > S ? NM : S)>([&](auto i) TSVGP_AI {
+                constexpr int I = decltype(i)::value;
+                if constexpr (I < NM) mf(cur, i);
+                if constexpr (I < NR) rds(nxt, i, TSVGP_IC(KS_ + 1), B0);
+                else if constexpr (I < NR + XW) read_weight_half(TSVGP_IC(I - NR), TSVGP_IC(1), BUF);
+                else if constexpr (I < S)
+                    f1[2 * KS_ + I - NR - XW] = *reinterpret_cast<const v2f*>(lds + off1 + B0 + (2 * KS_ + I - NR - XW) * 4 * TILE);
+                TSVGP_SB();
+            });
+            nxt.v[0] *= w1r[KS_ + 1];
+            nxt.v[1] *= w1r[KS_ + 1];
+            if constexpr (DIAG && (KS_ == 4 || KS_ == 5)) {
+#pragma unroll
+                for (int q = 4 * (KS_ - 4); q < 4 * (KS_ - 4) + 4; ++q) {
+                    acc1v[0] += w0r[q] * f1[q][0];
+                    acc1v[1] += w0r[q] * f1[q][1];
+                }
+            }
+            TSVGP_SB();
+            keep_set(cur);
+        });
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        TSVGP_SB();
+        // (NKS - 1 is odd: the last k-step's fragments sit in set Y)
+        if constexpr (NEXT) {
+            constexpr int S3 = NDMA + NWH + NR;
+            cfor<0, (NM > S3 ? NM : S3)>([&](auto i) TSVGP_AI {
+                constexpr int I = decltype(i)::value;
+                if constexpr (I < NM) mf(fy, i);
+                if constexpr (I < NDMA) dma_piece(TSVGP_IC(DIAG ? 2 * I : I), BUF);
+                else if constexpr (I < NDMA + NWH) read_weight_half(TSVGP_IC(I - NDMA), TSVGP_IC(0), BUF ^ 1);
+                else if constexpr (I < S3) rds(fx, TSVGP_IC(I - NDMA - NWH), TSVGP_IC(0), B1);
+                TSVGP_SB();
+            });
+            dma_weights(c_fetch, BUF);
+            fx.v[0] *= w1r[0];
+            fx.v[1] *= w1r[0];
+            TSVGP_SB();
+        } else {
+            cfor<0, NM>([&](auto i) TSVGP_AI { mf(fy, i); });
+        }
+        keep_set(fy);
+    };
+
+    if (nch > 0) {
+        dma_setup(c_lo);
+        cfor<0, NDMA>([&](auto i) TSVGP_AI { dma_piece(TSVGP_IC(DIAG ? 2 * decltype(i)::value : decltype(i)::value), 0); });
+        dma_weights(c_lo, 0);
+        const int64_t c1 = (nch > 1) ? c_lo + 1 : c_lo;  // a slice of one chunk fetches it twice (the second copy is never read)
+        dma_setup(c1);
+        cfor<0, NDMA>([&](auto i) TSVGP_AI { dma_piece(TSVGP_IC(DIAG ? 2 * decltype(i)::value : decltype(i)::value), 1); });
+        dma_weights(c1, 1);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        cfor<0, NWH>([&](auto i) TSVGP_AI { read_weight_half(i, TSVGP_IC(0), 0); });
+        cfor<0, NR>([&](auto i) TSVGP_AI { rds(fx, i, TSVGP_IC(0), 0); });
+        fx.v[0] *= w1r[0];
+        fx.v[1] *= w1r[0];
+        int i = 0;
+        const int64_t c_last = c_hi - 1;
+        auto fetch_of = [&](int idx) TSVGP_AI { const int64_t c = c_lo + idx + 2; return c < c_last ? c : c_last; };
+        if (nch >= 3) {  // the first pair in front of the loop: see syrk1_body
+            chunk(TSVGP_IC(0), TSVGP_BC(true), fetch_of(0));
+            chunk(TSVGP_IC(1), TSVGP_BC(true), fetch_of(1));
+            for (i = 2; i + 2 < nch; i += 2) {
+                chunk(TSVGP_IC(0), TSVGP_BC(true), fetch_of(i));
+                chunk(TSVGP_IC(1), TSVGP_BC(true), fetch_of(i + 1));
+            }
+        }
+        if (nch - i == 2) {
+            chunk(TSVGP_IC(0), TSVGP_BC(true), fetch_of(i));
+            chunk(TSVGP_IC(1), TSVGP_BC(false), 0);
+        } else {
+            chunk(TSVGP_IC(0), TSVGP_BC(false), 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+
+    float* out = a.part2 + ((size_t)p * per_p + slab) * (TILE * TILE) + (lane & 15);
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float* orow = out + (row_block(w, s) * 16 + Mfma<float>::row(lane, r)) * TILE;
+#pragma unroll
+            for (int n = 0; n < 8; ++n)
+                if (!DIAG || n <= (s == 0 ? W : 7 - W)) orow[n * 16] = acc[s][n][r];
+        }
+    if constexpr (DIAG) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            acc1v[q] += __shfl_xor(acc1v[q], 16);
+            acc1v[q] += __shfl_xor(acc1v[q], 32);
+        }
+        if (lk == 0) {
+            float* o1 = a.part1 + ((size_t)p * a.ns_diag + sidx) * Mp + it * TILE + w * 32 + lr * 2;
+            o1[0] = acc1v[0];
+            o1[1] = acc1v[1];
+        }
+    }
+}
+
+#ifndef TSVGP_S1F_WAVES  // waves per SIMD the register allocation may assume at most (1: one workgroup per CU)
+#define TSVGP_S1F_WAVES 2
+#endif
+__global__ __launch_bounds__(NTHREADS, 1) __attribute__((amdgpu_waves_per_eu(1, TSVGP_S1F_WAVES))) void syrk1f_kernel(SyrkArgs<float> a) {
+    __shared__ __attribute__((aligned(1024))) float lds[2 * S1F_BUF];
+    __shared__ __attribute__((aligned(1024))) float wl[2 * S1F_WL];
+#ifdef TSVGP_S1F_LDS_PAD  // experiment: more than half of a CU's LDS, i.e. one workgroup per CU
+    __shared__ float s1f_pad[TSVGP_S1F_LDS_PAD];
+    {
+        float* keep_pad = s1f_pad + threadIdx.x;
+        asm volatile("" ::"v"(keep_pad));
+    }
+#endif
+
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nt = a.nt, n_off = nt * (nt - 1) / 2;
+    const int per_p = n_off * a.ns_off + nt * a.ns_diag;
+    int lin = xcd_remap(blockIdx.x, gridDim.x);
+    const int p = lin / per_p;
+    lin -= p * per_p;
+    int it, jt, sidx;
+    if (lin < n_off * a.ns_off) {
+        sidx = lin / n_off;
+        const int idx = lin - sidx * n_off;  // idx-th pair (it, jt) with jt < it
+        it = 1;
+        while (it * (it + 1) / 2 <= idx) ++it;
+        jt = idx - it * (it - 1) / 2;
+    } else {
+        lin -= n_off * a.ns_off;
+        sidx = lin / nt;
+        it = jt = lin - sidx * nt;
+    }
+    const int tri = it * (it + 1) / 2 + jt;
+    const int slab = (tri - it) * a.ns_off + it * a.ns_diag + sidx;
+    if (it != jt) {
+        syrk1f_body<false, 0>(a, lds, wl, p, it, jt, sidx, slab, per_p, w);
+    } else if (w == 0) {
+        syrk1f_body<true, 0>(a, lds, wl, p, it, jt, sidx, slab, per_p, w);
+    } else if (w == 1) {
+        syrk1f_body<true, 1>(a, lds, wl, p, it, jt, sidx, slab, per_p, w);
+    } else if (w == 2) {
+        syrk1f_body<true, 2>(a, lds, wl, p, it, jt, sidx, slab, per_p, w);
+    } else {
+        syrk1f_body<true, 3>(a, lds, wl, p, it, jt, sidx, slab, per_p, w);
     }
 }
 
@@ -3055,13 +3422,11 @@ int moments(const T* A, int64_t strideA, const T* Tm, const T* gamma, const T* Y
     else if (mode == TSVGP_TRI_LOWER)
         hipLaunchKernelGGL((panel_kernel<T, MODE_MOMENTS, TSVGP_TRI_LOWER>), grid, block, 0, (hipStream_t)stream, a);
 #ifndef TSVGP_MOMENTS_OLD  // (-DTSVGP_MOMENTS_OLD: A/B builds keep round 2's panel_kernel on this path)
-    else if (mode == TSVGP_TRI_UPPER && sizeof(T) == 8 && (size_t)Mp * sizeof(T) <= P1_GAMMA_LDS_MAX) {
-        // fp64, upper form: one workgroup per CU with the hand-laid instruction stream (panel1_kernel)
-        if constexpr (sizeof(T) == 8) {
-            static DynLdsOptIn optin1;
-            if (optin1.ensure(reinterpret_cast<const void*>(&panel1_kernel), P1_GAMMA_LDS_MAX) != TSVGP_OK) return TSVGP_ELAUNCH;
-            hipLaunchKernelGGL(panel1_kernel, grid, block, (size_t)Mp * sizeof(T), (hipStream_t)stream, a);
-        }
+    else if (mode == TSVGP_TRI_UPPER && (sizeof(T) == 8 || !TSVGP_MOMENTS_OLD_F32) && (size_t)Mp * sizeof(T) <= P1_GAMMA_LDS_MAX) {
+        // upper form: one workgroup per CU with the hand-laid instruction stream (panel1_kernel)
+        static DynLdsOptIn optin1;
+        if (optin1.ensure(reinterpret_cast<const void*>(&panel1_kernel<T>), P1_GAMMA_LDS_MAX) != TSVGP_OK) return TSVGP_ELAUNCH;
+        hipLaunchKernelGGL((panel1_kernel<T>), grid, block, (size_t)Mp * sizeof(T), (hipStream_t)stream, a);
     }
 #endif
     else if (mode == TSVGP_TRI_UPPER && (size_t)Mp * sizeof(T) <= 8192)
@@ -3117,6 +3482,15 @@ int site_accum(const T* B, int64_t strideB, const T* g0, const T* g1, double* ac
         if (optin_s1.ensure(reinterpret_cast<const void*>(&syrk1_kernel), 0) != TSVGP_OK) return TSVGP_ELAUNCH;
         hipLaunchKernelGGL(syrk1_kernel, dim3((unsigned)nwg), dim3(NTHREADS), 0, (hipStream_t)stream, a);
       }
+    } else if (sizeof(T) == 4 && !TSVGP_SYRK_OLD_F32 && P <= 8) {
+      if constexpr (sizeof(T) == 4) {
+        const int64_t total32 = Np / S1F_KC;  // this kernel's chunks are 32 rows
+        a.chunks_off = (total32 + a.ns_off - 1) / a.ns_off;
+        a.chunks_diag = (total32 + a.ns_diag - 1) / a.ns_diag;
+        static DynLdsOptIn optin_s1f;  // 68 KB of static LDS
+        if (optin_s1f.ensure(reinterpret_cast<const void*>(&syrk1f_kernel), 0) != TSVGP_OK) return TSVGP_ELAUNCH;
+        hipLaunchKernelGGL(syrk1f_kernel, dim3((unsigned)nwg), dim3(NTHREADS), 0, (hipStream_t)stream, a);
+      }
     } else
 #endif
         hipLaunchKernelGGL(syrk_kernel<T>, dim3((unsigned)nwg), dim3(NTHREADS), 0, (hipStream_t)stream, a);
@@ -3134,6 +3508,12 @@ int site_accum_slots() {
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return -1;
 #ifndef TSVGP_SYRK_OLD
     if (sizeof(T) == 8) return cus;  // syrk1_kernel: one workgroup per CU by construction (512 registers per wave)
+    if (!TSVGP_SYRK_OLD_F32) {       // syrk1f_kernel: what its registers and 68 KB of LDS allow
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&syrk1f_kernel), NTHREADS, 0) !=
+            hipSuccess)
+            return -1;
+        return cus * (nb > 2 ? 2 : nb < 1 ? 1 : nb);
+    }
 #endif
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(&syrk_kernel<T>), NTHREADS,
                                                      0) != hipSuccess)

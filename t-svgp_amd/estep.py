@@ -19,6 +19,7 @@ Kernel sequence of ``run(..., sites=True)`` by projection route (models/tsvgp.py
 from __future__ import annotations
 
 import ctypes
+import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -49,6 +50,9 @@ class EStepStats:
 
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
+
+
+SYRK_OVER_F32 = int(os.environ.get("TSVGP_SYRK_OVER_F32", "8"))  # (tuning hook; see choose_nsplit)
 
 
 class EStepEngine:
@@ -142,8 +146,8 @@ class EStepEngine:
         """Number of N-slices per off-diagonal tile.  ns = the largest number whose workgroups all fit in ONE resident round,
         n_off * ns + nt * ns_diag <= slots / P (diagonal tiles cost less per row and get correspondingly longer slices: the rule
         of syrk_ns_diag in the kernel source), times an oversubscription factor:
-        fp32 (syrk_kernel, two workgroups per CU): 8 rounds of shorter slices keep two workgroups resident on every CU until the
-        very end (a workgroup left alone on a CU runs its MFMA pipe at ~60 %): 18.3 -> 17.2 ms at N = 1e6;
+        fp32 (syrk1f_kernel, two workgroups per CU by its registers and LDS): 8 -- at N = 1e6, M = 1024 the launch takes 8.21 /
+        8.28 / 7.82 / 7.94 / 8.03 ms with 28 / 56 / 112 / 224 / 448 slices (gpurun_out/r3m/s1f_ab.txt; round 2's syrk_kernel: 8.76);
         fp64 (syrk1_kernel, one workgroup per CU): 32 -- at N = 1e6, M = 1024 the launch takes 17.0 / 15.75 / 15.5 ms with 56 /
         120 / 224 slices (gpurun_out/r3e/kb4_*.txt) -- but never slices shorter than ~96 chunks of 16 rows (at 125 000 rows
         80 slices: 2.16 ms, 120: 2.18, 32: 2.36)."""
@@ -151,14 +155,15 @@ class EStepEngine:
         n_off = nt * (nt - 1) // 2
         budget = max(1, self.slots() // P)
         f64 = self.dtype == torch.float64
-        num = 20 if f64 else 23  # TSVGP_SYRK1_DIAG_NUM / TSVGP_SYRK_DIAG_NUM
+        num = 20 if f64 else 22  # TSVGP_SYRK1_DIAG_NUM / TSVGP_SYRK1F_DIAG_NUM
         ns = 1
         while n_off * (ns + 1) + nt * ((num * (ns + 1) + 31) // 32) <= budget:
             ns += 1
-        over = self.syrk_oversubscribe if self.syrk_oversubscribe is not None else (32 if f64 else 8)
+        over = self.syrk_oversubscribe if self.syrk_oversubscribe is not None else (32 if f64 else SYRK_OVER_F32)
         nsplit = ns * over
-        if f64 and Np is not None:
-            nsplit = max(ns, min(nsplit, (Np // 16) // 96))
+        if Np is not None:
+            chunk_rows = 16 if f64 else 32
+            nsplit = max(ns, min(nsplit, (Np // chunk_rows) // (96 if f64 else 48)))
         return nsplit
 
     def _pad_square(self, A: torch.Tensor, Mp: int, key: str = None) -> torch.Tensor:

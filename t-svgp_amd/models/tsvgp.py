@@ -327,8 +327,11 @@ class t_SVGP(base_SVGP):
             l1, L = l1.index_select(1, idx), L.index_select(0, idx)
         Kzz = warm[1]["Kzz"] if warm else eng.kuu(Z, kernel)  # HIP fill kernel, no jitter
         Id = self._eye(M)
-        K6 = Kzz.clone()
-        K6.diagonal(dim1=-2, dim2=-1).add_(default_jitter())  # tsvgp.py:209-211
+        if warm and "K6" in warm[1]:
+            K6 = warm[1]["K6"]  # read only from here on (40 us of copy + strided add per step otherwise)
+        else:
+            K6 = Kzz.clone()
+            K6.diagonal(dim1=-2, dim2=-1).add_(default_jitter())  # tsvgp.py:209-211
         P_ = L.shape[0]
         potrf = getattr(eng, "cholesky", None)  # HIP blocked Cholesky (tsvgp_potrf_f64)
         if potrf is not None and routes is not None and any(r == "projected" for r in routes):
@@ -419,7 +422,7 @@ class t_SVGP(base_SVGP):
                        project_T=L9inv.transpose(-1, -2).contiguous(), project_mode=B.TRI_UPPER, moments_on_kfu=True)
             return ops
         if warm_key is not None and not warm:
-            self._warm = (warm_key, dict(Kzz=Kzz, U9=U9, Uinv9=Uinv9))
+            self._warm = (warm_key, dict(Kzz=Kzz, K6=K6, U9=U9, Uinv9=Uinv9))
         routes = list(routes) if routes is not None else ["whitened"] * P_
         ops["routes"] = routes
         if all(r == "direct" for r in routes):
