@@ -975,9 +975,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void panel_kernel(PanelArgs<T> a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// panel1_kernel (round 3): the fp64 moments of panel_kernel<MOMENTS, UPPER, FUSE> as ONE 256-thread workgroup per CU with a
-// hand-laid instruction stream -- 0.90 of the fp64 MFMA peak where panel_kernel holds 0.83 on the same box
-// (profiles/r03_moments_lab_notes.txt; tools/panel_lab.hip is the bench it was developed in).
+// panel1_kernel (round 3): the upper-form products of panel_kernel -- the moments (MODE_MOMENTS, mean fused) and the stored
+// product of tsvgp_trmm (MODE_STORE) -- as ONE 256-thread workgroup per CU with a hand-laid instruction stream, for both
+// types.  fp64 moments: 0.90 of the MFMA peak where panel_kernel holds 0.83 on the same box
+// (profiles/r03_moments_lab_notes.txt; tools/panel_lab.hip is the bench it was developed in); alone at N = 1e6, M = 1024
+// (tools/kbench.py, old -> new): fp64 moments 17.4 -> 15.2 ms, fp64 trmm 18.3 -> 16.2, fp32 moments 8.28 -> 8.04, fp32 trmm
+// 8.6 -> 8.0.  The lower-form products (projected route) stay on panel_kernel.
 //   * one wave per SIMD (__launch_bounds__(256, 1)): 512 registers per wave, so two fragment register sets, the accumulators
 //     and everything else live without a single scratch access (panel_kernel is pinned at 256 by its partner workgroup);
 //   * the chunk stream of a row panel runs through all column tiles without draining: every MFMA is followed by at most one
@@ -1037,7 +1040,7 @@ struct Frag1 {
 #define TSVGP_BC(x) std::integral_constant<bool, (x)>{}
 #define TSVGP_SB() __builtin_amdgcn_sched_barrier(0)
 
-template <typename T>
+template <typename T, int MODE = MODE_MOMENTS>
 __global__ __launch_bounds__(NTHREADS, 1) void panel1_kernel(PanelArgs<T> a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char panel_dyn_smem[];
     typedef typename P1Types<T>::frag_t frag_t;
@@ -1088,11 +1091,17 @@ __global__ __launch_bounds__(NTHREADS, 1) void panel1_kernel(PanelArgs<T> a) {
     double ve_acc = 0.0;
     int nonpos = 0;
 
+    // STORE (tsvgp_trmm): one latent per grid.y slice, the operands and the output advance by their latent strides, a.P = 1;
+    // MOMENTS: the workgroup takes its row panel through all P latents in turn
+    const int pb = (MODE == MODE_STORE) ? (int)blockIdx.y : 0;
     for (int p = 0; p < a.P; ++p) {
-        const T* Tp = a.Tm + (size_t)p * Mp * Mp;
-        const char* Ab = reinterpret_cast<const char*>(a.A + (size_t)p * a.strideA + (n0 + 8 * w) * (int64_t)Mp);
-        __syncthreads();  // the previous latent's readers of gsm / rowq / rowm are done
-        for (int j = t; j < Mp; j += NTHREADS) gsm[j] = a.gamma[(size_t)j * a.P + p];
+        const T* Tp = (MODE == MODE_STORE) ? a.Tm + (size_t)pb * a.strideT : a.Tm + (size_t)p * Mp * Mp;
+        const char* Ab = reinterpret_cast<const char*>(a.A + (size_t)(MODE == MODE_STORE ? pb : p) * a.strideA +
+                                                       (n0 + 8 * w) * (int64_t)Mp);
+        if constexpr (MODE == MODE_MOMENTS) {
+            __syncthreads();  // the previous latent's readers of gsm / rowq / rowm are done
+            for (int j = t; j < Mp; j += NTHREADS) gsm[j] = a.gamma[(size_t)j * a.P + p];
+        }
 
         struct Cursor {
             int it, c;
@@ -1276,12 +1285,28 @@ __global__ __launch_bounds__(NTHREADS, 1) void panel1_kernel(PanelArgs<T> a) {
                 chunk(TSVGP_IC(0xFF), TSVGP_IC((1 << BPC) - 1), TSVGP_IC(1), gc, c_last);
             };
 #undef TSVGP_ZACC
-            if (it == 0) {
-                diag(TSVGP_BC(true));
-                if (!last_tile) full(TSVGP_BC(true));
+            if (MODE == MODE_MOMENTS && it == 0) {
+                if constexpr (MODE == MODE_MOMENTS) {
+                    diag(TSVGP_BC(true));
+                    if (!last_tile) full(TSVGP_BC(true));
+                }
             } else {
                 diag(TSVGP_BC(false));
                 if (!last_tile) full(TSVGP_BC(false));
+            }
+            if constexpr (MODE == MODE_STORE) {
+                // the column tile goes out as panel_kernel writes it (the next tile's first chunks are already on their way; its
+                // first barrier waits for these stores with them -- they share vmcnt)
+                T* Cb = a.C + (size_t)pb * a.strideC + n0 * (int64_t)Mp + it * TILE + (lane & 15);
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        T* Cr = Cb + (int64_t)(row_block(w, s) * 16 + Mfma<T>::row(lane, r)) * Mp;
+#pragma unroll
+                        for (int n = 0; n < 8; ++n) Cr[n * 16] = acc[s][n][r];
+                    }
+                continue;
             }
             // the column tile is complete: squares of its entries, summed per row (as panel_kernel)
             double keep = 0.0;
@@ -1304,6 +1329,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void panel1_kernel(PanelArgs<T> a) {
             rs_mine += keep;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the saturated re-fetches of the last two chunks have landed
+        if constexpr (MODE == MODE_STORE) return;
 
         // row sums and means to LDS, then the likelihood map of panel_kernel's epilogue (two threads per row)
         if ((lane & 15) < 8) {
@@ -3346,6 +3372,13 @@ int trmm(const T* A, int64_t strideA, const T* Tm, int64_t strideT, T* C, int64_
     const dim3 grid((unsigned)(Np / TILE), (unsigned)batch), block(NTHREADS);
     if (mode == TSVGP_TRI_LOWER)
         hipLaunchKernelGGL((panel_kernel<T, MODE_STORE, TSVGP_TRI_LOWER>), grid, block, 0, (hipStream_t)stream, a);
+#ifndef TSVGP_TRMM_OLD  // (-DTSVGP_TRMM_OLD: A/B builds keep round 2's panel_kernel for the upper product)
+    else if (mode == TSVGP_TRI_UPPER) {
+        static DynLdsOptIn optin1s;  // 66 KB of static LDS
+        if (optin1s.ensure(reinterpret_cast<const void*>(&panel1_kernel<T, MODE_STORE>), 0) != TSVGP_OK) return TSVGP_ELAUNCH;
+        hipLaunchKernelGGL((panel1_kernel<T, MODE_STORE>), grid, block, 0, (hipStream_t)stream, a);
+    }
+#endif
     else if (mode == TSVGP_TRI_UPPER)
         hipLaunchKernelGGL((panel_kernel<T, MODE_STORE, TSVGP_TRI_UPPER>), grid, block, 0, (hipStream_t)stream, a);
     else

@@ -29,6 +29,7 @@ from __future__ import annotations
 
 import abc
 import functools
+import os
 import time
 import warnings
 
@@ -395,7 +396,9 @@ class t_SVGP(base_SVGP):
                 ops["K9inv"] = Uinv9.transpose(-1, -2) @ Uinv9
 
         side = getattr(eng, "_side", None)
-        if self.overlap_fill and side is not None and Kzz.is_cuda:
+        if os.environ.get("TSVGP_EPI_INLINE") == "1":  # experiment: on the main stream, in front of the moments kernel
+            epilogue_operands()
+        elif self.overlap_fill and side is not None and Kzz.is_cuda:
             capturing = torch.cuda.is_current_stream_capturing()  # the side stream then joins the capture (fork / join by events)
             main = torch.cuda.current_stream(self.device)
             ready = torch.cuda.Event()

@@ -54,6 +54,7 @@ def timeit(name, fn, flops=None, byts=None):
 
 timeit("se_fill", lambda: eng.se_fill(X, Z, inv_ls, 1.0, Kfu), byts=N * M * esz)
 timeit("trmm lower", lambda: eng.trmm(Kfu, Tl, Bw, B.TRI_LOWER), flops=N * M * (M + 1))
+timeit("trmm upper", lambda: eng.trmm(Kfu, Tu[0], Bw, B.TRI_UPPER), flops=N * M * (M + 1))
 for lik, nm in ((0, "none"), (1, "gauss"), (2, "bern")):
     timeit(f"moments upper lik={nm}", lambda: B.check(eng._fn("tsvgp_moments")(Bw.data_ptr(), Tu.data_ptr(), gam.data_ptr(), Y.data_ptr(), 1e9, lik, 0.1, None, None, g0.data_ptr(), g1.data_ptr(), vep.data_ptr(), npp.data_ptr(), N, Np, Mp, P, B.TRI_UPPER, st), "m"), flops=N * M * (M + 1) * P)
 g1.uniform_(-1.0, -0.1); g0.normal_()
