@@ -52,9 +52,6 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
 
-SYRK_OVER_F32 = int(os.environ.get("TSVGP_SYRK_OVER_F32", "8"))  # (tuning hook; see choose_nsplit)
-
-
 class EStepEngine:
     """Launches the C-ABI kernels (include/tsvgp_hip.h) on torch-allocated device memory."""
 
@@ -143,28 +140,40 @@ class EStepEngine:
         return self._slots
 
     def choose_nsplit(self, Mp: int, P: int, Np: int = None) -> int:
-        """Number of N-slices per off-diagonal tile.  ns = the largest number whose workgroups all fit in ONE resident round,
-        n_off * ns + nt * ns_diag <= slots / P (diagonal tiles cost less per row and get correspondingly longer slices: the rule
-        of syrk_ns_diag in the kernel source), times an oversubscription factor:
-        fp32 (syrk1f_kernel, two workgroups per CU by its registers and LDS): 8 -- at N = 1e6, M = 1024 the launch takes 8.21 /
-        8.28 / 7.82 / 7.94 / 8.03 ms with 28 / 56 / 112 / 224 / 448 slices (gpurun_out/r3m/s1f_ab.txt; round 2's syrk_kernel: 8.76);
-        fp64 (syrk1_kernel, one workgroup per CU): 32 -- at N = 1e6, M = 1024 the launch takes 17.0 / 15.75 / 15.5 ms with 56 /
-        120 / 224 slices (gpurun_out/r3e/kb4_*.txt) -- but never slices shorter than ~96 chunks of 16 rows (at 125 000 rows
-        80 slices: 2.16 ms, 120: 2.18, 32: 2.36)."""
+        """Number of N-slices per off-diagonal tile of the weighted Gram (diagonal tiles cost less per row and get
+        correspondingly fewer, longer slices: the rule of syrk_ns_diag in the kernel source, mirrored in ``ns_diag`` below).
+        All workgroups of the launch take the same time by construction, so the launch runs in ROUNDS of `slots` workgroups
+        (one per CU for fp64, two for fp32) and costs  rounds * (chunks per slice + o):  o ~ 14 chunk-times per workgroup for
+        its first fetch, the 128 x 128 partial tile it writes and the reduction's read of it (fitted at M = 512: 58 / 116 /
+        232 / 464 / 651 slices take 4.20 / 4.27 / 4.43 / 4.64 / 4.85 ms, gpurun_out/r3m/kbench_m512.txt).  The slice count is
+        the one that minimises this: whole rounds, and few of them.  At N = 1e6 (gpurun_out/r3m/nsplit_rounds.txt):
+        M = 1024 fp64: 62 slices (2048 workgroups = 8 rounds exactly) 15.19 ms, 124: 15.32, 224 (28.9 rounds): 15.62,
+        56 (7.2 rounds): 17.0; M = 1024 fp32: 61 slices 7.65 ms, 120: 7.99; M = 512 fp64: 120 slices 4.15 ms, 651: 4.72.
+        A launch of exactly one round is charged 2 % more (nothing evens out the diagonal against the off-diagonal tiles:
+        M = 512, 29 slices = one round 4.33 ms against 4.20 for two)."""
         nt = Mp // B.TILE
         n_off = nt * (nt - 1) // 2
-        budget = max(1, self.slots() // P)
+        slots = self.slots()
         f64 = self.dtype == torch.float64
         num = 20 if f64 else 22  # TSVGP_SYRK1_DIAG_NUM / TSVGP_SYRK1F_DIAG_NUM
-        ns = 1
-        while n_off * (ns + 1) + nt * ((num * (ns + 1) + 31) // 32) <= budget:
-            ns += 1
-        over = self.syrk_oversubscribe if self.syrk_oversubscribe is not None else (32 if f64 else SYRK_OVER_F32)
-        nsplit = ns * over
-        if Np is not None:
-            chunk_rows = 16 if f64 else 32
-            nsplit = max(ns, min(nsplit, (Np // chunk_rows) // (96 if f64 else 48)))
-        return nsplit
+        ns_diag = lambda ns: max(1, (num * ns + 31) // 32)
+        if Np is None or self.syrk_oversubscribe is not None:
+            # (no row count, or a forced oversubscription: the largest count that fits one round, times the factor)
+            ns = 1
+            while P * (n_off * (ns + 1) + nt * ns_diag(ns + 1)) <= slots:
+                ns += 1
+            return ns * (self.syrk_oversubscribe if self.syrk_oversubscribe is not None else 8)
+        chunks = max(1, Np // (16 if f64 else 32))  # the kernels' chunks: 16 rows (fp64) / 32 rows (fp32)
+        overhead = 14.0
+        best, best_t = 1, None
+        for ns in range(1, max(1, min(chunks // 32, 1024)) + 1):
+            nd = ns_diag(ns)
+            rounds = -(-(P * (n_off * ns + nt * nd)) // slots)
+            per = max(-(-chunks // ns) if n_off else 0, -(-chunks // nd) * num / 32.0)
+            t = rounds * (per + overhead) * (1.02 if rounds == 1 else 1.0)
+            if best_t is None or t < best_t * (1.0 - 1e-9):
+                best, best_t = ns, t
+        return best
 
     def _pad_square(self, A: torch.Tensor, Mp: int, key: str = None) -> torch.Tensor:
         """[.., M, M] fp64 -> zero-padded contiguous [.., Mp, Mp] in the compute dtype (a cached buffer per key)."""
