@@ -303,7 +303,7 @@ class t_SVGP(base_SVGP):
     def _use_direct(self, jitter) -> list:
         return [r == "direct" for r in self._routes(jitter)]
 
-    def _site_operands(self, whiten_jitter=None, warm_key=None, routes=None, latents=None):
+    def _site_operands(self, whiten_jitter=None, warm_key=None, routes=None, latents=None, fork=True):
         """Everything the N-pass needs that depends only on (theta, Z, lambda): O(M^3), fp64, replicated.
         No host synchronisation happens here: Cholesky statuses are collected in ops["infos"] and checked once per
         call by ``_check_step`` (TF raises immediately; here the raise comes at the end of the same call).
@@ -396,7 +396,9 @@ class t_SVGP(base_SVGP):
                 ops["K9inv"] = Uinv9.transpose(-1, -2) @ Uinv9
 
         side = getattr(eng, "_side", None)
-        if os.environ.get("TSVGP_EPI_INLINE") == "1":  # experiment: on the main stream, in front of the moments kernel
+        if not fork or os.environ.get("TSVGP_EPI_INLINE") == "1":
+            # in line, in front of the moments kernel: a captured launch-bound step (see _step_front); as an experiment at
+            # N = 1e6 it measured 33.83 / 33.90 ms against 33.92 / 33.96 on the side stream -- no difference worth a second path
             epilogue_operands()
         elif self.overlap_fill and side is not None and Kzz.is_cuda:
             capturing = torch.cuda.is_current_stream_capturing()  # the side stream then joins the capture (fork / join by events)
@@ -706,10 +708,12 @@ class t_SVGP(base_SVGP):
         # measured 0.1-0.2 ms SLOWER per step, and again 36.61 vs 36.46 ms after the fill and the factorisation were reworked:
         # the factorisation and the moments kernel behind a later fill lose more than the two GEMMs gain.)
         pre = None
-        if self.overlap_fill and hasattr(eng, "start_fill"):
+        # (inside a capture of a launch-bound size the fork / join costs a replay more than the overlap gains: in line there)
+        fork = not (torch.cuda.is_current_stream_capturing() and X.shape[0] * self.num_inducing < self.GRAPH_FORK_MIN_NM)
+        if self.overlap_fill and fork and hasattr(eng, "start_fill"):
             pre = eng.start_fill(X, self._Z(), self.kernel, b_tag=warm_key,
                                  want="Kfu" if all(r == "direct" for r in routes) else "B", routes=routes)
-        ops = self._site_operands(whiten_jitter=jitter, warm_key=warm_key, routes=routes)
+        ops = self._site_operands(whiten_jitter=jitter, warm_key=warm_key, routes=routes, fork=fork)
         st = eng.run(X, Y, ops["Z"], self.kernel, moment_Tm=ops["moment_Tm"], prefill=pre,
                      moment_mode=ops["moment_mode"], gamma=ops["gamma"],
                      lik_id=self.likelihood.lik_id, lik_param=self.likelihood.lik_param,
@@ -838,6 +842,12 @@ class t_SVGP(base_SVGP):
 
     # -- hipGraph replay of the step (launch-bound problem sizes) -------------------------------------------------
     GRAPH_AUTO_MAX_NM = 200_000_000  # "auto": replay when N * M is at most this (tools/bench_graph_sizes.py, below)
+    # A captured step forks the K(X, Z) fill and the epilogue operands onto the side stream from this N * M on; below it they
+    # are captured in line: the cross-stream edges cost a replay 0.12-0.15 ms, more than the overlap gains at launch-bound
+    # sizes -- replayed step, forked / in line (gpurun_out/r3m/c1_routes.txt, graph_fork.txt, graph_fork_sizes.txt):
+    # N = 1000, M = 32: 0.46 / 0.31 ms; 5000 x 128: 0.44 / 0.38; 62 500 x 1024: 3.91 / 3.83; 125 000 x 1024: 5.96 / 5.97;
+    # 250 000 x 1024: 9.94 / 10.02.
+    GRAPH_FORK_MIN_NM = int(os.environ.get("TSVGP_GRAPH_FORK_MIN_NM", "100000000"))
 
     def _wants_graph(self, X) -> bool:
         """use_graph = True / False, or "auto" (the default): replay from a captured graph where that is faster.

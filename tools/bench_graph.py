@@ -8,7 +8,7 @@ import bench
 pkg = importlib.import_module("t-svgp_amd")
 SIZES = [("c1 (N=1000, M=32)", bench.WORKLOADS["c1"])] + [
     (f"N={n}, M={m}, D=8", dict(bench.WORKLOADS["ns"], N=n, M=m))
-    for n, m in ((2000, 64), (5000, 128), (20000, 128), (5000, 256), (20000, 256), (100000, 128), (50000, 512))]
+    for n, m in ((2000, 64), (5000, 128), (20000, 128), (5000, 256), (20000, 256), (100000, 128), (50000, 512), (20000, 1024), (62500, 1024))]
 for name, w in SIZES:
     X, Y, Z = bench.make_data(w)
     Xd, Yd = torch.as_tensor(X, device="cuda:0"), torch.as_tensor(Y, device="cuda:0")
