@@ -709,7 +709,8 @@ class t_SVGP(base_SVGP):
         # the factorisation and the moments kernel behind a later fill lose more than the two GEMMs gain.)
         pre = None
         # (inside a capture of a launch-bound size the fork / join costs a replay more than the overlap gains: in line there)
-        fork = not (torch.cuda.is_current_stream_capturing() and X.shape[0] * self.num_inducing < self.GRAPH_FORK_MIN_NM)
+        fork = not (self.device.type == "cuda" and torch.cuda.is_current_stream_capturing()
+                    and X.shape[0] * self.num_inducing < self.GRAPH_FORK_MIN_NM)
         if self.overlap_fill and fork and hasattr(eng, "start_fill"):
             pre = eng.start_fill(X, self._Z(), self.kernel, b_tag=warm_key,
                                  want="Kfu" if all(r == "direct" for r in routes) else "B", routes=routes)
