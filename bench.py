@@ -264,6 +264,37 @@ def elbo_match(model, w, X, Y, Z, budget_s, elbo_all_ranks=None):
                     "timed steps; rel = |hip - oracle| / |oracle|; tolerance stated in SURVEY 8(d): 1e-9 (fp64), 1e-4 (fp32)"}
 
 
+def elbo_match_white(model, w, X, Y, Z, rows=20000):
+    """ELBO match for `--model white`: the oracle's t_SVGP_white (reference src/models/tsvgp_white.py:23-246,
+    src/util.py:11-88) on the HIP model's (lambda_1, lambda_2), ELBO and predictive moments of a row prefix through both (the
+    minibatch scale num_data / rows applies on both sides)."""
+    import torch
+    from oracle import tsvgp_oracle as O
+
+    lik = O.Gaussian(variance=w.get("noise", 0.1)) if w["lik"] == "gaussian" else O.Bernoulli()
+    kernel, wrap = make_kernel(O, w)
+    ora = O.t_SVGP_white(kernel, lik, wrap(Z), num_latent_gps=w["P"], num_data=w["N"],
+                         lambda_1=model.lambda_1.numpy(), lambda_2=model.lambda_2.numpy())
+    rows = min(rows, w["N"])
+    t0 = time.perf_counter()
+    e_o = float(ora.elbo((X[:rows], Y[:rows])))
+    mu_o, var_o = ora.predict_f(X[:rows])
+    t_o = time.perf_counter() - t0
+    dev, dt = model.device, model.compute_dtype
+    dp_saved, model.data_parallel = model.data_parallel, False  # rank 0 alone: no collective
+    model._get_engine().release()
+    Xd, Yd = torch.as_tensor(X[:rows], dtype=dt).to(dev), torch.as_tensor(Y[:rows], dtype=dt).to(dev)
+    e_h = float(model.elbo((Xd, Yd)))
+    mu_h, var_h = model.predict_f(Xd)
+    model.data_parallel = dp_saved
+    rel = lambda a, b: float(np.max(np.abs(np.asarray(a.cpu() if hasattr(a, "cpu") else a) - b)) / np.max(np.abs(b)))
+    return {"hip": e_h, "hip_is": "one GPU", "oracle": e_o, "rel": abs(e_h - e_o) / abs(e_o), "rows": int(rows),
+            "full_N": bool(rows == w["N"]), "oracle_seconds": round(t_o, 1), "sample_rows": int(rows),
+            "sample_max_rel_err": {"mean": rel(mu_h, mu_o), "var": rel(var_h, var_o)},
+            "note": "oracle t_SVGP_white.elbo / predict_f (reference src/models/tsvgp_white.py, src/util.py:11-88 restated) on the "
+                    "HIP model's (lambda_1, lambda_2) after the timed steps, on a row prefix; rel = |hip - oracle| / |oracle|"}
+
+
 def self_launch(n_ranks: int) -> int:
     """`python bench.py --gpus N` without a launcher: runs `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
     --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>` as a child and returns its exit code."""
@@ -578,6 +609,8 @@ def main():
         with blas_threads():
             if not args.no_elbo_match and args.model == "tsvgp":
                 out["elbo_match"] = elbo_match(model, w, X, Y, Z, args.elbo_budget, elbo_all_ranks=elbo if world > 1 else None)
+            elif not args.no_elbo_match:
+                out["elbo_match"] = elbo_match_white(model, w, X, Y, Z)
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(w, args.cpu_budget, model_kind=args.model)
         out["elbo_vs_1gpu"] = elbo_vs_1gpu(args, w, elbo, steps_before_elbo)

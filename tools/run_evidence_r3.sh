@@ -23,7 +23,7 @@ fi
 if [ "$what" = pmc ] || [ "$what" = all ]; then
   bash tools/pmc_passes.sh $O/pmc > $O/pmc.log 2>&1
   python tools/pmc_summary.py $O/pmc > $O/pmc_summary.txt 2>&1 || true
-  python tools/make_hbm_traffic.py $O/pmc ns --source "profiles/r03_v1_ns_pmc_summary.txt" > $O/traffic.txt 2>&1 || true
+  python tools/make_hbm_traffic.py $O/pmc ns --source "profiles/r03_v2_ns_pmc_summary.txt" > $O/traffic.txt 2>&1 || true
   cp profiles/hbm_traffic.json $O/hbm_traffic.json
   find $O/pmc -name "*.csv" -size +5M -delete
 fi
