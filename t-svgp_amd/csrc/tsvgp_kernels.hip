@@ -980,7 +980,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void panel_kernel(PanelArgs<T> a) {
 // types.  fp64 moments: 0.90 of the MFMA peak where panel_kernel holds 0.83 on the same box
 // (profiles/r03_moments_lab_notes.txt; tools/panel_lab.hip is the bench it was developed in); alone at N = 1e6, M = 1024
 // (tools/kbench.py, old -> new): fp64 moments 17.4 -> 15.2 ms, fp64 trmm 18.3 -> 16.2, fp32 moments 8.28 -> 8.04, fp32 trmm
-// 8.6 -> 8.0.  The lower-form products (projected route) stay on panel_kernel.
+// 8.6 -> 8.0.  TRI selects the triangle: the upper form (tile it: chunks from its diagonal k-tile on) or the lower form (tile it:
+// the full k-tiles in front of the diagonal one, then that one, whose chunk j meets the column blocks from j on; projected route,
+// t_SVGP_white's whitened single-product variance): fp64 lower trmm 17.3 -> 16.2 ms, lower moments 17.0 -> 16.0.  The dense
+// products (M-step) stay on panel_kernel.
 //   * one wave per SIMD (__launch_bounds__(256, 1)): 512 registers per wave, so two fragment register sets, the accumulators
 //     and everything else live without a single scratch access (panel_kernel is pinned at 256 by its partner workgroup);
 //   * the chunk stream of a row panel runs through all column tiles without draining: every MFMA is followed by at most one
@@ -1040,7 +1043,7 @@ struct Frag1 {
 #define TSVGP_BC(x) std::integral_constant<bool, (x)>{}
 #define TSVGP_SB() __builtin_amdgcn_sched_barrier(0)
 
-template <typename T, int MODE = MODE_MOMENTS>
+template <typename T, int MODE = MODE_MOMENTS, int TRI = TSVGP_TRI_UPPER>
 __global__ __launch_bounds__(NTHREADS, 1) void panel1_kernel(PanelArgs<T> a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char panel_dyn_smem[];
     typedef typename P1Types<T>::frag_t frag_t;
@@ -1134,10 +1137,12 @@ __global__ __launch_bounds__(NTHREADS, 1) void panel1_kernel(PanelArgs<T> a) {
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(la), "v"(vo_), "s"(g) : "memory");
         };
         auto advance = [&](Cursor& cu) TSVGP_AI {  // saturates at the last chunk (a harmless re-fetch into a dead buffer)
-            if (cu.c + 1 == nchunk) {
+            // upper form: tile it takes the chunks CPT it .. nchunk - 1; lower form: 0 .. CPT (it + 1) - 1 (its diagonal k-tile last)
+            const int c_end = (TRI == TSVGP_TRI_UPPER) ? nchunk : (cu.it + 1) * CPT;
+            if (cu.c + 1 == c_end) {
                 if (cu.it + 1 < ntile) {
                     ++cu.it;
-                    cu.c = cu.it * CPT;
+                    cu.c = (TRI == TSVGP_TRI_UPPER) ? cu.it * CPT : 0;
                 }
             } else {
                 ++cu.c;
@@ -1157,19 +1162,24 @@ __global__ __launch_bounds__(NTHREADS, 1) void panel1_kernel(PanelArgs<T> a) {
             else f.v[E] = lds[offb[KS] + boff + (E - 2) * 256];
         };
         // slot S of a k-step's reads -> element of the set: T fragments first, the two A fragments last (see the header)
+        // (a chunk of mask popcount MM meets the column blocks N0 .. N0 + MM - 1: N0 = 0 in the upper form, 8 - MM in the lower)
         auto rds = [&](Frag& f, auto slot_tag, auto m_tag, auto ks_tag, const int boff) TSVGP_AI {
             constexpr int S = decltype(slot_tag)::value, MM = decltype(m_tag)::value;
-            if constexpr (S < MM) rd1(f, TSVGP_IC(2 + S), ks_tag, boff);
+            constexpr int N0 = (TRI == TSVGP_TRI_UPPER) ? 0 : 8 - MM;
+            if constexpr (S < MM) rd1(f, TSVGP_IC(2 + N0 + S), ks_tag, boff);
             else rd1(f, TSVGP_IC(S - MM), ks_tag, boff);
         };
         auto keep_set = [&](const Frag& f, auto m_tag) TSVGP_AI {  // the set's registers stay occupied up to this point
-            cfor<0, 2 + decltype(m_tag)::value>([&](auto e) TSVGP_AI {
-                const frag_t x = f.v[decltype(e)::value];
+            constexpr int MM = decltype(m_tag)::value, N0 = (TRI == TSVGP_TRI_UPPER) ? 0 : 8 - MM;
+            cfor<0, 2 + MM>([&](auto e) TSVGP_AI {
+                constexpr int E = decltype(e)::value;
+                const frag_t x = f.v[E < 2 ? E : E + N0];
                 asm volatile("" ::"v"(x));
             });
         };
-        auto mf = [&](const Frag& f, auto i_tag) TSVGP_AI {  // MFMA slot I of a k-step: column block I / 2, row block I % 2
-            constexpr int I = decltype(i_tag)::value, n = I >> 1, sblk = I & 1;
+        auto mf = [&](const Frag& f, auto i_tag, auto m_tag) TSVGP_AI {  // MFMA slot I of a k-step: column block N0 + I / 2, row block I % 2
+            constexpr int I = decltype(i_tag)::value, sblk = I & 1;
+            constexpr int n = ((TRI == TSVGP_TRI_UPPER) ? 0 : 8 - decltype(m_tag)::value) + (I >> 1);
             if constexpr (sizeof(T) == 8) {
                 acc[sblk][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.v[sblk], f.v[2 + n], acc[sblk][n], 0, 0, 0);
             } else {  // the two halves of the 8-byte fragments: two MFMAs of half the cycles
@@ -1193,7 +1203,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void panel1_kernel(PanelArgs<T> a) {
             constexpr int S0 = NR + (GC ? 5 : 0);
             cfor<0, (NM > S0 ? NM : S0)>([&](auto i) TSVGP_AI {
                 constexpr int I = decltype(i)::value;
-                if constexpr (I < NM) mf(fx, i);
+                if constexpr (I < NM) mf(fx, i, TSVGP_IC(m));
                 if constexpr (I < NR) rds(fy, i, TSVGP_IC(m), TSVGP_IC(1), B0);
                 else if constexpr (GC && I == NR) gg = *reinterpret_cast<const unit_t*>(gsm + c_this * KC + UE * glog);
                 else if constexpr (GC && I > NR && I < NR + 5) gx[I - NR - 1] = *reinterpret_cast<const unit_t*>(lds + B0 + (I - NR - 1) * 512 + t * 2);
@@ -1203,7 +1213,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void panel1_kernel(PanelArgs<T> a) {
             constexpr int S1 = NR + (GC ? 4 : 0);
             cfor<0, (NM > S1 ? NM : S1)>([&](auto i) TSVGP_AI {
                 constexpr int I = decltype(i)::value;
-                if constexpr (I < NM) mf(fy, i);
+                if constexpr (I < NM) mf(fy, i, TSVGP_IC(m));
                 if constexpr (I < NR) rds(fx, i, TSVGP_IC(m), TSVGP_IC(2), B0);
                 else if constexpr (GC && I < NR + 4) {
                     T dot = gx[I - NR][0] * gg[0];
@@ -1216,7 +1226,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void panel1_kernel(PanelArgs<T> a) {
             keep_set(fy, TSVGP_IC(m));
             cfor<0, (NM > NR ? NM : NR)>([&](auto i) TSVGP_AI {
                 constexpr int I = decltype(i)::value;
-                if constexpr (I < NM) mf(fx, i);
+                if constexpr (I < NM) mf(fx, i, TSVGP_IC(m));
                 if constexpr (I < NR) rds(fy, i, TSVGP_IC(m), TSVGP_IC(3), B0);
                 TSVGP_SB();
             });
@@ -1229,13 +1239,13 @@ __global__ __launch_bounds__(NTHREADS, 1) void panel1_kernel(PanelArgs<T> a) {
                 constexpr int S3 = 8 + NRN;
                 cfor<0, (NM > S3 ? NM : S3)>([&](auto i) TSVGP_AI {
                     constexpr int I = decltype(i)::value;
-                    if constexpr (I < NM) mf(fy, i);
+                    if constexpr (I < NM) mf(fy, i, TSVGP_IC(m));
                     if constexpr (I < 8) dma_piece(i, BUF);
                     else if constexpr (I < S3) rds(fx, TSVGP_IC(I - 8), TSVGP_IC(mn), TSVGP_IC(0), B1);
                     TSVGP_SB();
                 });
             } else {
-                cfor<0, NM>([&](auto i) TSVGP_AI { mf(fy, i); });
+                cfor<0, NM>([&](auto i) TSVGP_AI { mf(fy, i, TSVGP_IC(m)); });
             }
             keep_set(fy, TSVGP_IC(m));
         };
@@ -1249,7 +1259,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void panel1_kernel(PanelArgs<T> a) {
         advance(cf);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __syncthreads();  // both chunks and gamma are in LDS for every wave
-        cfor<0, 2 + BPC>([&](auto i) TSVGP_AI { rd1(fx, i, TSVGP_IC(0), 0); });  // a0, a1, b0 (fp32: and b1) of chunk (0, 0)
+        // a0, a1, b0 (fp32: and b1) of chunk (0, 0); lower form: tile 0 starts with its diagonal k-tile, all eight column blocks
+        cfor<0, (TRI == TSVGP_TRI_UPPER ? 2 + BPC : 10)>([&](auto i) TSVGP_AI { rd1(fx, i, TSVGP_IC(0), 0); });
 
         for (int it = 0; it < ntile; ++it) {
             const int cd = it * CPT;
@@ -1285,7 +1296,42 @@ __global__ __launch_bounds__(NTHREADS, 1) void panel1_kernel(PanelArgs<T> a) {
                 chunk(TSVGP_IC(0xFF), TSVGP_IC((1 << BPC) - 1), TSVGP_IC(1), gc, c_last);
             };
 #undef TSVGP_ZACC
-            if (MODE == MODE_MOMENTS && it == 0) {
+            // lower form: the full k-tiles 0 .. it - 1 first, then the diagonal one, whose chunk j meets the column blocks from
+            // BPC j on; all accumulators start the tile at zero; the mean rides on the LAST tile (its k-range is the whole panel)
+            auto lower_tile = [&](auto gc) TSVGP_AI {
+                cfor<0, 8>([&](auto n) TSVGP_AI {
+                    acc[0][decltype(n)::value] = acc_t{0, 0, 0, 0};
+                    acc[1][decltype(n)::value] = acc_t{0, 0, 0, 0};
+                });
+                for (int c = 0; c < cd; c += 2) {
+                    chunk(TSVGP_IC(0xFF), TSVGP_IC(0xFF), TSVGP_IC(0), gc, c);
+                    chunk(TSVGP_IC(0xFF), TSVGP_IC(0xFF), TSVGP_IC(1), gc, c + 1);
+                }
+                if constexpr (CPT == 8) {
+                    chunk(TSVGP_IC(0xFF), TSVGP_IC(0xFE), TSVGP_IC(0), gc, cd);
+                    chunk(TSVGP_IC(0xFE), TSVGP_IC(0xFC), TSVGP_IC(1), gc, cd + 1);
+                    chunk(TSVGP_IC(0xFC), TSVGP_IC(0xF8), TSVGP_IC(0), gc, cd + 2);
+                    chunk(TSVGP_IC(0xF8), TSVGP_IC(0xF0), TSVGP_IC(1), gc, cd + 3);
+                    chunk(TSVGP_IC(0xF0), TSVGP_IC(0xE0), TSVGP_IC(0), gc, cd + 4);
+                    chunk(TSVGP_IC(0xE0), TSVGP_IC(0xC0), TSVGP_IC(1), gc, cd + 5);
+                    chunk(TSVGP_IC(0xC0), TSVGP_IC(0x80), TSVGP_IC(0), gc, cd + 6);
+                    if (!last_tile) chunk(TSVGP_IC(0x80), TSVGP_IC(0xFF), TSVGP_IC(1), gc, cd + 7);
+                    else chunk(TSVGP_IC(0x80), TSVGP_IC(0), TSVGP_IC(1), gc, cd + 7);
+                } else {
+                    chunk(TSVGP_IC(0xFF), TSVGP_IC(0xFC), TSVGP_IC(0), gc, cd);
+                    chunk(TSVGP_IC(0xFC), TSVGP_IC(0xF0), TSVGP_IC(1), gc, cd + 1);
+                    chunk(TSVGP_IC(0xF0), TSVGP_IC(0xC0), TSVGP_IC(0), gc, cd + 2);
+                    if (!last_tile) chunk(TSVGP_IC(0xC0), TSVGP_IC(0xFF), TSVGP_IC(1), gc, cd + 3);
+                    else chunk(TSVGP_IC(0xC0), TSVGP_IC(0), TSVGP_IC(1), gc, cd + 3);
+                }
+            };
+            if constexpr (TRI == TSVGP_TRI_LOWER) {
+                if (MODE == MODE_MOMENTS && last_tile) {
+                    if constexpr (MODE == MODE_MOMENTS) lower_tile(TSVGP_BC(true));
+                } else {
+                    lower_tile(TSVGP_BC(false));
+                }
+            } else if (MODE == MODE_MOMENTS && it == 0) {
                 if constexpr (MODE == MODE_MOMENTS) {
                     diag(TSVGP_BC(true));
                     if (!last_tile) full(TSVGP_BC(true));
@@ -3370,6 +3416,14 @@ int trmm(const T* A, int64_t strideA, const T* Tm, int64_t strideT, T* C, int64_
     a.strideT = strideT;
     a.strideC = strideC;
     const dim3 grid((unsigned)(Np / TILE), (unsigned)batch), block(NTHREADS);
+#ifndef TSVGP_LOWER_OLD
+    if (mode == TSVGP_TRI_LOWER) {
+        static DynLdsOptIn optin1sl;
+        if (optin1sl.ensure(reinterpret_cast<const void*>(&panel1_kernel<T, MODE_STORE, TSVGP_TRI_LOWER>), 0) != TSVGP_OK)
+            return TSVGP_ELAUNCH;
+        hipLaunchKernelGGL((panel1_kernel<T, MODE_STORE, TSVGP_TRI_LOWER>), grid, block, 0, (hipStream_t)stream, a);
+    } else
+#endif
     if (mode == TSVGP_TRI_LOWER)
         hipLaunchKernelGGL((panel_kernel<T, MODE_STORE, TSVGP_TRI_LOWER>), grid, block, 0, (hipStream_t)stream, a);
 #ifndef TSVGP_TRMM_OLD  // (-DTSVGP_TRMM_OLD: A/B builds keep round 2's panel_kernel for the upper product)
@@ -3449,6 +3503,16 @@ int moments(const T* A, int64_t strideA, const T* Tm, const T* gamma, const T* Y
     const dim3 grid((unsigned)(Np / TILE)), block(NTHREADS);
     if (mean_only)
         hipLaunchKernelGGL((mean_lik_kernel<T>), grid, block, (size_t)Mp * P * sizeof(T), (hipStream_t)stream, a);
+#ifndef TSVGP_LOWER_OLD  // (-DTSVGP_LOWER_OLD: A/B builds keep round 2's panel_kernel for the lower-form products)
+    else if (mode == TSVGP_TRI_LOWER && (size_t)Mp * sizeof(T) <= P1_GAMMA_LDS_MAX) {
+        static DynLdsOptIn optin1l;
+        if (optin1l.ensure(reinterpret_cast<const void*>(&panel1_kernel<T, MODE_MOMENTS, TSVGP_TRI_LOWER>), P1_GAMMA_LDS_MAX) !=
+            TSVGP_OK)
+            return TSVGP_ELAUNCH;
+        hipLaunchKernelGGL((panel1_kernel<T, MODE_MOMENTS, TSVGP_TRI_LOWER>), grid, block, (size_t)Mp * sizeof(T),
+                           (hipStream_t)stream, a);
+    }
+#endif
     else if (mode == TSVGP_TRI_LOWER && (size_t)Mp * sizeof(T) <= 8192)
         hipLaunchKernelGGL((panel_kernel<T, MODE_MOMENTS, TSVGP_TRI_LOWER, true>), grid, block, (size_t)Mp * sizeof(T),
                            (hipStream_t)stream, a);

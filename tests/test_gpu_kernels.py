@@ -71,7 +71,7 @@ def test_se_fill_exp_is_the_library_exp_bit_for_bit(engines):
 
 @pytest.mark.parametrize("dtype,tol", DTYPES)
 @pytest.mark.parametrize("mode", [0, 1, 2])
-@pytest.mark.parametrize("Np,Mp", [(128, 128), (384, 256), (256, 640)])
+@pytest.mark.parametrize("Np,Mp", [(128, 128), (384, 256), (256, 640), (256, 1024)])
 def test_trmm(engines, dtype, tol, mode, Np, Mp):
     eng = engines[dtype]
     rng = np.random.RandomState(2)
@@ -193,7 +193,8 @@ def test_moments_mean_only(engines, dtype, tol, lik, N, M, P):
 
 @pytest.mark.parametrize("dtype,tol", DTYPES)
 @pytest.mark.parametrize("Np,Mp,P,nsplit", [(128, 128, 1, 1), (1024, 256, 2, 3), (640, 384, 1, 7), (4096, 128, 3, 64),
-                                            (1024, 1024, 1, 5), (640, 1024, 8, 3)])  # the benchmark's 36 lower tiles
+                                            (1024, 1024, 1, 5), (640, 1024, 8, 3),  # the benchmark's 36 lower tiles
+                                            (128, 256, 1, 8), (256, 128, 2, 5)])  # slices of one chunk, and empty ones
 def test_site_accum(engines, dtype, tol, Np, Mp, P, nsplit):
     eng = engines[dtype]
     B = pkg()._backend

@@ -57,6 +57,7 @@ timeit("trmm lower", lambda: eng.trmm(Kfu, Tl, Bw, B.TRI_LOWER), flops=N * M * (
 timeit("trmm upper", lambda: eng.trmm(Kfu, Tu[0], Bw, B.TRI_UPPER), flops=N * M * (M + 1))
 for lik, nm in ((0, "none"), (1, "gauss"), (2, "bern")):
     timeit(f"moments upper lik={nm}", lambda: B.check(eng._fn("tsvgp_moments")(Bw.data_ptr(), Tu.data_ptr(), gam.data_ptr(), Y.data_ptr(), 1e9, lik, 0.1, None, None, g0.data_ptr(), g1.data_ptr(), vep.data_ptr(), npp.data_ptr(), N, Np, Mp, P, B.TRI_UPPER, st), "m"), flops=N * M * (M + 1) * P)
+timeit("moments lower lik=gauss", lambda: B.check(eng._fn("tsvgp_moments")(Bw.data_ptr(), Tl.data_ptr(), gam.data_ptr(), Y.data_ptr(), 1e9, 1, 0.1, None, None, g0.data_ptr(), g1.data_ptr(), vep.data_ptr(), npp.data_ptr(), N, Np, Mp, 1, B.TRI_LOWER, st), "m"), flops=N * M * (M + 1))
 g1.uniform_(-1.0, -0.1); g0.normal_()
 for ns in [nsplit] + [int(x) for x in a.nsplits.split(",") if x]:
     work = torch.empty(int(eng._fn("tsvgp_site_accum_work_bytes")(Mp, P, ns)), dtype=torch.uint8, device="cuda:0")
