@@ -581,7 +581,10 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": w["dtype"],
             "data": "synthetic",
             "config": {"workload": w["name"], "N": w["N"], "M": w["M"], "D": w["D"], "P": w["P"],
-                       "likelihood": w["lik"], "rows_per_gpu": rows, "parallelism": f"N-sharded x{world}, 1 all-reduce/step",
+                       "likelihood": w["lik"], "rows_per_gpu": rows, "parallelism": (f"N-sharded x{world}, M x M work of the latents split over the ranks (all-gather of operands, "
+                                       f"reduce-scatter of the sums, all-gather of the state)"
+                                       if world > 1 and getattr(model, "_latent_split", None) is not None
+                                       and model._latent_split(model._routes(1e-9)) else f"N-sharded x{world}, 1 all-reduce/step"),
                        "e_step": "cold (K_uu, K_uf, Choleskys, whitening rebuilt every step; the projection-route decision "
                                  "is cached per (theta, Z, jitter): see route_gate_ms)", "lr": 0.8,
                        "projection": getattr(model, "projection", None), "routes": routes,
