@@ -608,7 +608,9 @@ class t_SVGP(base_SVGP):
             Kfu, g0, g1 = eng._buf["Kfu"], eng._buf["g0"], eng._buf["g1"]  # [Np, Mp], [Np, len(lat)] (rows >= N are zero)
             Ubuf = eng._get("U", tuple(Kfu.shape), Kfu.dtype)
             for c, p_ in enumerate(lat):
-                eng.trmm(Kfu, eng._pad_square(0.5 * (Q[p_] + Q[p_].T), Kfu.shape[1], "pad_Q"), Ubuf, B.TRI_DENSE)  # U = K_fu Q_p
+                # U = K_fu Q_p: a plain dense GEMM, so it goes to the BLAS library (rocBLAS DGEMM holds 0.95 of the fp64 MFMA
+                # peak at this shape, tools/dgemm_ref.py: 28.1 ms at N = 1e6, M = 1024 against 33.8 for tsvgp_trmm's dense mode)
+                torch.mm(Kfu, eng._pad_square(0.5 * (Q[p_] + Q[p_].T), Kfu.shape[1], "pad_Q"), out=Ubuf)
                 v, l, z = eng.kernel_grad(X, ops["Z"], kern, Ubuf, g0[:, c], g1[:, c], beta[:, p_])
                 dvar[ki] += v
                 dls[ki] += l
