@@ -507,7 +507,10 @@ def test_execution_options_do_not_change_the_step(lik):
     mk = lambda **kw: p.t_SVGP(p.SquaredExponential(1.0, 1.1), p.Gaussian(0.15) if lik == "gaussian" else p.Bernoulli(), Z,
                                num_data=3000, **kw)
     variants = {"plain": mk(overlap_fill=False), "overlap": mk(), "graph": mk(use_graph=True), "warm": mk(cache_whitened=True),
-                "whitened+overlap": mk(projection="whitened")}
+                "whitened+overlap": mk(projection="whitened"), "graph+fork": mk(use_graph=True),
+                "whitened+graph+fork": mk(projection="whitened", use_graph=True)}
+    for name in ("graph+fork", "whitened+graph+fork"):  # capture as a shard of N * M >= 1e8 is captured: fill forked inside
+        variants[name].GRAPH_FORK_MIN_NM = 0
     if lik == "gaussian":
         variants["skip"] = mk(skip_unused_variance=True)
         variants["skip+graph+warm-off"] = mk(skip_unused_variance=True, use_graph=True)

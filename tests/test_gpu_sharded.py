@@ -103,6 +103,7 @@ def _worker_graph(rank, world, port, out):
         X, Y, Z = synthetic(N=3001, M=64, D=4, lik="bernoulli", seed=10)
         Xs, Ys = p.distributed.shard_rows(X, Y)
         m = p.t_SVGP(p.SquaredExponential(1.0, 1.0), p.Bernoulli(), Z, num_data=3001, device="cuda:0", use_graph=True)
+        m.GRAPH_FORK_MIN_NM = 0  # fork the fill inside the capture, as a shard of N * M >= 1e8 does (one rank's share of 8)
         Xd, Yd = torch.as_tensor(Xs, device="cuda:0"), torch.as_tensor(Ys, device="cuda:0")
         for _ in range(5):  # eager, capture + replay, three more replays
             m.natgrad_step((Xd, Yd), lr=0.8)
@@ -159,8 +160,10 @@ def _worker_rccl(rank, world, port, out):
         X, Y, Z = synthetic(N=4001, M=160, D=4, lik="bernoulli", seed=12)
         Xd, Yd = torch.as_tensor(X, device="cuda:0"), torch.as_tensor(Y, device="cuda:0")
         res = {}
-        for tag, use_graph in (("eager", False), ("graph", True)):
+        for tag, use_graph in (("eager", False), ("graph", True), ("graphfork", True)):
             m = p.t_SVGP(p.SquaredExponential(1.0, 1.0), p.Bernoulli(), Z, num_data=4001, device="cuda:0", use_graph=use_graph)
+            if tag == "graphfork":  # the capture of a large shard: fill and epilogue operands forked onto the side stream
+                m.GRAPH_FORK_MIN_NM = 0
             assert m._reduce()
             n0 = calls["all_reduce"]
             for _ in range(5):  # graph: eager, capture + replay, three more replays
@@ -193,8 +196,9 @@ def test_rccl_single_rank_drives_the_collective_path(tmp_path):
     e = ora.elbo((X, Y))
     assert bool(got["captured"])
     assert int(got["eager_reduces"]) == 5 and int(got["graph_reduces"]) == 5  # one all-reduce per step, replayed or not
+    assert int(got["graphfork_reduces"]) == 5
     assert int(got["broadcasts"]) >= 1  # the route decision (cond(K_uu + jitter I)) came from rank 0
-    for tag in ("eager", "graph"):
+    for tag in ("eager", "graph", "graphfork"):
         assert relerr(got[tag + "_l1"], ora.lambda_1) < 1e-8
         assert relerr(got[tag + "_L2"], ora.lambda_2) < 1e-8
         assert abs(float(got[tag + "_elbo"]) - e) < 1e-9 * abs(e)
