@@ -1007,6 +1007,10 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 constexpr int P1_OPS = TILE * 16;    // 8-byte fragment units per operand image of a chunk (16 KB)
 constexpr int P1_BUFS = 2 * P1_OPS;  // fragment units per chunk buffer (A image + T image, 32 KB)
 constexpr size_t P1_GAMMA_LDS_MAX = 64 * 1024;  // dynamic LDS for gamma_p beside the 64 KB ring: Mp <= 8192 (fp32: 16384)
+constexpr size_t P1W_GAMMA_LDS_MAX = 32 * 1024;  // two tiles per pass: beside the 96 KB ring (Mp <= 4096 in fp64)
+#ifndef TSVGP_MOMENTS_WIDE  // (-DTSVGP_MOMENTS_WIDE=0: A/B builds keep one column tile per pass)
+#define TSVGP_MOMENTS_WIDE 0
+#endif
 #ifndef TSVGP_MOMENTS_OLD_F32  // (-DTSVGP_MOMENTS_OLD_F32=1: A/B builds keep round 2's panel_kernel for fp32)
 #define TSVGP_MOMENTS_OLD_F32 0
 #endif
@@ -1034,23 +1038,30 @@ struct P1Types<float> {
     typedef v2f frag_t;
     typedef v4f unit_t;
 };
-template <typename F>
+template <typename F, int NT = 8>
 struct Frag1 {
-    F v[10];  // v[0], v[1]: A fragments of the wave's two row blocks; v[2 + n]: T fragment of column block n
+    F v[2 + NT];  // v[0], v[1]: A fragments of the wave's two row blocks; v[2 + n]: T fragment of column block n
 };
 #define TSVGP_AI __attribute__((always_inline))
 #define TSVGP_IC(x) std::integral_constant<int, (x)>{}
 #define TSVGP_BC(x) std::integral_constant<bool, (x)>{}
 #define TSVGP_SB() __builtin_amdgcn_sched_barrier(0)
 
-template <typename T, int MODE = MODE_MOMENTS, int TRI = TSVGP_TRI_UPPER>
+// W2: column tiles per pass (1, or 2 for the upper-form moments at an even number of tiles): with two, the A fragments of a
+// k-step serve 32 MFMAs instead of 16, a barrier and a set of DMA issues come once per 128 MFMAs, and the row panel is swept
+// 2.5 instead of 4.5 times (M = 1024); the accumulators are then all 256 AGPRs of the wave (fp64).
+template <typename T, int MODE = MODE_MOMENTS, int TRI = TSVGP_TRI_UPPER, int W2 = 1>
 __global__ __launch_bounds__(NTHREADS, 1) void panel1_kernel(PanelArgs<T> a) {
+    static_assert(W2 == 1 || (W2 == 2 && MODE == MODE_MOMENTS && TRI == TSVGP_TRI_UPPER), "two tiles per pass: upper-form moments");
+    constexpr int NB = 8 * W2;                // column blocks of a pass
+    constexpr int BUFS = (1 + W2) * P1_OPS;   // fragment units per chunk buffer: the A image + W2 T images
+    constexpr int NDMA = 4 + 4 * W2;          // DMA pieces per wave and chunk
     extern __shared__ __attribute__((aligned(16))) unsigned char panel_dyn_smem[];
     typedef typename P1Types<T>::frag_t frag_t;
     typedef typename P1Types<T>::unit_t unit_t;
-    typedef Frag1<frag_t> Frag;
+    typedef Frag1<frag_t, NB> Frag;
     T* const gsm = reinterpret_cast<T*>(panel_dyn_smem);  // gamma_p, Mp elements
-    __shared__ __attribute__((aligned(1024))) frag_t lds[2 * P1_BUFS];
+    __shared__ __attribute__((aligned(1024))) frag_t lds[2 * BUFS];
     __shared__ double rowq[TILE];
     __shared__ double rowm[TILE];
     __shared__ double red[NTHREADS / 64];
@@ -1086,6 +1097,19 @@ __global__ __launch_bounds__(NTHREADS, 1) void panel1_kernel(PanelArgs<T> a) {
         offb[ks] = o + P1_OPS;
         offa0[ks] = o + w * 256;
         offa1[ks] = o + (7 - w) * 256;
+    }
+    // Two tiles per pass: the ring is 96 KB, beyond the 64 KB a ds_read's immediate offset reaches from one base.  Left to fold
+    // the buffer offset into every read, the compiler materialises one address register per (k-step, fragment) of the second
+    // buffer and spills; the second buffer therefore gets its own twelve bases, opaque to constant folding.
+    int offa0_1[4], offa1_1[4], offb_1[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        offa0_1[ks] = offa0[ks] + BUFS;
+        offa1_1[ks] = offa1[ks] + BUFS;
+        offb_1[ks] = offb[ks] + BUFS;
+        if constexpr (W2 == 2) {
+            asm volatile("" : "+v"(offa0_1[ks]), "+v"(offa1_1[ks]), "+v"(offb_1[ks]));
+        }
     }
     // mean (column tile 0): the thread reads the 16-byte unit t & 7 of rows 32 q + (t >> 3) of the landed A image; behind
     // that physical unit sits the logical unit glog (columns 2 glog, 2 glog + 1 of the chunk)
@@ -1127,10 +1151,12 @@ __global__ __launch_bounds__(NTHREADS, 1) void panel1_kernel(PanelArgs<T> a) {
             dma_vo = dvoff + (unsigned)(cu.c * KC * sizeof(T));
             tb_u = uni64(Tp + ((size_t)cu.it * TILE + 8 * w) * Mp);
         };
-        auto dma_piece = [&](auto i_tag, const int buf) TSVGP_AI {  // piece I of a chunk: I even -> A piece I / 2, I odd -> T piece
-            constexpr int I = decltype(i_tag)::value, q = I >> 1;
-            const unsigned la = lds_u + (unsigned)((buf * P1_BUFS + q * 512 + (I & 1) * P1_OPS) * sizeof(frag_t));
-            const uint64_t g = ((I & 1) ? tb_u : ab_u) + q * grp;
+        // piece I of a chunk: I < 8: I even -> A piece I / 2, I odd -> piece I / 2 of the first T image; I >= 8: piece I - 8 of the second
+        auto dma_piece = [&](auto i_tag, const int buf) TSVGP_AI {
+            constexpr int I = decltype(i_tag)::value, q = I < 8 ? (I >> 1) : I - 8;
+            constexpr int IMG = I < 8 ? (I & 1) : 2;  // 0: A, 1: T of the pass's first tile, 2: T of its second tile
+            const unsigned la = lds_u + (unsigned)((buf * BUFS + q * 512 + IMG * P1_OPS) * sizeof(frag_t));
+            const uint64_t g = (IMG == 0 ? ab_u : tb_u + (IMG == 2 ? 4 * grp : 0)) + q * grp;
             const unsigned vo_ = dma_vo;  // (an asm operand alone does not capture a variable in a generic lambda)
             // one wait state between the write of M0 and the LDS-DMA that reads it.  (Fetching only the T pieces a diagonal chunk
             // reads -- the others issued with EXEC = 0 -- was 1.7 % SLOWER at M = 1024 and 512: profiles/r03_moments_lab_notes.txt)
@@ -1140,8 +1166,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void panel1_kernel(PanelArgs<T> a) {
             // upper form: tile it takes the chunks CPT it .. nchunk - 1; lower form: 0 .. CPT (it + 1) - 1 (its diagonal k-tile last)
             const int c_end = (TRI == TSVGP_TRI_UPPER) ? nchunk : (cu.it + 1) * CPT;
             if (cu.c + 1 == c_end) {
-                if (cu.it + 1 < ntile) {
-                    ++cu.it;
+                if (cu.it + W2 < ntile) {
+                    cu.it += W2;
                     cu.c = (TRI == TSVGP_TRI_UPPER) ? cu.it * CPT : 0;
                 }
             } else {
@@ -1149,21 +1175,28 @@ __global__ __launch_bounds__(NTHREADS, 1) void panel1_kernel(PanelArgs<T> a) {
             }
         };
 
-        acc_t acc[2][8];
+        acc_t acc[2][NB];
         Frag fx, fy;
         double rs_mine = 0.0;
         T mpart[4] = {0, 0, 0, 0};
         unit_t gx[4], gg;  // the mean's operands in flight (column tile 0)
 
-        auto rd1 = [&](Frag& f, auto e_tag, auto ks_tag, const int boff) TSVGP_AI {
-            constexpr int E = decltype(e_tag)::value, KS = decltype(ks_tag)::value;
-            if constexpr (E == 0) f.v[0] = lds[offa0[KS] + boff];
-            else if constexpr (E == 1) f.v[1] = lds[offa1[KS] + boff];
-            else f.v[E] = lds[offb[KS] + boff + (E - 2) * 256];
+        auto rd1 = [&](Frag& f, auto e_tag, auto ks_tag, auto buf_tag) TSVGP_AI {
+            constexpr int E = decltype(e_tag)::value, KS = decltype(ks_tag)::value, BI = decltype(buf_tag)::value;
+            if constexpr (W2 == 2 && BI == 1) {
+                if constexpr (E == 0) f.v[0] = lds[offa0_1[KS]];
+                else if constexpr (E == 1) f.v[1] = lds[offa1_1[KS]];
+                else f.v[E] = lds[offb_1[KS] + ((E - 2) >> 3) * P1_OPS + ((E - 2) & 7) * 256];
+            } else {
+                constexpr int boff = BI * BUFS;
+                if constexpr (E == 0) f.v[0] = lds[offa0[KS] + boff];
+                else if constexpr (E == 1) f.v[1] = lds[offa1[KS] + boff];
+                else f.v[E] = lds[offb[KS] + boff + ((E - 2) >> 3) * P1_OPS + ((E - 2) & 7) * 256];
+            }
         };
         // slot S of a k-step's reads -> element of the set: T fragments first, the two A fragments last (see the header)
         // (a chunk of mask popcount MM meets the column blocks N0 .. N0 + MM - 1: N0 = 0 in the upper form, 8 - MM in the lower)
-        auto rds = [&](Frag& f, auto slot_tag, auto m_tag, auto ks_tag, const int boff) TSVGP_AI {
+        auto rds = [&](Frag& f, auto slot_tag, auto m_tag, auto ks_tag, auto boff) TSVGP_AI {
             constexpr int S = decltype(slot_tag)::value, MM = decltype(m_tag)::value;
             constexpr int N0 = (TRI == TSVGP_TRI_UPPER) ? 0 : 8 - MM;
             if constexpr (S < MM) rd1(f, TSVGP_IC(2 + N0 + S), ks_tag, boff);
@@ -1193,8 +1226,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void panel1_kernel(PanelArgs<T> a) {
         auto chunk = [&](auto m_tag, auto mn_tag, auto buf_tag, auto gc_tag, const int c_this) TSVGP_AI {
             constexpr int M = decltype(m_tag)::value, MN = decltype(mn_tag)::value, BUF = decltype(buf_tag)::value;
             constexpr bool GC = decltype(gc_tag)::value;
-            constexpr int m = popc8(M), mn = popc8(MN), NM = 2 * m, NR = 2 + m, NRN = 2 + mn;
-            constexpr int B0 = BUF * P1_BUFS, B1 = (BUF ^ 1) * P1_BUFS;
+            constexpr int m = popc8(M & 0xFF) + popc8(M >> 8), mn = popc8(MN & 0xFF) + popc8(MN >> 8), NM = 2 * m, NR = 2 + m, NRN = 2 + mn;
+            constexpr int B0 = BUF * BUFS, B1 = (BUF ^ 1) * BUFS;
             if constexpr (MN != 0) {  // the DMA addresses of chunk c + 2: scalar work in front of the first MFMAs
                 dma_setup(cf);
                 advance(cf);
@@ -1204,7 +1237,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void panel1_kernel(PanelArgs<T> a) {
             cfor<0, (NM > S0 ? NM : S0)>([&](auto i) TSVGP_AI {
                 constexpr int I = decltype(i)::value;
                 if constexpr (I < NM) mf(fx, i, TSVGP_IC(m));
-                if constexpr (I < NR) rds(fy, i, TSVGP_IC(m), TSVGP_IC(1), B0);
+                if constexpr (I < NR) rds(fy, i, TSVGP_IC(m), TSVGP_IC(1), TSVGP_IC(BUF));
                 else if constexpr (GC && I == NR) gg = *reinterpret_cast<const unit_t*>(gsm + c_this * KC + UE * glog);
                 else if constexpr (GC && I > NR && I < NR + 5) gx[I - NR - 1] = *reinterpret_cast<const unit_t*>(lds + B0 + (I - NR - 1) * 512 + t * 2);
                 TSVGP_SB();
@@ -1214,7 +1247,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void panel1_kernel(PanelArgs<T> a) {
             cfor<0, (NM > S1 ? NM : S1)>([&](auto i) TSVGP_AI {
                 constexpr int I = decltype(i)::value;
                 if constexpr (I < NM) mf(fy, i, TSVGP_IC(m));
-                if constexpr (I < NR) rds(fx, i, TSVGP_IC(m), TSVGP_IC(2), B0);
+                if constexpr (I < NR) rds(fx, i, TSVGP_IC(m), TSVGP_IC(2), TSVGP_IC(BUF));
                 else if constexpr (GC && I < NR + 4) {
                     T dot = gx[I - NR][0] * gg[0];
 #pragma unroll
@@ -1227,7 +1260,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void panel1_kernel(PanelArgs<T> a) {
             cfor<0, (NM > NR ? NM : NR)>([&](auto i) TSVGP_AI {
                 constexpr int I = decltype(i)::value;
                 if constexpr (I < NM) mf(fx, i, TSVGP_IC(m));
-                if constexpr (I < NR) rds(fy, i, TSVGP_IC(m), TSVGP_IC(3), B0);
+                if constexpr (I < NR) rds(fy, i, TSVGP_IC(m), TSVGP_IC(3), TSVGP_IC(BUF));
                 TSVGP_SB();
             });
             keep_set(fx, TSVGP_IC(m));
@@ -1236,12 +1269,12 @@ __global__ __launch_bounds__(NTHREADS, 1) void panel1_kernel(PanelArgs<T> a) {
             asm volatile("" ::: "memory");
             TSVGP_SB();
             if constexpr (MN != 0) {
-                constexpr int S3 = 8 + NRN;
+                constexpr int S3 = NDMA + NRN;
                 cfor<0, (NM > S3 ? NM : S3)>([&](auto i) TSVGP_AI {
                     constexpr int I = decltype(i)::value;
                     if constexpr (I < NM) mf(fy, i, TSVGP_IC(m));
-                    if constexpr (I < 8) dma_piece(i, BUF);
-                    else if constexpr (I < S3) rds(fx, TSVGP_IC(I - 8), TSVGP_IC(mn), TSVGP_IC(0), B1);
+                    if constexpr (I < NDMA) dma_piece(i, BUF);
+                    else if constexpr (I < S3) rds(fx, TSVGP_IC(I - NDMA), TSVGP_IC(mn), TSVGP_IC(0), TSVGP_IC(BUF ^ 1));
                     TSVGP_SB();
                 });
             } else {
@@ -1252,19 +1285,19 @@ __global__ __launch_bounds__(NTHREADS, 1) void panel1_kernel(PanelArgs<T> a) {
 
         // prologue: chunks (0, 0) and (0, 1) on their way into the two buffers, the first fragments read
         dma_setup(cf);
-        cfor<0, 8>([&](auto i) TSVGP_AI { dma_piece(i, 0); });
+        cfor<0, NDMA>([&](auto i) TSVGP_AI { dma_piece(i, 0); });
         advance(cf);
         dma_setup(cf);
-        cfor<0, 8>([&](auto i) TSVGP_AI { dma_piece(i, 1); });
+        cfor<0, NDMA>([&](auto i) TSVGP_AI { dma_piece(i, 1); });
         advance(cf);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __syncthreads();  // both chunks and gamma are in LDS for every wave
         // a0, a1, b0 (fp32: and b1) of chunk (0, 0); lower form: tile 0 starts with its diagonal k-tile, all eight column blocks
-        cfor<0, (TRI == TSVGP_TRI_UPPER ? 2 + BPC : 10)>([&](auto i) TSVGP_AI { rd1(fx, i, TSVGP_IC(0), 0); });
+        cfor<0, (TRI == TSVGP_TRI_UPPER ? 2 + BPC : 10)>([&](auto i) TSVGP_AI { rd1(fx, i, TSVGP_IC(0), TSVGP_IC(0)); });
 
-        for (int it = 0; it < ntile; ++it) {
+        for (int it = 0; it < ntile; it += W2) {
             const int cd = it * CPT;
-            const bool last_tile = it + 1 == ntile;
+            const bool last_tile = it + W2 == ntile;
             // an accumulator is zeroed in front of the diagonal chunk that first touches its column block
 #define TSVGP_ZACC(n_) { acc[0][n_] = acc_t{0, 0, 0, 0}; acc[1][n_] = acc_t{0, 0, 0, 0}; }
             auto diag = [&](auto gc) TSVGP_AI {
@@ -1325,7 +1358,46 @@ __global__ __launch_bounds__(NTHREADS, 1) void panel1_kernel(PanelArgs<T> a) {
                     else chunk(TSVGP_IC(0xC0), TSVGP_IC(0), TSVGP_IC(1), gc, cd + 3);
                 }
             };
-            if constexpr (TRI == TSVGP_TRI_LOWER) {
+            // two tiles per pass (upper form): the diagonal k-tile of the first tile (its column blocks one by one), then the
+            // diagonal k-tile of the second one under the full first tile, then the full k-tiles behind both
+            auto wide_pass = [&](auto gc) TSVGP_AI {
+                cfor<0, CPT>([&](auto j) TSVGP_AI {  // region A: chunk j adds the column blocks BPC j .. of the first tile
+                    constexpr int J = decltype(j)::value;
+                    constexpr int M_ = (1 << (BPC * (J + 1))) - 1;
+                    constexpr int MN_ = J + 1 < CPT ? (1 << (BPC * (J + 2))) - 1 : (0xFF | (((1 << BPC) - 1) << 8));
+                    cfor<0, BPC>([&](auto q) TSVGP_AI {
+                        acc[0][BPC * J + decltype(q)::value] = acc_t{0, 0, 0, 0};
+                        acc[1][BPC * J + decltype(q)::value] = acc_t{0, 0, 0, 0};
+                    });
+                    chunk(TSVGP_IC(M_), TSVGP_IC(MN_), TSVGP_IC(J & 1), gc, cd + J);
+                });
+                cfor<0, CPT>([&](auto j) TSVGP_AI {  // region B: the first tile in full, the second one block by block
+                    constexpr int J = decltype(j)::value;
+                    constexpr int M_ = 0xFF | (((1 << (BPC * (J + 1))) - 1) << 8);
+                    constexpr int MN_ = J + 1 < CPT ? (0xFF | (((1 << (BPC * (J + 2))) - 1) << 8)) : 0xFFFF;
+                    cfor<0, BPC>([&](auto q) TSVGP_AI {
+                        acc[0][8 + BPC * J + decltype(q)::value] = acc_t{0, 0, 0, 0};
+                        acc[1][8 + BPC * J + decltype(q)::value] = acc_t{0, 0, 0, 0};
+                    });
+                    // (no separate variant for the end of the stream: the last chunk of the last pass fetches the saturated cursor
+                    // into a dead buffer and pre-reads fragments nobody uses -- one straight line instead of a branch with 256
+                    // live accumulators on both sides of its join)
+                    chunk(TSVGP_IC(M_), TSVGP_IC(MN_), TSVGP_IC(J & 1), gc, cd + CPT + J);
+                });
+                if (!last_tile) {
+                    const int c_last = nchunk - 1;
+                    for (int c = cd + 2 * CPT; c < c_last - 1; c += 2) {
+                        chunk(TSVGP_IC(0xFFFF), TSVGP_IC(0xFFFF), TSVGP_IC(0), gc, c);
+                        chunk(TSVGP_IC(0xFFFF), TSVGP_IC(0xFFFF), TSVGP_IC(1), gc, c + 1);
+                    }
+                    chunk(TSVGP_IC(0xFFFF), TSVGP_IC(0xFFFF), TSVGP_IC(0), gc, c_last - 1);
+                    chunk(TSVGP_IC(0xFFFF), TSVGP_IC((1 << BPC) - 1), TSVGP_IC(1), gc, c_last);
+                }
+            };
+            if constexpr (W2 == 2) {
+                if (it == 0) wide_pass(TSVGP_BC(true));
+                else wide_pass(TSVGP_BC(false));
+            } else if constexpr (TRI == TSVGP_TRI_LOWER) {
                 if (MODE == MODE_MOMENTS && last_tile) {
                     if constexpr (MODE == MODE_MOMENTS) lower_tile(TSVGP_BC(true));
                 } else {
@@ -1362,7 +1434,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void panel1_kernel(PanelArgs<T> a) {
                 for (int r = 0; r < 4; ++r) {
                     double q = 0.0;
 #pragma unroll
-                    for (int n = 0; n < 8; ++n) {
+                    for (int n = 0; n < NB; ++n) {
                         const double v = (double)acc[s][n][r];
                         q += v * v;
                     }
@@ -3519,6 +3591,18 @@ int moments(const T* A, int64_t strideA, const T* Tm, const T* gamma, const T* Y
     else if (mode == TSVGP_TRI_LOWER)
         hipLaunchKernelGGL((panel_kernel<T, MODE_MOMENTS, TSVGP_TRI_LOWER>), grid, block, 0, (hipStream_t)stream, a);
 #ifndef TSVGP_MOMENTS_OLD  // (-DTSVGP_MOMENTS_OLD: A/B builds keep round 2's panel_kernel on this path)
+#if TSVGP_MOMENTS_WIDE
+    else if (mode == TSVGP_TRI_UPPER && (sizeof(T) == 8 || !TSVGP_MOMENTS_OLD_F32) && (Mp % (2 * TILE)) == 0 &&
+             (size_t)Mp * sizeof(T) <= P1W_GAMMA_LDS_MAX) {
+        // upper form, an even number of column tiles: two tiles per pass
+        static DynLdsOptIn optin1w;
+        if (optin1w.ensure(reinterpret_cast<const void*>(&panel1_kernel<T, MODE_MOMENTS, TSVGP_TRI_UPPER, 2>), P1W_GAMMA_LDS_MAX) !=
+            TSVGP_OK)
+            return TSVGP_ELAUNCH;
+        hipLaunchKernelGGL((panel1_kernel<T, MODE_MOMENTS, TSVGP_TRI_UPPER, 2>), grid, block, (size_t)Mp * sizeof(T),
+                           (hipStream_t)stream, a);
+    }
+#endif
     else if (mode == TSVGP_TRI_UPPER && (sizeof(T) == 8 || !TSVGP_MOMENTS_OLD_F32) && (size_t)Mp * sizeof(T) <= P1_GAMMA_LDS_MAX) {
         // upper form: one workgroup per CU with the hand-laid instruction stream (panel1_kernel)
         static DynLdsOptIn optin1;
