@@ -52,6 +52,32 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
 
+def site_sum_slices(Mp: int, P: int, Np, slots: int, f64: bool, oversubscribe=None) -> int:
+    """The slice count of ``EStepEngine.choose_nsplit`` as a pure function of the shape and of the resident workgroup slots
+    (256 for fp64, 512 for fp32 on MI355X): see there for the cost model and the measurements behind it."""
+    nt = Mp // B.TILE
+    n_off = nt * (nt - 1) // 2
+    num = 20 if f64 else 22  # TSVGP_SYRK1_DIAG_NUM / TSVGP_SYRK1F_DIAG_NUM
+    ns_diag = lambda ns: max(1, (num * ns + 31) // 32)
+    if Np is None or oversubscribe is not None:
+        # (no row count, or a forced oversubscription: the largest count that fits one round, times the factor)
+        ns = 1
+        while P * (n_off * (ns + 1) + nt * ns_diag(ns + 1)) <= slots:
+            ns += 1
+        return ns * (oversubscribe if oversubscribe is not None else 8)
+    chunks = max(1, Np // (16 if f64 else 32))  # the kernels' chunks: 16 rows (fp64) / 32 rows (fp32)
+    overhead = 14.0
+    best, best_t = 1, None
+    for ns in range(1, max(1, min(chunks // 32, 1024)) + 1):
+        nd = ns_diag(ns)
+        rounds = -(-(P * (n_off * ns + nt * nd)) // slots)
+        per = max(-(-chunks // ns) if n_off else 0, -(-chunks // nd) * num / 32.0)
+        t = rounds * (per + overhead) * (1.02 if rounds == 1 else 1.0)
+        if best_t is None or t < best_t * (1.0 - 1e-9):
+            best, best_t = ns, t
+    return best
+
+
 class EStepEngine:
     """Launches the C-ABI kernels (include/tsvgp_hip.h) on torch-allocated device memory."""
 
@@ -151,29 +177,7 @@ class EStepEngine:
         56 (7.2 rounds): 17.0; M = 1024 fp32: 61 slices 7.65 ms, 120: 7.99; M = 512 fp64: 120 slices 4.15 ms, 651: 4.72.
         A launch of exactly one round is charged 2 % more (nothing evens out the diagonal against the off-diagonal tiles:
         M = 512, 29 slices = one round 4.33 ms against 4.20 for two)."""
-        nt = Mp // B.TILE
-        n_off = nt * (nt - 1) // 2
-        slots = self.slots()
-        f64 = self.dtype == torch.float64
-        num = 20 if f64 else 22  # TSVGP_SYRK1_DIAG_NUM / TSVGP_SYRK1F_DIAG_NUM
-        ns_diag = lambda ns: max(1, (num * ns + 31) // 32)
-        if Np is None or self.syrk_oversubscribe is not None:
-            # (no row count, or a forced oversubscription: the largest count that fits one round, times the factor)
-            ns = 1
-            while P * (n_off * (ns + 1) + nt * ns_diag(ns + 1)) <= slots:
-                ns += 1
-            return ns * (self.syrk_oversubscribe if self.syrk_oversubscribe is not None else 8)
-        chunks = max(1, Np // (16 if f64 else 32))  # the kernels' chunks: 16 rows (fp64) / 32 rows (fp32)
-        overhead = 14.0
-        best, best_t = 1, None
-        for ns in range(1, max(1, min(chunks // 32, 1024)) + 1):
-            nd = ns_diag(ns)
-            rounds = -(-(P * (n_off * ns + nt * nd)) // slots)
-            per = max(-(-chunks // ns) if n_off else 0, -(-chunks // nd) * num / 32.0)
-            t = rounds * (per + overhead) * (1.02 if rounds == 1 else 1.0)
-            if best_t is None or t < best_t * (1.0 - 1e-9):
-                best, best_t = ns, t
-        return best
+        return site_sum_slices(Mp, P, Np, self.slots(), self.dtype == torch.float64, self.syrk_oversubscribe)
 
     def _pad_square(self, A: torch.Tensor, Mp: int, key: str = None) -> torch.Tensor:
         """[.., M, M] fp64 -> zero-padded contiguous [.., Mp, Mp] in the compute dtype (a cached buffer per key)."""

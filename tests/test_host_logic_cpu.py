@@ -320,3 +320,27 @@ def test_cholesky_workgroup_fits_beside_the_fill():
     assert diag and fill, "kernel names not found in the compiler remarks"
     assert max(diag) <= 112, f"potrf_diag_kernel uses {max(diag)} VGPRs"
     assert max(fill) <= 96, f"se_fill_kernel<double, SE, 8> uses {max(fill)} VGPRs"
+
+
+def test_site_sum_slices_fill_whole_rounds():
+    """EStepEngine.choose_nsplit's rule as a pure function: the launch of the site sums runs in rounds of `slots` equal workgroups
+    (n_off * ns + nt * ns_diag(ns) per latent), so the chosen count leaves the last round (nearly) full and prefers few rounds;
+    the measured optima of round 3 (profiles/r03_second_half_kernel_ab.txt) are what it returns."""
+    import importlib
+
+    slices = importlib.import_module("t-svgp_amd.estep").site_sum_slices
+    nd = lambda ns, num: max(1, (num * ns + 31) // 32)  # syrk_ns_diag of the kernel source
+    for Mp, P, Np, slots, f64 in [(1024, 1, 1000064, 256, True), (512, 1, 1000064, 256, True), (1024, 1, 125056, 256, True),
+                                  (1024, 1, 1000064, 512, False), (1024, 8, 1000064, 256, True), (768, 1, 1000064, 256, True),
+                                  (2048, 1, 250112, 256, True), (256, 1, 1000064, 256, True)]:
+        ns = slices(Mp, P, Np, slots, f64)
+        nt = Mp // 128
+        wgs = P * (nt * (nt - 1) // 2 * ns + nt * nd(ns, 20 if f64 else 22))
+        rounds = -(-wgs // slots)
+        assert ns >= 1 and wgs / (rounds * slots) > 0.9, (Mp, P, Np, ns, wgs)  # the last round is not left half empty
+        assert Np // (16 if f64 else 32) // ns >= 32  # slices stay long against the per-workgroup overhead
+    assert slices(1024, 1, 1000064, 256, True) == 62  # 2048 workgroups = 8 rounds exactly (15.19 ms; 224 slices: 15.62)
+    assert slices(1024, 1, 1000064, 512, False) == 61  # fp32, two workgroups per CU (7.65 ms; 120 slices: 7.99)
+    assert slices(512, 1, 1000064, 256, True) in (60, 120)  # 512 / 1020 workgroups (4.19 / 4.15 ms; 651 slices: 4.72)
+    assert slices(128, 1, 1024, 256, True) >= 1 and slices(128, 1, 128, 256, True) == 1  # tiny problems: at least one slice
+    assert slices(1024, 1, None, 256, True) == 7 * 8 and slices(1024, 1, 1000064, 256, True, oversubscribe=4) == 28
