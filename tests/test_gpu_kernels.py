@@ -96,7 +96,8 @@ def _moments_ref(A, Tm, gamma, kdiag):
 @pytest.mark.parametrize("dtype,tol", DTYPES)
 @pytest.mark.parametrize("lik", ["none", "gaussian", "bernoulli"])
 @pytest.mark.parametrize("N,M,P,mode", [(100, 128, 1, 2), (300, 256, 2, 1), (129, 384, 3, 1),
-                                        (600, 1024, 1, 1), (300, 1024, 8, 1)])  # the last two: the benchmark's 8 x 8 tile grid
+                                        (600, 1024, 1, 1), (300, 1024, 8, 1),  # these two: the benchmark's 8 x 8 tile grid
+                                        (300, 256, 2, 0), (129, 384, 3, 0), (600, 1024, 1, 0)])  # the lower form
 def test_moments_and_likelihood_map(engines, dtype, tol, lik, N, M, P, mode):
     eng = engines[dtype]
     B = pkg()._backend
@@ -107,6 +108,8 @@ def test_moments_and_likelihood_map(engines, dtype, tol, lik, N, M, P, mode):
     Tm = rng.randn(P, M, M) * 0.5
     if mode == 1:
         Tm = np.triu(Tm)
+    elif mode == 0:
+        Tm = np.tril(Tm)
     gamma = rng.randn(M, P)
     kdiag = 2.5
     Y = (rng.rand(N, P) > 0.5).astype(float) if lik == "bernoulli" else rng.randn(N, P)
