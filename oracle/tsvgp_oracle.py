@@ -40,7 +40,8 @@ and ``tests/test_utils.py:44-137`` (site conditionals, Woodbury, site KL), plus
 an independent autodiff natural-gradient SVGP for the Bernoulli case
 (the shape of ``tests/models/test_tsvgp.py:123-131``).  Because the Bernoulli
 comparison model is our own restatement of GPflow's SVGP + NaturalGradient and
-not GPflow itself, parity of the non-conjugate site update against the real
+not GPflow itself, and the reference holds no golden vectors: **parity unpinned**
+by the rule -- parity of the non-conjugate site update against the real
 reference is **unpinned beyond those checks**.
 
 Also restated here, with the same status: ``t_SVGP_white``
