@@ -205,7 +205,10 @@ int tsvgp_moments_batched_f32(const float *A, int64_t strideA, const float *Tm, 
  *        acc1[p][i]    = sum_n g0[n,p] * B[n,i]                 ([P x Mp], fp64)
  *     B [Np x Mp]; g0,g1 [Np x P] with rows >= N equal to 0.
  *     The N range is cut into `nsplit` slices; partial tiles go to `work` and are summed in a fixed order (bitwise
- *     reproducible; no atomics).  work must hold tsvgp_site_accum_work_bytes_*(Mp, P, nsplit) bytes. */
+ *     reproducible; no atomics).  work must hold tsvgp_site_accum_work_bytes_*(Mp, P, nsplit) bytes.  Any nsplit >= 1 is
+ *     valid; the launch runs in rounds of tsvgp_site_accum_slots_*() equal workgroups (per latent: n_off * nsplit off-diagonal
+ *     + nt * ceil(20 nsplit / 32) diagonal ones, 22 / 32 in fp32), so a count that fills whole rounds is the fast one
+ *     (N = 1e6, M = 1024, fp64: 62 slices = 2048 workgroups = 8 rounds of 256; the Python mirror's EStepEngine.choose_nsplit). */
 int64_t tsvgp_site_accum_work_bytes_f64(int Mp, int P, int nsplit);
 int64_t tsvgp_site_accum_work_bytes_f32(int Mp, int P, int nsplit);
 int tsvgp_site_accum_f64(const double *B, const double *g0, const double *g1, double *acc2, double *acc1, void *work,
