@@ -203,10 +203,12 @@ int tsvgp_moments_batched_f32(const float *A, int64_t strideA, const float *Tm, 
 /* (5) Site accumulation (the two einsums of reference src/models/tsvgp.py:278-281 in whitened coordinates):
  *        acc2[p][i][j] = sum_n g1[n,p] * B[n,i] * B[n,j]        (full symmetric [P x Mp x Mp], fp64)
  *        acc1[p][i]    = sum_n g0[n,p] * B[n,i]                 ([P x Mp], fp64)
- *     B [Np x Mp]; g0,g1 [Np x P] with rows >= N equal to 0.
+ *     B [Np x Mp]; g0,g1 contiguous [Np x P] with rows >= N equal to 0.  B, g0, g1 and work on 16-byte boundaries (operand
+ *     rows and the 16 P weights of a chunk travel as 16-byte LDS-DMA pieces; TSVGP_EINVAL otherwise).
  *     The N range is cut into `nsplit` slices; partial tiles go to `work` and are summed in a fixed order (bitwise
  *     reproducible; no atomics).  work must hold tsvgp_site_accum_work_bytes_*(Mp, P, nsplit) bytes.  Any nsplit >= 1 is
- *     valid; the launch runs in rounds of tsvgp_site_accum_slots_*() equal workgroups (per latent: n_off * nsplit off-diagonal
+ *     valid (a slice is a whole number of chunks -- 16 rows in fp64, 32 in fp32 with P <= 8 -- so a count above Np / chunk
+ *     leaves workgroups with empty slices: correct, wasted); the launch runs in rounds of tsvgp_site_accum_slots_*() equal workgroups (per latent: n_off * nsplit off-diagonal
  *     + nt * ceil(20 nsplit / 32) diagonal ones, 22 / 32 in fp32), so a count that fills whole rounds is the fast one
  *     (N = 1e6, M = 1024, fp64: 62 slices = 2048 workgroups = 8 rounds of 256; the Python mirror's EStepEngine.choose_nsplit). */
 int64_t tsvgp_site_accum_work_bytes_f64(int Mp, int P, int nsplit);

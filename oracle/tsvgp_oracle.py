@@ -317,10 +317,12 @@ class Bernoulli:
 # --------------------------------------------------------------------------
 # GPflow conditionals / KL [ext]
 # --------------------------------------------------------------------------
-def base_conditional(Kmn, Kmm, Knn, f, q_sqrt=None, white=False):
+def base_conditional(Kmn, Kmm, Knn, f, q_sqrt=None, white=False, _Lm=None):
     """gpflow.conditionals.util.base_conditional [ext] (full_cov=False).
-    Kmn [M,N], Kmm [M,M], Knn [N], f [M,P], q_sqrt [P,M,M] -> mean [N,P], var [N,P]."""
-    Lm = _chol(Kmm)
+    Kmn [M,N], Kmm [M,M], Knn [N], f [M,P], q_sqrt [P,M,M] -> mean [N,P], var [N,P].
+    ``_Lm`` (not GPflow's): chol(Kmm) from a previous call with the same Kmm -- row-blocked callers factor once, as the
+    reference's single call over all rows does."""
+    Lm = _chol(Kmm) if _Lm is None else _Lm
     A = _trsm(Lm, Kmn, lower=True)  # [M,N]
     P = f.shape[-1]
     fvar = Knn - np.sum(A * A, axis=-2)  # [N]
@@ -336,7 +338,7 @@ def base_conditional(Kmn, Kmm, Knn, f, q_sqrt=None, white=False):
     return fmean, fvar.T
 
 
-def conditional(Xnew, iv, kernel, f, q_sqrt=None, white=False):
+def conditional(Xnew, iv, kernel, f, q_sqrt=None, white=False, _Lm=None):
     """gpflow.conditionals.conditional (InducingPoints, Kernel) [ext]: jitter = default_jitter().
     For (SharedIndependentInducingVariables, SeparateIndependent) GPflow dispatches to
     separate_independent_conditional [ext]: base_conditional per latent with its own Kmm / Kmn / Knn."""
@@ -345,10 +347,11 @@ def conditional(Xnew, iv, kernel, f, q_sqrt=None, white=False):
     Knn = kernel.K_diag(Xnew)
     if _is_multi(iv, kernel):
         outs = [base_conditional(Kmn[p], Kmm[p], Knn[:, p], f[:, p:p + 1],
-                                 q_sqrt=None if q_sqrt is None else q_sqrt[p:p + 1], white=white)
+                                 q_sqrt=None if q_sqrt is None else q_sqrt[p:p + 1], white=white,
+                                 _Lm=None if _Lm is None else _Lm[p])
                 for p in range(len(kernel.kernels))]
         return np.concatenate([o[0] for o in outs], axis=1), np.concatenate([o[1] for o in outs], axis=1)
-    return base_conditional(Kmn, Kmm, Knn, f, q_sqrt=q_sqrt, white=white)
+    return base_conditional(Kmn, Kmm, Knn, f, q_sqrt=q_sqrt, white=white, _Lm=_Lm)
 
 
 def gauss_kl(q_mu, q_sqrt, K):
@@ -866,3 +869,95 @@ def elbo_chunked(model, data, chunk_rows=20000, progress=None):
             progress(min(lo + chunk_rows, X.shape[0]), X.shape[0])
     scale = (float(model.num_data) / X.shape[0]) if model.num_data is not None else 1.0
     return math.fsum(sums) * scale - kl
+
+
+class _CompensatedSum:
+    """Running sum of equally shaped arrays with Neumaier's compensation (the array form of ``math.fsum``'s idea): the
+    rounding error of every addition is kept in a second array and added back at the end, so the order and the number of
+    row blocks do not show in the result beyond one rounding."""
+
+    def __init__(self):
+        self.s = None
+        self.c = None
+
+    def add(self, x):
+        x = np.asarray(x, dtype=np.float64)
+        if self.s is None:
+            self.s, self.c = x.copy(), np.zeros_like(x)
+            return
+        t = self.s + x
+        big = np.abs(self.s) >= np.abs(x)
+        self.c += np.where(big, (self.s - t) + x, (x - t) + self.s)
+        self.s = t
+
+    def value(self):
+        return self.s + self.c
+
+
+def natgrad_step_chunked(model, data, lr=0.1, jitter=1e-9, chunk_rows=20000, progress=None):
+    """``t_SVGP.natgrad_step`` (src/models/tsvgp.py:234-304) with the N rows taken block by block, so that the reference's op
+    sequence can be run at N = 1e6, M = 1024 (one call over all rows would hold ~8 arrays of N M 8 bytes = 67 GB).
+    Everything that does not depend on the rows is done ONCE, where the reference does it (posterior factorisation :246 -> :102,
+    predict_f(Z) :249-254, K_uu and its factor :268-270, the update :284-304); per block of ``chunk_rows`` rows the reference's
+    N-sized ops run unchanged and in its order: ``conditional`` [ext] (:246 -- K_uf, two triangular solves, the dense
+    q_sqrt^T A product), the likelihood gradients and the crop (:256-263), K_uf AGAIN (:269), ``cholesky_solve`` (:270-271), the
+    tile (:276-277) and the two einsums (:279-280), whose block results G0 [M,P], G1 [P,M,M] are added with compensated
+    summation (``_CompensatedSum``).  Same numbers as ``natgrad_step`` up to the order of the row sums (checked in
+    tests/test_oracle_pins.py); what tests/test_gpu_fullsize.py compares the HIP step with at full size, and -- timed -- the
+    MEASURED CPU baseline of the metric (bench.py ``state_match``)."""
+    import math
+
+    X, Y = data
+    X = np.asarray(X, dtype=np.float64)
+    Y = np.asarray(Y, dtype=np.float64)
+    iv, kernel = model.inducing_variable, model.kernel
+    # :246 -> :102-103: (m, chol S) once; the factor of K_uu + 1e-6 I that ``conditional`` takes per call
+    q_mu, q_sqrt = model.get_mean_chol_cov_inducing_posterior()
+    Lm = _chol(Kuu(iv, kernel, jitter=DEFAULT_JITTER))
+    if isinstance(iv, SharedIndependentInducingVariables):  # :249-252
+        meanZ, _ = model.predict_f(iv.inducing_variables[0].Z)
+    else:
+        meanZ, _ = model.predict_f(iv.Z)  # :254
+    Id = np.eye(model.num_inducing)  # :265
+    K_uu = Kuu(iv, kernel)  # :268 (no jitter)
+    chol_Kuu = _chol(K_uu + Id * jitter)  # :270
+    G0, G1, A_abs = _CompensatedSum(), _CompensatedSum(), _CompensatedSum()
+    N = X.shape[0]
+    means, vars_, g0s, g1s, ve = [], [], [], [], []
+    kl_before = model.prior_kl()  # :65-70 at the state the step starts from (for ``last["elbo_before"]``, below)
+    for lo in range(0, N, chunk_rows):
+        Xb, Yb = X[lo:lo + chunk_rows], Y[lo:lo + chunk_rows]
+        mean, var = conditional(Xb, iv, kernel, q_mu, q_sqrt=q_sqrt, white=False, _Lm=Lm)  # :246 -> :103
+        if not np.all(var > 0):  # :113
+            raise FloatingPointError("predict_f: non-positive predictive variance")
+        g0, g1 = model.likelihood.variational_expectations_grads(mean, var, Yb)  # :256-259
+        g1 = np.minimum(g1, -1e-8 * np.ones_like(g1))  # :262-263
+        K_uf = Kuf(iv, kernel, Xb)  # :269
+        A = np.transpose(_chol_solve(chol_Kuu, K_uf))  # :271
+        if A.ndim == 2:
+            A = np.tile(A[..., None], [1, 1, model.num_latent_gps])  # :276-277
+        G0.add(np.einsum("nml,nl->ml", A, g0))  # :279
+        # (not part of the step) sum_n |a_n|: the sensitivity of G0 to its inputs -- an error e in g0 moves G0 by at most
+        # e * sum_n |a_n|.  G0 = A^T (y - mean) / s2 is a small difference of N-sized terms once the sites fit the data, so
+        # its RELATIVE error is unbounded while lambda_1, which it updates, is not affected; comparisons scale by this
+        A_abs.add(np.sum(np.abs(A), axis=0))
+        G1.add(np.einsum("nml,nol,nl->lmo", A, A, g1, optimize=True))  # :280
+        means.append(mean), vars_.append(var), g0s.append(g0), g1s.append(g1)
+        # not part of the step: the block's term of ``elbo`` (:88-95) at the state the step STARTS from rides along (O(n P)),
+        # so one pass over the rows yields both halves of the metric's parity check
+        ve.append(float(np.sum(model.likelihood.variational_expectations(mean, var, Yb))))
+        if progress is not None:
+            progress(min(lo + chunk_rows, N), N)
+    grads = [G0.value(), G1.value()]
+    grad_mu = gradient_transformation_mean_var_to_expectation(meanZ, grads)  # :284
+    scale = (float(model.num_data) / N) if model.num_data is not None else 1.0  # :286-291
+    lambda_2 = -0.5 * model.lambda_2  # :293
+    lambda_1 = (1 - lr) * model.lambda_1 + lr * scale * grad_mu[0]  # :296
+    lambda_2 = (1 - lr) * lambda_2 + lr * scale * grad_mu[1]  # :297
+    lambda_2_sqrt = -_chol(-2.0 * lambda_2 + Id * jitter)  # :300
+    model.sites.lambda_1 = lambda_1  # :302
+    model.sites._lambda_2_sqrt = np.tril(lambda_2_sqrt)  # :303
+    model.get_mean_chol_cov_inducing_posterior()  # :304 (result discarded)
+    model.last = dict(mean=np.concatenate(means), var=np.concatenate(vars_), meanZ=meanZ, g0=np.concatenate(g0s),
+                      g1=np.concatenate(g1s), G0=grads[0], G1=grads[1],
+                      elbo_before=math.fsum(ve) * scale - kl_before, A_abs_colsum=A_abs.value())

@@ -65,6 +65,12 @@ class Parameter:
         """(assign counter, the tensor's own edit counter): an in-place edit of ``.value`` changes the second."""
         return (self.version, self._value._version)
 
+    def stamp(self):
+        """Cache key of this parameter's CONTENTS as far as the host can tell without reading the device: identity, the
+        ``assign`` counter and the tensor's own edit counter (an in-place edit of ``.value`` -- ``p.value.mul_(2)`` -- does
+        not pass through ``assign``).  What a captured hipGraph or a cached factor that baked the value in is keyed on."""
+        return (id(self), self.version, self._value._version)
+
     def item(self) -> float:
         """The scalar value as a Python float.  Kernel launches take scalars by value; reading them back from the
         device on every E-step would put a host synchronisation in the middle of the step, so the host copy is kept

@@ -3636,6 +3636,10 @@ int site_accum(const T* B, int64_t strideB, const T* g0, const T* g1, double* ac
     if (!B || !g0 || !g1 || !acc2 || !acc1 || !work || Np <= 0 || (Np % TILE) || Mp <= 0 || (Mp % TILE) || P <= 0 ||
         nsplit <= 0 || strideB < 0 || (strideB != 0 && strideB < Np * (int64_t)Mp))
         return TSVGP_EINVAL;
+    // the operand rows and the weights of a chunk travel by 16-byte LDS-DMA pieces: B, g0, g1 (contiguous [Np x P]) on
+    // 16-byte boundaries, as every allocator hands them out; a sliced view that is not gets an error, not a fault
+    if (((uintptr_t)B | (uintptr_t)g0 | (uintptr_t)g1 | (uintptr_t)work) & 15 || ((strideB * (int64_t)sizeof(T)) & 15))
+        return TSVGP_EINVAL;
     const int nt = Mp / TILE, ntri = nt * (nt + 1) / 2, n_off = ntri - nt;
     const int64_t total_chunks = Np / KC;
     SyrkArgs<T> a{};

@@ -52,6 +52,13 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
 
+def site_sum_chunk_rows(f64: bool, P: int) -> int:
+    """Rows per k-chunk of the site-sum kernel that runs for this type and latent count: syrk1_kernel (fp64) 16,
+    syrk1f_kernel (fp32, P <= 8) 32, the round-2 syrk_kernel (P > 8, either type) 16.  A slice shorter than one chunk is an
+    empty workgroup (harmless, wasted): the slice count is capped at Np / this."""
+    return 32 if (not f64 and P <= 8) else 16
+
+
 def site_sum_slices(Mp: int, P: int, Np, slots: int, f64: bool, oversubscribe=None) -> int:
     """The slice count of ``EStepEngine.choose_nsplit`` as a pure function of the shape and of the resident workgroup slots
     (256 for fp64, 512 for fp32 on MI355X): see there for the cost model and the measurements behind it."""
@@ -65,7 +72,7 @@ def site_sum_slices(Mp: int, P: int, Np, slots: int, f64: bool, oversubscribe=No
         while P * (n_off * (ns + 1) + nt * ns_diag(ns + 1)) <= slots:
             ns += 1
         return ns * (oversubscribe if oversubscribe is not None else 8)
-    chunks = max(1, Np // (16 if f64 else 32))  # the kernels' chunks: 16 rows (fp64) / 32 rows (fp32)
+    chunks = max(1, Np // site_sum_chunk_rows(f64, P))  # the kernels' chunks: 16 rows (fp64) / 32 rows (fp32, P <= 8)
     overhead = 14.0
     best, best_t = 1, None
     for ns in range(1, max(1, min(chunks // 32, 1024)) + 1):
@@ -138,13 +145,17 @@ class EStepEngine:
             pool.append(torch.cuda.Event(enable_timing=True))
 
     def profile_summary(self):
-        """{kernel: (launches, mean ms)} from the recorded events (synchronises); the events go back to the pool."""
+        """{kernel: (launches, mean ms, min ms, median ms, max ms, [ms in launch order])} from the recorded events (synchronises); the events go
+        back to the pool."""
         torch.cuda.synchronize(self.device)
         out = {}
         pool = self.__dict__.setdefault("_event_pool", [])
         for name, evs in (self.profile or {}).items():
-            ms = [a.elapsed_time(b) for a, b in evs]
-            out[name] = (len(ms), sum(ms) / max(len(ms), 1))
+            series = [a.elapsed_time(b) for a, b in evs]  # in launch order
+            ms = sorted(series)
+            n = len(ms)
+            med = 0.0 if n == 0 else (ms[n // 2] if n % 2 else 0.5 * (ms[n // 2 - 1] + ms[n // 2]))
+            out[name] = (n, sum(ms) / max(n, 1), ms[0] if n else 0.0, med, ms[-1] if n else 0.0, series)
             for a, b in evs:
                 pool += [a, b]
         if self.profile is not None:
@@ -551,7 +562,7 @@ class EStepEngine:
             stats.g0, stats.g1 = g0[:N].to(torch.float64), g1[:N].to(torch.float64)
         if sites:
             nsplit = self.nsplit_override or self.choose_nsplit(Mp, P, Np)
-            nsplit = max(1, min(nsplit, Np // 16))
+            nsplit = max(1, min(nsplit, Np // site_sum_chunk_rows(T == torch.float64, P)))
             nbytes = int(self._fn("tsvgp_site_accum_work_bytes")(Mp, P, nsplit))
             work = self._get("work", (nbytes,), torch.uint8)
             acc2 = torch.empty((P, Mp, Mp), dtype=torch.float64, device=dev)
@@ -626,8 +637,8 @@ class EStepEngine:
             return None
         # Under stream capture (hipGraph) the side stream JOINS the capture: it waits for an event recorded on the capturing
         # stream (a fork) and the consumer waits for its event (the join) inside the same capture, so a replayed step runs the
-        # fill beside the prelude exactly as an eager one.  Allocator bookkeeping (record_stream) is skipped there: a graph owns
-        # its buffers for its lifetime.
+        # fill beside the prelude exactly as an eager one.  record_stream means nothing to a graph's private pool, so there the
+        # ticket itself keeps every tensor the side stream reads alive until the join (`keep`, below).
         capturing = torch.cuda.is_current_stream_capturing()
         T, dev = self.dtype, self.device
         N, D = X.shape
@@ -657,7 +668,8 @@ class EStepEngine:
             if not capturing:
                 for t in (Xc, Zc, KfuP):
                     t.record_stream(side)
-            return dict(event=done, KfuP=KfuP)
+            # `keep`: see the single-kernel ticket below
+            return dict(event=done, KfuP=KfuP, keep=(Xc, Zc))
         if (b_tag is not None and self._b_tag == (want, b_tag) and self._buf.get(want) is not None
                 and tuple(self._buf[want].shape) == (Np, Mp)):
             return None
@@ -679,7 +691,15 @@ class EStepEngine:
         if not capturing:
             for t in (Xc, Zc, inv_ls, Kfu):  # blocks of the main stream's allocator pool that the side stream touches
                 t.record_stream(side)
-        return dict(event=done, key=(X.data_ptr(), tuple(X.shape), Z.data_ptr(), tuple(Z.shape), id(kernel)), Kfu=Kfu)
+        # `keep`: the converted inputs must outlive the side stream's read of them.  Eagerly record_stream sees to that; under
+        # capture nothing does -- a block freed DURING a capture goes straight back to the graph's pool, the next allocation on
+        # the capturing stream (a prelude temporary) takes it, and in the replayed graph that kernel runs BESIDE the forked fill
+        # still reading it.  Found in round 4 by the two-rank fp32 test of BASELINE configs[3] (fp32: Z [M, D] is converted into
+        # such a temporary; fp64 passes its tensors through, which is why three rounds of fp64 tests never saw it): the state
+        # after four replayed steps was off by 1e-5 ... 0.4, differently on every run.  The ticket holds them until ``run`` has
+        # made the consuming stream wait for the fill.
+        return dict(event=done, key=(X.data_ptr(), tuple(X.shape), Z.data_ptr(), tuple(Z.shape), id(kernel)), Kfu=Kfu,
+                    keep=(Xc, Zc, inv_ls))
 
     # ------------------------------------------------------------------ one N-pass
     def run(self, X, Y, Z, kernel, *, moment_Tm, moment_mode, gamma, lik_id=B.LIK_NONE, lik_param=0.0,
@@ -818,7 +838,7 @@ class EStepEngine:
         dev = self.device
         Np, Mp = A.shape
         nsplit = self.nsplit_override or self.choose_nsplit(Mp, P, Np)
-        nsplit = max(1, min(nsplit, Np // 16))
+        nsplit = max(1, min(nsplit, Np // site_sum_chunk_rows(self.dtype == torch.float64, P)))
         nbytes = int(self._fn("tsvgp_site_accum_work_bytes")(Mp, P, nsplit))
         work = self._get("work", (nbytes,), torch.uint8)
         acc2 = torch.empty((P, Mp, Mp), dtype=torch.float64, device=dev)

@@ -252,13 +252,12 @@ class t_SVGP(base_SVGP):
         if isinstance(self.kernel, SeparateIndependent):
             return None  # one K(X, Z) buffer serves the latents in turn: nothing N-sized survives the call
         return (X.data_ptr(), tuple(X.shape), X._version, X.dtype, self._kernel_versions(),
-                id(self.inducing_variable.Z), self.inducing_variable.Z.version, float(jitter), self.compute_dtype)
+                self.inducing_variable.Z.stamp(), float(jitter), self.compute_dtype)
 
     def _kernel_versions(self):
         # Parameter identity and the tensors' own edit counters ride along: a replaced Parameter restarts at version 0 and an
         # in-place edit of .value does not pass through assign()
-        return tuple((id(k), id(k.variance), k.variance.version, k.variance.value._version,
-                      id(k.lengthscales), k.lengthscales.version, k.lengthscales.value._version)
+        return tuple((id(k), k.variance.stamp(), k.lengthscales.stamp())
                      for k in latent_kernels(self.kernel, self.num_latent_gps))
 
     # Route gates on cond(K_uu + jitter I), per latent GP.  direct: K^-1 (sum g k k^T) K^-1 cancels two factors of K, so its
@@ -285,13 +284,15 @@ class t_SVGP(base_SVGP):
         P = self.num_latent_gps
         if self.projection != "auto":
             return [self.projection] * P
-        key = (self._kernel_versions(), id(self.inducing_variable.Z), self.inducing_variable.Z.version, float(jitter))
+        key = (self._kernel_versions(), self.inducing_variable.Z.stamp(), float(jitter))
         if self._cond_cache is None or self._cond_cache[0] != key:
             eng = self._get_engine()
             Kzz = eng.kuu(self._Z(), self.kernel)  # [M, M] or [P, M, M]
             Kzz.diagonal(dim1=-2, dim2=-1).add_(jitter)
             cond = cond2_estimate(Kzz, getattr(eng, "cholesky", None)).reshape(-1)
-            cond = D_.broadcast_from_rank0(cond.contiguous()).tolist()  # one decision for all ranks
+            # one decision for all ranks -- only when this model's steps are collective at all (data_parallel=False, or a
+            # rank-0-only side computation, must not issue a broadcast the other ranks never join)
+            cond = (D_.broadcast_from_rank0(cond.contiguous()) if self._reduce() else cond).tolist()
             self._cond_cache = (key, cond if len(cond) == P else cond * P, {})
         dmax, wmax = self.DIRECT_MAX_COND[self.compute_dtype], self.WHITENED_MAX_COND[self.compute_dtype]
         routes = ["direct" if c <= dmax else "whitened" if c <= wmax else "projected" for c in self._cond_cache[1]]
@@ -851,6 +852,10 @@ class t_SVGP(base_SVGP):
     # N = 1000, M = 32: 0.46 / 0.31 ms; 5000 x 128: 0.44 / 0.38; 62 500 x 1024: 3.91 / 3.83; 125 000 x 1024: 5.96 / 5.97;
     # 250 000 x 1024: 9.94 / 10.02.
     GRAPH_FORK_MIN_NM = int(os.environ.get("TSVGP_GRAPH_FORK_MIN_NM", "100000000"))
+    # Memory cost of use_graph: a captured step owns its own K(X, Z), partial-tile and operand buffers beside the eager path's
+    # (8 N M bytes + ~0.5 GB in fp64: 1.0 GB at 125 000 x 1024, 1.6 GB at the "auto" limit).  Up to four captures are kept for
+    # small problems (alternating minibatches, lr schedules); from this N * M on only the latest one (see _graph_step).
+    GRAPH_SINGLE_MIN_NM = 10_000_000
 
     def _wants_graph(self, X) -> bool:
         """use_graph = True / False, or "auto" (the default): replay from a captured graph where that is faster.
@@ -883,10 +888,12 @@ class t_SVGP(base_SVGP):
         # front of it (prelude, fill, moments, site sums, packing) and everything behind it (unpacking, epilogue, state
         # update, status words); the collective itself is issued between the two replays on the same stream.
         two = self._reduce()
-        lik_v = tuple(p.version for p in vars(self.likelihood).values() if hasattr(p, "version"))
+        # scalars (likelihood variance, kernel variance) travel as kernel ARGUMENTS and Z is converted into a capture-owned
+        # buffer, so every parameter is keyed on Parameter.stamp(): identity + assign counter + the tensor's own edit counter
+        # (an in-place edit of .value -- likelihood.variance.value.mul_(2), Z.value.add_(..) -- never passes through assign)
+        lik_v = tuple(p.stamp() for p in vars(self.likelihood).values() if hasattr(p, "stamp"))
         key = (X.data_ptr(), Y.data_ptr(), tuple(X.shape), tuple(Y.shape), X.dtype, Y.dtype, self._kernel_versions(),
-               lik_v, id(self.inducing_variable.Z), self.inducing_variable.Z.version, float(lr), float(jitter),
-               tuple(routes), self.num_data)
+               lik_v, self.inducing_variable.Z.stamp(), float(lr), float(jitter), tuple(routes), self.num_data)
         entry = self._graphs.get(key)
         if entry is None:
             if len(self._graphs) >= 64:  # ever-changing inputs (fresh minibatch tensors): keep the markers bounded
@@ -895,7 +902,11 @@ class t_SVGP(base_SVGP):
             return False
         l1p, Lp = self.lambda_1, self.sites._lambda_2_sqrt
         if entry == "seen":
-            if len(self._graphs) > 4:  # each graph owns its buffers (K(X, Z) among them): keep few
+            # each graph owns its work buffers (K(X, Z), the partial tiles, the operands: ~10 N M bytes): keep few, and above
+            # GRAPH_SINGLE_MIN_NM only ONE -- every M-step changes the kernel versions and with them the key, so the previous
+            # capture is dead weight (1.6-3.2 GB at the "auto" limit) the moment a new key is captured
+            big = X.shape[0] * self.num_inducing > self.GRAPH_SINGLE_MIN_NM
+            if len(self._graphs) > 4 or (big and any(isinstance(v, dict) for v in self._graphs.values())):
                 self._graphs = {key: "seen"}
             sl1, sL = l1p.value.clone(), Lp.value.clone()  # static state tensors the graph reads and writes
             bl1, bL = torch.empty_like(sl1), torch.empty_like(sL)
@@ -966,19 +977,9 @@ class t_SVGP(base_SVGP):
         Lp.version += 1
         return True
 
-    def _apply_site_update(self, st, ops, lr, jitter, inplace=False, reduced=None, latents=None):
-        """All-reduce of the packed accumulators (RCCL) + the replicated M x M epilogue (tsvgp.py:278-303).
-        Returns the status flags (device tensor, see ``_status_flags``).  ``reduced``: the already summed
-        (acc2, acc1, nonpos, rows) when the caller did the collective itself (the two-graph replay)."""
-        P, M = self.num_latent_gps, self.num_inducing
-        eng = self._get_engine()
-        if reduced is not None:
-            acc2, acc1, nonpos, rows = reduced
-        else:
-            acc2, acc1, _, nonpos, rows, _ = D_.reduce_stats(st, P, M, True, self._reduce(), eng)
-        if ops.get("epi_event") is not None:  # L L^T, K_uu beta, K9^-1 from the side stream (see _site_operands)
-            torch.cuda.current_stream(self.device).wait_event(ops["epi_event"])
-
+    def _map_sums(self, ops, acc2, acc1):
+        """The accumulators of the N-pass in the coordinates their route took them in -> the reference's
+        G1 = sum_n g1 a a^T [P, M, M] and G0 = sum_n g0 a [M, P] with a = K9^-1 k (tsvgp.py:278-281)."""
         Uinv9 = ops["Uinv9"]
         Uinv9t = Uinv9.transpose(-1, -2) if Uinv9 is not None else None  # None: projected route on the lower factor
         routes = ops["routes"]
@@ -1000,6 +1001,37 @@ class t_SVGP(base_SVGP):
         else:  # mixed routes (separate kernels): every latent keeps the form its sums were taken in
             G1 = torch.stack([forms[r][0][p] for p, r in enumerate(routes)])
             G0 = torch.stack([forms[r][1][:, p] for p, r in enumerate(routes)], dim=1)
+        return G1, G0
+
+    def site_sums(self, data, jitter=1e-9):
+        """(G0 [M, P], G1 [P, M, M]) of tsvgp.py:279-280 at the CURRENT state -- the N-pass of one E-step on the route
+        ``natgrad_step`` would take, mapped back to the reference's coordinates, without updating the state.  Not part of the
+        reference's API: what full-size parity checks (tests/, bench.py's ``state_match``) compare with the oracle's einsums."""
+        X, Y = self._as_device(data[0]), self._as_device(data[1])
+        routes = self._routes(jitter)
+        st, ops = self._step_front(X, Y, 0.0, jitter, routes)
+        acc2, acc1, _, nonpos, _, _ = D_.reduce_stats(st, self.num_latent_gps, self.num_inducing, True, self._reduce(),
+                                                      self._get_engine())
+        if ops.get("epi_event") is not None:
+            torch.cuda.current_stream(self.device).wait_event(ops["epi_event"])
+        G1, G0 = self._map_sums(ops, acc2, acc1)
+        self._check_step(ops, nonpos)
+        return G0, 0.5 * (G1 + G1.transpose(-1, -2))
+
+    def _apply_site_update(self, st, ops, lr, jitter, inplace=False, reduced=None, latents=None):
+        """All-reduce of the packed accumulators (RCCL) + the replicated M x M epilogue (tsvgp.py:278-303).
+        Returns the status flags (device tensor, see ``_status_flags``).  ``reduced``: the already summed
+        (acc2, acc1, nonpos, rows) when the caller did the collective itself (the two-graph replay)."""
+        P, M = self.num_latent_gps, self.num_inducing
+        eng = self._get_engine()
+        if reduced is not None:
+            acc2, acc1, nonpos, rows = reduced
+        else:
+            acc2, acc1, _, nonpos, rows, _ = D_.reduce_stats(st, P, M, True, self._reduce(), eng)
+        if ops.get("epi_event") is not None:  # L L^T, K_uu beta, K9^-1 from the side stream (see _site_operands)
+            torch.cuda.current_stream(self.device).wait_event(ops["epi_event"])
+
+        G1, G0 = self._map_sums(ops, acc2, acc1)
         # tsvgp.py:286-300 in one pass (tsvgp_site_target_f64): with lambda_2 = -1/2 L L^T the matrix to factor is
         #   -2 [(1 - lr) lambda_2 + lr scale G1] + jitter I = (1 - lr) L L^T - 2 lr scale G1 + jitter I;
         # L L^T of the old factor comes from the prelude, `rows` (the global number of rows) is a device scalar: the

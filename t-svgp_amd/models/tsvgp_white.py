@@ -214,7 +214,7 @@ class t_SVGP_white(base_SVGP):
         """cond(K_uu + default_jitter I), estimated (``util.cond2_estimate``) once per change of the kernel parameters or
         Z, taken from rank 0."""
         k, Zp = self.kernel, self.inducing_variable.Z
-        key = (id(k), k.variance.version, k.lengthscales.version, id(Zp), Zp.version)
+        key = (id(k), k.variance.stamp(), k.lengthscales.stamp(), Zp.stamp())
         if self._cond_cache is None or self._cond_cache[0] != key:
             eng = self._get_engine()
             Kzz = eng.kuu(self._Z(), k)

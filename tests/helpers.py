@@ -6,6 +6,17 @@ import numpy as np
 from oracle import tsvgp_oracle as O
 
 
+def free_port() -> int:
+    """A rendezvous port nobody holds right now: bound on the loopback interface, read back and released (what bench.py's
+    self_launch does).  A port derived from the pid can collide with a previous test's socket in TIME_WAIT, and a collision
+    there is a hang, not a failure."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def pkg():
     return importlib.import_module("t-svgp_amd")
 

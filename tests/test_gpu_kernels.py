@@ -232,6 +232,49 @@ def test_site_accum(engines, dtype, tol, Np, Mp, P, nsplit):
     assert torch.equal(acc2, acc2b) and torch.equal(acc1, acc1b)
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-12), (torch.float32, 1e-5)])
+@pytest.mark.parametrize("P", [1, 9])
+def test_site_accum_more_slices_than_chunks(engines, dtype, tol, P):
+    """``nsplit`` above Np / chunk (16 rows in fp64, 32 in fp32 with P <= 8, 16 in the P > 8 kernel): workgroups whose slice is
+    EMPTY contribute exact zeros -- correct, only wasted (include/tsvgp_hip.h: any nsplit >= 1 is valid)."""
+    eng = engines[dtype]
+    B = pkg()._backend
+    Np, Mp = 256, 256
+    rng = np.random.RandomState(8)
+    t = lambda a: torch.as_tensor(a, dtype=dtype, device="cuda:0").contiguous()
+    Bt, g0t, g1t = t(rng.randn(Np, Mp)), t(rng.randn(Np, P)), t(-rng.rand(Np, P) - 0.1)
+    Bd, g0d, g1d = Bt.double().cpu().numpy(), g0t.double().cpu().numpy(), g1t.double().cpu().numpy()
+    ref2, ref1 = np.einsum("nm,no,nl->lmo", Bd, Bd, g1d), np.einsum("nm,nl->lm", Bd, g0d)
+    for nsplit in (Np // 32 + 3, Np // 16 + 5, 40):  # beyond the fp32 chunk count, beyond the fp64 one, far beyond both
+        nbytes = int(eng._fn("tsvgp_site_accum_work_bytes")(Mp, P, nsplit))
+        work = torch.empty(nbytes, dtype=torch.uint8, device="cuda:0")
+        acc2 = torch.full((P, Mp, Mp), float("nan"), dtype=torch.float64, device="cuda:0")
+        acc1 = torch.full((P, Mp), float("nan"), dtype=torch.float64, device="cuda:0")
+        B.check(eng._fn("tsvgp_site_accum")(Bt.data_ptr(), g0t.data_ptr(), g1t.data_ptr(), acc2.data_ptr(), acc1.data_ptr(),
+                                            work.data_ptr(), Np, Mp, P, nsplit, eng._stream()), "site_accum")
+        torch.cuda.synchronize()
+        assert relerr(acc2.cpu().numpy(), ref2) < tol * 50 and relerr(acc1.cpu().numpy(), ref1) < tol * 50, nsplit
+
+
+def test_site_accum_rejects_misaligned_operands(engines):
+    """B, g0, g1 travel by 16-byte LDS-DMA pieces: a view that starts off a 16-byte boundary is an invalid argument, not a
+    memory fault (include/tsvgp_hip.h (5))."""
+    eng = engines[torch.float64]
+    Np, Mp, P = 128, 128, 1
+    Bt = torch.zeros(Np * Mp + 2, dtype=torch.float64, device="cuda:0")
+    g = torch.zeros(Np * P + 2, dtype=torch.float64, device="cuda:0")
+    acc2 = torch.zeros((P, Mp, Mp), dtype=torch.float64, device="cuda:0")
+    acc1 = torch.zeros((P, Mp), dtype=torch.float64, device="cuda:0")
+    work = torch.empty(int(eng.lib.tsvgp_site_accum_work_bytes_f64(Mp, P, 1)), dtype=torch.uint8, device="cuda:0")
+    call = lambda b, g0, g1: eng.lib.tsvgp_site_accum_f64(b, g0, g1, acc2.data_ptr(), acc1.data_ptr(), work.data_ptr(), Np, Mp,
+                                                           P, 1, eng._stream())
+    assert call(Bt.data_ptr(), g.data_ptr(), g.data_ptr()) == 0
+    assert call(Bt.data_ptr() + 8, g.data_ptr(), g.data_ptr()) == 1
+    assert call(Bt.data_ptr(), g.data_ptr() + 8, g.data_ptr()) == 1
+    assert call(Bt.data_ptr(), g.data_ptr(), g.data_ptr() + 8) == 1
+    torch.cuda.synchronize()
+
+
 def test_invalid_arguments_are_rejected(engines):
     eng = engines[torch.float64]
     lib = eng.lib

@@ -414,6 +414,50 @@ def test_graph_replay_matches_eager(lik):
     assert len([e for e in graph._graphs.values() if isinstance(e, dict)]) == 2
 
 
+def test_graph_replay_sees_in_place_parameter_edits():
+    """Scalars are baked into a captured step as kernel ARGUMENTS and Z into a capture-owned buffer, so the graph key must see
+    edits that never pass through ``assign``: ``likelihood.variance.value.mul_()``, ``kernel.variance.value.add_()``,
+    ``Z.value.add_()`` (round-3 advisor finding: only the assign counters were keyed for the likelihood and Z, and a replay
+    then silently used the stale value).  After every edit the graph model must equal an eager model AND the oracle."""
+    p = pkg()
+    X, Y, Z = synthetic(N=600, M=32, D=3, P=1, lik="gaussian", seed=5)
+    Xd, Yd = torch.as_tensor(X, device="cuda:0"), torch.as_tensor(Y, device="cuda:0")
+    mk = lambda **kw: p.t_SVGP(p.SquaredExponential(1.0, 1.0), p.Gaussian(0.1), Z.copy(), **kw)
+    eager, graph = mk(use_graph=False), mk(use_graph=True)
+    ora = O.t_SVGP(O.SquaredExponential(1.0, 1.0), O.Gaussian(0.1), Z.copy())
+    noise, kvar, Zo = 0.1, 1.0, Z.copy()
+
+    def steps(n):
+        for _ in range(n):
+            eager.natgrad_step((Xd, Yd), lr=0.6)
+            graph.natgrad_step((Xd, Yd), lr=0.6)
+            ora.natgrad_step((X, Y), lr=0.6)
+        assert relerr(graph.lambda_1.numpy(), eager.lambda_1.numpy()) < 1e-12
+        assert relerr(graph.lambda_2.cpu().numpy(), eager.lambda_2.cpu().numpy()) < 1e-12
+        assert relerr(graph.lambda_1.numpy(), ora.lambda_1) < 1e-8 and relerr(graph.lambda_2.cpu().numpy(), ora.lambda_2) < 1e-8
+
+    steps(4)  # eager, capture, two replays
+    assert sum(isinstance(e, dict) for e in graph._graphs.values()) == 1
+    for m in (eager, graph):
+        m.likelihood.variance.value.mul_(2.0)  # in place: no assign(), the version counter does not move
+    noise *= 2.0
+    ora.likelihood = O.Gaussian(noise)
+    steps(4)
+    for m in (eager, graph):
+        m.kernel.variance.value.add_(0.25)
+    kvar += 0.25
+    ora.kernel = O.SquaredExponential(kvar, 1.0)
+    steps(4)
+    shift = 0.05 * np.random.RandomState(1).randn(*Z.shape)
+    for m in (eager, graph):
+        m.inducing_variable.Z.value.add_(torch.as_tensor(shift, device=m.inducing_variable.Z.value.device))
+    Zo = Zo + shift
+    ora.inducing_variable = O.inducingpoint_wrapper(Zo)
+    steps(4)
+    e_o = ora.elbo((X, Y))
+    assert abs(float(graph.elbo((Xd, Yd))) - e_o) < 1e-9 * abs(e_o)
+
+
 def test_graph_replay_error_path_restores_state():
     """A replayed step that fails its status check leaves the state untouched and raises like the eager path."""
     p = pkg()

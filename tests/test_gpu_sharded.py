@@ -10,7 +10,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from oracle import tsvgp_oracle as O
-from tests.helpers import pkg, relerr, synthetic
+from tests.helpers import free_port, pkg, relerr, synthetic
 
 pytestmark = pytest.mark.gpu
 
@@ -37,7 +37,7 @@ def _worker(rank, world, port, out):
 
 def test_two_ranks_on_one_gpu_match_single_process(tmp_path):
     out = str(tmp_path / "r0.npz")
-    port = 29500 + (os.getpid() % 2000)
+    port = free_port()
     mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
     got = np.load(out)
     X, Y, Z = synthetic(N=5001, M=96, D=4, lik="bernoulli", seed=9)
@@ -81,7 +81,7 @@ def test_empty_shard_contributes_zeros(tmp_path):
     """N < world size: the rank without rows takes part in the all-reduce with zeros instead of raising alone while the
     others wait (``shard_bounds`` hands it an empty block); a single process with no rows still raises."""
     out = str(tmp_path / "r0.npz")
-    port = 27500 + (os.getpid() % 2000)
+    port = free_port()
     mp.spawn(_worker_empty, args=(2, port, out), nprocs=2, join=True)
     got = np.load(out)
     X, Y, Z = synthetic(N=2, M=2, D=2, seed=3)
@@ -119,7 +119,7 @@ def test_two_rank_step_replayed_as_two_graphs_around_the_all_reduce(tmp_path):
     """use_graph with more than one rank: the step is captured as two graphs (in front of and behind the all-reduce of
     the packed accumulators) and replayed with the collective issued in between; results against the oracle."""
     out = str(tmp_path / "r0.npz")
-    port = 25500 + (os.getpid() % 2000)
+    port = free_port()
     mp.spawn(_worker_graph, args=(2, port, out), nprocs=2, join=True)
     got = np.load(out)
     assert bool(got["captured"])
@@ -186,7 +186,7 @@ def test_rccl_single_rank_drives_the_collective_path(tmp_path):
     two-graph replay around the all-reduce, the route broadcast and the ELBO / gradient reductions all go through RCCL on
     device buffers and must reproduce the oracle (reference src/models/tsvgp.py:278-281, :95 summed over ranks)."""
     out = str(tmp_path / "r0.npz")
-    port = 23500 + (os.getpid() % 2000)
+    port = free_port()
     mp.spawn(_worker_rccl, args=(1, port, out), nprocs=1, join=True)
     got = np.load(out)
     X, Y, Z = synthetic(N=4001, M=160, D=4, lik="bernoulli", seed=12)
@@ -243,7 +243,7 @@ def test_latent_split_over_ranks_matches_oracle(tmp_path, world, backend):
     over gloo, and one rank over RCCL with the collectives forced (all_gather_into_tensor / reduce_scatter_tensor on device
     buffers); against the oracle (reference src/models/tsvgp.py:249-254, 268-303 with K_uu [P, M, M])."""
     out = str(tmp_path / "r0.npz")
-    port = 21500 + (os.getpid() % 2000) + world
+    port = free_port()
     mp.spawn(_worker_split, args=(world, port, out, backend), nprocs=world, join=True)
     got = np.load(out)
     X, Y, Z = synthetic(N=3001, M=130, D=5, P=3, lik="gaussian", seed=13)
@@ -254,3 +254,98 @@ def test_latent_split_over_ranks_matches_oracle(tmp_path, world, backend):
     assert relerr(got["l1"], ora.lambda_1) < 1e-8
     assert relerr(got["L2"], ora.lambda_2) < 1e-8
     assert abs(float(got["elbo"]) - ora.elbo((X, Y))) < 1e-9 * abs(ora.elbo((X, Y)))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE configs[3] ("C4"): configs[2] -- Bernoulli probit, M = 1024, D = 16, fp32 N-arrays -- sharded over the ranks
+# ---------------------------------------------------------------------------------------------------------------------
+C4_ROWS = 6001  # 47 row panels, the last one ragged; uneven shards (3001 + 3000); the fp64 oracle takes ~2 s per step here
+C4_STEPS = 4  # eager, capture + replay, two more replays
+
+
+def _c4_problem():
+    import bench
+
+    w = dict(bench.WORKLOADS["c3"], N=C4_ROWS)
+    assert (w["M"], w["D"], w["lik"], w["dtype"]) == (1024, 16, "bernoulli", "f32")
+    return bench.make_data(w)  # bench.py's own generator: what `bench.py --workload c3 --gpus N` shards
+
+
+def _worker_c4(rank, world, port, out, backend):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        p = pkg()
+        if world == 1:
+            p.distributed.FORCE_COLLECTIVES = True
+        reduces = {"n": 0}
+        real_ar = dist.all_reduce
+
+        def counted(t, *a, **k):
+            if t.numel() > 1000:  # the packed accumulators (M (M + 1) / 2 + M + 3 doubles), not the small bookkeeping ones
+                assert t.dtype == torch.float64 and t.numel() == 1024 * 1025 // 2 + 1024 + 3
+                reduces["n"] += 1
+            return real_ar(t, *a, **k)
+
+        dist.all_reduce = counted
+        X, Y, Z = _c4_problem()
+        Xs, Ys = p.distributed.shard_rows(X, Y)
+        Xd = torch.as_tensor(Xs, dtype=torch.float32, device="cuda:0")
+        Yd = torch.as_tensor(Ys, dtype=torch.float32, device="cuda:0")
+        res = {}
+        for tag, use_graph, fork_min in (("eager", False, None), ("graph", True, None), ("graphfork", True, 0)):
+            m = p.t_SVGP(p.SquaredExponential(1.0, 1.0), p.Bernoulli(), Z, num_data=C4_ROWS, device="cuda:0",
+                         compute_dtype=torch.float32, use_graph=use_graph)
+            if fork_min is not None:  # the capture of a 125 000-row shard: fill and epilogue operands forked onto the side stream
+                m.GRAPH_FORK_MIN_NM = fork_min
+            assert m._reduce() and m._routes(1e-9) == ["direct"]  # D = 16: cond(K_uu) ~ 3, inside the fp32 gate (30)
+            n0 = reduces["n"]
+            for _ in range(C4_STEPS):
+                m.natgrad_step((Xd, Yd), lr=0.8)
+            res[tag + "_reduces"] = reduces["n"] - n0
+            if use_graph:
+                res[tag + "_captured"] = any(isinstance(e, dict) and "tail" in e for e in m._graphs.values())
+            res[tag + "_l1"], res[tag + "_L2"] = m.lambda_1.numpy(), m.lambda_2.cpu().numpy()
+            res[tag + "_elbo"] = float(m.elbo((Xd, Yd)))  # all-reduced over the ranks
+            m.data_parallel = False  # predictions of the first rows of THIS rank's shard: no collective
+            mu, var = m.predict_f(Xd[:300])
+            res[tag + "_mu"], res[tag + "_var"] = mu.cpu().numpy(), var.cpu().numpy()
+        if rank == 0:
+            np.savez(out, **res)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,backend", [(2, "gloo"), (1, "nccl")])
+def test_c4_sharded_fp32_bernoulli_matches_oracle(tmp_path, world, backend):
+    """BASELINE configs[3] as far as one GPU allows: bench.py's `c3` problem (Bernoulli probit GH-20, M = 1024, D = 16, fp32
+    N-arrays, fp64 M x M algebra) at N = 6001, row-sharded over TWO ranks sharing cuda:0 (gloo) and over ONE rank on backend
+    nccl = RCCL with the collectives forced on; eager steps, the two-graph replay around the all-reduce, and the replay with the
+    fill forked inside the capture (what a 125 000-row shard of the 8-GPU run takes).  One all-reduce of the packed fp64
+    accumulators per step (reference src/models/tsvgp.py:278-281, :95 summed over the ranks).  Against the fp64 oracle's
+    single-process steps at SURVEY 8(d)'s fp32 tolerances: moments atol 1e-4 + rtol 1e-3, |dELBO| / |ELBO| <= 1e-4; the three
+    execution modes against each other to summation order."""
+    out = str(tmp_path / "r0.npz")
+    mp.spawn(_worker_c4, args=(world, free_port(), out, backend), nprocs=world, join=True)
+    got = np.load(out)
+    X, Y, Z = _c4_problem()
+    ora = O.t_SVGP(O.SquaredExponential(1.0, 1.0), O.Bernoulli(), Z, num_data=C4_ROWS)
+    for _ in range(C4_STEPS):
+        ora.natgrad_step((X, Y), lr=0.8)
+    e_o = ora.elbo((X, Y))
+    mu_o, var_o = ora.predict_f(X[:300])  # rank 0's shard starts at row 0
+    assert bool(got["graph_captured"]) and bool(got["graphfork_captured"])
+    for tag in ("eager", "graph", "graphfork"):
+        assert int(got[tag + "_reduces"]) == C4_STEPS, tag  # ONE packed all-reduce per step, replayed or not
+        assert abs(float(got[tag + "_elbo"]) - e_o) < 1e-4 * abs(e_o), tag
+        np.testing.assert_allclose(got[tag + "_mu"], mu_o, rtol=1e-3, atol=1e-4, err_msg=tag)
+        np.testing.assert_allclose(got[tag + "_var"], var_o, rtol=1e-3, atol=1e-4, err_msg=tag)
+        # the site parameters themselves: fp32 rounding of K(X, Z) enters the sums of 6001 rows at ~1e-5 relative
+        assert relerr(got[tag + "_l1"], ora.lambda_1) < 2e-3, tag
+        assert relerr(got[tag + "_L2"], ora.lambda_2) < 2e-3, tag
+        # replayed == eager: same kernels, same shards, same summation order
+        assert relerr(got[tag + "_l1"], got["eager_l1"]) < 1e-10 and relerr(got[tag + "_L2"], got["eager_L2"]) < 1e-10, tag

@@ -11,7 +11,7 @@ import torch.multiprocessing as mp
 
 from oracle import tsvgp_oracle as O
 from tests.cpu_engine import NumpyShardEngine
-from tests.helpers import pkg, relerr, synthetic
+from tests.helpers import free_port, pkg, relerr, synthetic
 
 
 def _pair(Z, lik, P=1, num_data=None, kind="plain"):
@@ -206,7 +206,7 @@ def _worker(rank, world, port, lik, P, out, kind="plain"):
 @pytest.mark.parametrize("lik,P", [("gaussian", 1), ("bernoulli", 2)])
 def test_sharded_estep_gloo_world2_matches_single_process_oracle(tmp_path, lik, P):
     out = str(tmp_path / "r0.npz")
-    port = 29500 + (os.getpid() % 2000)
+    port = free_port()
     mp.spawn(_worker, args=(2, port, lik, P, out), nprocs=2, join=True)
     got = np.load(out)
     X, Y, Z = synthetic(N=401, M=20, D=2, P=P, lik=lik, seed=4)
@@ -224,7 +224,7 @@ def test_sharded_variants_gloo_world2(tmp_path, kind, lik, P):
     SPLIT over the ranks by latent (``t_SVGP._step_device_split``: all-gather of the N-pass operands, reduce-scatter of the sums
     by latent, all-gather of the new state; P = 3 on two ranks leaves rank 1 a padded slot)."""
     out = str(tmp_path / "r0.npz")
-    port = 31500 + (os.getpid() % 2000)
+    port = free_port()
     mp.spawn(_worker, args=(2, port, lik, P, out, kind), nprocs=2, join=True)
     got = np.load(out)
     X, Y, Z = synthetic(N=401, M=20, D=2, P=P, lik=lik, seed=4)
@@ -234,6 +234,79 @@ def test_sharded_variants_gloo_world2(tmp_path, kind, lik, P):
     assert relerr(got["l1"], ora.lambda_1) < 1e-9
     assert relerr(got["L2"], ora.lambda_2) < 1e-9
     assert abs(float(got["elbo"]) - ora.elbo((X, Y))) < 1e-9 * abs(ora.elbo((X, Y)))
+
+
+def _worker_split3(rank, world, port, out, inject_failure):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        p = pkg()
+        P = 2
+        X, Y, Z = synthetic(N=401, M=20, D=2, P=P, lik="gaussian", seed=4)
+        Xs, Ys = p.distributed.shard_rows(X, Y)
+        hip, _ = _pair(Z, "gaussian", P, num_data=401, kind="separate")
+        routes = hip._routes(1e-9)
+        assert hip._latent_split(routes)
+        own = [q for q in range(P) if q % world == rank]
+        assert own == ([rank] if rank < P else [])  # rank 2 owns no latent: zero slots, flags from the scalars only
+        demoted = []
+        if inject_failure:
+            # the owner of latent 0 reports a failed FINAL factorisation on the first step (what a direct route that lost
+            # definiteness does): the max-reduced status words must make EVERY rank restore the state, demote and retry
+            real = hip._apply_site_update
+            calls = {"n": 0}
+
+            def flaky(*a, **k):
+                res = real(*a, **k)
+                calls["n"] += 1
+                if rank == 0 and calls["n"] == 1:
+                    flags = res[0].clone()
+                    flags[2] = 1.0
+                    return (flags,) + tuple(res[1:])
+                return res
+
+            hip._apply_site_update = flaky
+            real_demote = dict(hip._DEMOTE)
+
+            class Spy(dict):
+                def get(self, k, d=None):
+                    demoted.append(k)
+                    return real_demote.get(k, d)
+
+            hip._DEMOTE = Spy(real_demote)
+        for _ in range(3):
+            hip.natgrad_step((Xs, Ys), lr=0.8)
+        elbo = float(hip.elbo((Xs, Ys)))
+        np.savez(out + f".{rank}.npz", l1=hip.lambda_1.numpy(), L2=hip.lambda_2.numpy(), elbo=elbo,
+                 demoted=len(demoted), routes_before=np.array(routes), routes_after=np.array(hip._routes(1e-9)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("inject_failure", [False, True])
+def test_latent_split_with_a_rank_that_owns_no_latent(tmp_path, inject_failure):
+    """P = 2 latents on THREE ranks (what P < world does on an 8-GPU node, e.g. P = 3): rank 2 owns no latent, sends zero
+    slots into both all-gathers and takes its status words from the all-reduced scalars alone
+    (``t_SVGP._step_device_split``, the ``own == []`` branch).  With ``inject_failure`` the owner of latent 0 reports a failed
+    final factorisation once: all three ranks -- also the one without a latent -- must see it through the max-reduce, put the
+    state back, move one route down and redo the step together.  Every rank's state against the oracle."""
+    out = str(tmp_path / "r")
+    mp.spawn(_worker_split3, args=(3, free_port(), out, inject_failure), nprocs=3, join=True)
+    X, Y, Z = synthetic(N=401, M=20, D=2, P=2, lik="gaussian", seed=4)
+    _, ora = _pair(Z, "gaussian", 2, num_data=401, kind="separate")
+    for _ in range(3):
+        ora.natgrad_step((X, Y), lr=0.8)
+    for r in range(3):
+        got = np.load(out + f".{r}.npz")
+        assert relerr(got["l1"], ora.lambda_1) < 1e-9
+        assert relerr(got["L2"], ora.lambda_2) < 1e-9
+        assert abs(float(got["elbo"]) - ora.elbo((X, Y))) < 1e-9 * abs(ora.elbo((X, Y)))
+        if inject_failure:
+            assert int(got["demoted"]) == 2  # both latents moved one route down, on every rank
+            down = {"direct": "whitened", "whitened": "projected"}
+            assert list(got["routes_after"]) == [down[r] for r in got["routes_before"]]  # remembered until (theta, Z) change
+        else:
+            assert int(got["demoted"]) == 0
 
 
 def test_cond2_estimate_tracks_the_eigenvalue_ratio():

@@ -408,3 +408,41 @@ def test_row_blocked_evaluators_equal_the_single_call_forms():
         mu, var = m.predict_f(X[:300])
         mu_c, var_c = O.predict_f_chunked(m, X[:300], chunk_rows=64)
         assert np.max(np.abs(mu - mu_c)) < 1e-13 and np.max(np.abs(var - var_c)) < 1e-13
+
+
+@pytest.mark.parametrize("lik,P,separate", [("gaussian", 1, False), ("bernoulli", 2, False), ("gaussian", 3, True)])
+def test_row_blocked_step_is_the_step(lik, P, separate):
+    """``natgrad_step_chunked`` -- the reference's E-step (src/models/tsvgp.py:234-304) with its N-sized ops taken per row block
+    and the block sums of G0 / G1 compensated: what is run at N = 1e6 (full-size state match, measured CPU baseline) -- is
+    ``natgrad_step``: same state, same intermediates, to rounding, over three steps, with a block size that does not divide N;
+    the ELBO it reports for the state a step starts from is ``elbo`` of that state."""
+    from tests.helpers import synthetic
+
+    X, Y, Z = synthetic(N=1203, M=24, D=3, P=P, lik=lik, seed=1)  # cond(K_uu) ~ 1e3: block order shows at ~1e-13 only
+
+    def mk():
+        k = O.SeparateIndependent([O.SquaredExponential(1.0, l) for l in (0.9, 1.1, 1.3)]) if separate else O.SquaredExponential(1.0, 1.0)
+        iv = O.SharedIndependentInducingVariables(Z) if separate else Z
+        return O.t_SVGP(k, O.Gaussian(0.1) if lik == "gaussian" else O.Bernoulli(), iv, num_latent_gps=P, num_data=2000)
+
+    a, b = mk(), mk()
+    rel = lambda x, y: np.max(np.abs(x - y)) / max(np.max(np.abs(y)), 1e-300)  # (the first step's mean is exactly zero)
+    for _ in range(3):
+        # both from the SAME state (bit for bit), so that what is compared is the row blocking alone: near the fixed point
+        # G0 is a small difference of large terms and would amplify a last-digit difference of the states to ~1e-10
+        b.sites.lambda_1, b.sites._lambda_2_sqrt = a.sites.lambda_1.copy(), a.sites._lambda_2_sqrt.copy()
+        e = a.elbo((X, Y))
+        a.natgrad_step((X, Y), lr=0.8)
+        O.natgrad_step_chunked(b, (X, Y), lr=0.8, chunk_rows=100)
+        assert abs(b.last["elbo_before"] - e) < 1e-12 * abs(e)
+        for k in ("mean", "var", "g0", "g1", "G0", "G1", "meanZ"):
+            assert rel(b.last[k], a.last[k]) < 1e-11, k
+        assert rel(b.lambda_1, a.lambda_1) < 1e-11 and rel(b.lambda_2, a.lambda_2) < 1e-11
+
+
+def test_compensated_sum_recovers_what_plain_addition_loses():
+    s = O._CompensatedSum()
+    parts = [np.array([1.0, 1e16]), np.array([1e-3, 1.0]), np.array([-1.0, -1e16]), np.array([1e-3, 1.0])]
+    for x in parts:
+        s.add(x)
+    assert np.allclose(s.value(), [2e-3, 2.0], rtol=1e-15, atol=0)
