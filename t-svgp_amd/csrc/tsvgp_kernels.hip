@@ -1000,8 +1000,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void panel_kernel(PanelArgs<T> a) {
 //     f(row) = (row & 7) ^ ((row >> 3) & 1) on the per-lane global source address and on the reads: conflict free for
 //     ds_read_b64 over each half wave;
 //   * the T fragments of a set are read first and the two A fragments -- operands of the step's LAST MFMAs -- last, and a set's
-//     registers stay occupied to the end of its step: a ds_read landing in an A/B operand register of a
-//     v_mfma_f64_16x16x4_f64 issued just before it corrupted results (the compiler's hazard recognizer does not know it).
+//     registers stay occupied to the end of its step.  Round 3 adopted this order believing that a ds_read landing in an A/B
+//     operand register of a v_mfma_f64_16x16x4_f64 issued just before it had corrupted results.  Round 4 measured it
+//     (tools/hazard_probe.hip; this kernel built with -DTSVGP_HAZARD_AFIRST, i.e. the suspect order, 100-190 such sites at
+//     distance one per instantiation: every parity and repeatability test passes -- profiles/r04_hazard_probe.txt): there is
+//     no such window, the operands are read when the MFMA issues.  The order stays because it costs nothing.  What the stream
+//     really depends on -- the wait state between the write of M0 and the LDS-DMA, five wait states between v_readfirstlane and
+//     a memory instruction using that SGPR as its base, no scratch access among the MFMAs -- nothing pads inside asm volatile,
+//     so tests/test_isa_lint.py checks it on the compiler's assembly (tools/isa_hazards.py).
 // ---------------------------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void lds_void_t;
 constexpr int P1_OPS = TILE * 16;    // 8-byte fragment units per operand image of a chunk (16 KB)
@@ -1199,10 +1205,18 @@ __global__ __launch_bounds__(NTHREADS, 1) void panel1_kernel(PanelArgs<T> a) {
         auto rds = [&](Frag& f, auto slot_tag, auto m_tag, auto ks_tag, auto boff) TSVGP_AI {
             constexpr int S = decltype(slot_tag)::value, MM = decltype(m_tag)::value;
             constexpr int N0 = (TRI == TSVGP_TRI_UPPER) ? 0 : 8 - MM;
+#ifdef TSVGP_HAZARD_AFIRST  // diagnostic build (tools/isa_hazards.py, profiles/r04_hazard_*): the order round 3 saw corrupt results with
+            if constexpr (S < 2) rd1(f, TSVGP_IC(S), ks_tag, boff);
+            else rd1(f, TSVGP_IC(2 + N0 + S - 2), ks_tag, boff);
+#else
             if constexpr (S < MM) rd1(f, TSVGP_IC(2 + N0 + S), ks_tag, boff);
             else rd1(f, TSVGP_IC(S - MM), ks_tag, boff);
+#endif
         };
         auto keep_set = [&](const Frag& f, auto m_tag) TSVGP_AI {  // the set's registers stay occupied up to this point
+#ifdef TSVGP_HAZARD_AFIRST
+            return;
+#endif
             constexpr int MM = decltype(m_tag)::value, N0 = (TRI == TSVGP_TRI_UPPER) ? 0 : 8 - MM;
             cfor<0, 2 + MM>([&](auto e) TSVGP_AI {
                 constexpr int E = decltype(e)::value;

@@ -1006,7 +1006,7 @@ class t_SVGP(base_SVGP):
     def site_sums(self, data, jitter=1e-9):
         """(G0 [M, P], G1 [P, M, M]) of tsvgp.py:279-280 at the CURRENT state -- the N-pass of one E-step on the route
         ``natgrad_step`` would take, mapped back to the reference's coordinates, without updating the state.  Not part of the
-        reference's API: what full-size parity checks (tests/, bench.py's ``state_match``) compare with the oracle's einsums."""
+        reference's API: what full-size parity checks (tests/, bench.py's ``state_match``) compare with the CPU restatement's einsums."""
         X, Y = self._as_device(data[0]), self._as_device(data[1])
         routes = self._routes(jitter)
         st, ops = self._step_front(X, Y, 0.0, jitter, routes)

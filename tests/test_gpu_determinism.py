@@ -1,7 +1,8 @@
 """Bitwise repeatability of the hand-laid kernels at a size where every CU runs several workgroups (tools/determinism_check.py):
 moments / trmm in the upper and lower form and the site sums, fp64 and fp32, four launches each on one input -- all outputs
-bit-identical, the first against a torch fp64 reference.  A timing-dependent fault (the MFMA operand hazard found while building
-panel1_kernel corrupted some lanes differently from run to run) fails the first half of that."""
+bit-identical, the first against a torch fp64 reference.  A timing-dependent fault (the lab kernel of round 3 had lanes corrupted
+differently from run to run: inline-asm memory operations that nothing pads or counts -- the rules of tests/test_isa_lint.py)
+fails the first half of that."""
 import importlib.util
 import os
 

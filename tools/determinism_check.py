@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Bitwise repeatability and large-size correctness of the hand-laid kernels (GPU box).  A timing-dependent fault -- the class
-of the MFMA operand hazard found while building panel1_kernel: a ds_read landing in an operand register of an MFMA issued just
-before it, wrong values in some lanes, different from run to run -- shows up as two launches on the same input disagreeing.
+met while building panel1_kernel: wrong values in some lanes, different from run to run (inline-asm memory operations the
+compiler neither pads nor counts; round 3 blamed an MFMA operand hazard, round 4 measured that none exists:
+profiles/r04_hazard_probe.txt) -- shows up as two launches on the same input disagreeing.
 Every product (moments / trmm in the upper and lower form, site sums; fp64 and fp32) runs REPS times on one input: all outputs
 must be bit-identical, and the first one must match a torch fp64 reference (chunked over rows).
     python tools/determinism_check.py [--rows 262144] [--M 1024] [--reps 12]"""

@@ -6,7 +6,7 @@
 // first, A fragments last, a set's registers kept occupied to the end of its k-step).  This probe measures the WINDOW so that the
 // convention can be checked on the generated code (tests/test_isa_hazards.py) instead of being trusted.
 //
-// One wave per workgroup.  Everything between "operands ready" and "result read" is ONE asm statement, so the compiler inserts
+// One wave per workgroup; the fp64 accumulators live in AGPRs as in the product kernels.  Everything between "operands ready" and "result read" is ONE asm statement, so the compiler inserts
 // nothing:   [K leading MFMAs on other accumulators: the matrix pipe is busy when the target issues]
 //            target:  v_mfma  accT, a, b, accT
 //            [D fillers: s_nop 0 | v_mfma on other registers]
@@ -39,7 +39,7 @@ enum { FILL_NOP = 0, FILL_MFMA = 1 };
 enum { BY_LDS = 0, BY_VALU = 1 };
 
 // K leading MFMAs, D fillers, WHICH operand is overwritten, FILL kind, BY what.
-template <int K, int D, int WHICH, int FILL, int BY>
+template <int K, int D, int WHICH, int FILL, int BY, int CHAIN = 0>
 __global__ __launch_bounds__(64) void probe_f64(const double* __restrict__ in, double* __restrict__ out, int iters) {
     __shared__ double poison[64];
     const int lane = threadIdx.x;
@@ -54,9 +54,15 @@ __global__ __launch_bounds__(64) void probe_f64(const double* __restrict__ in, d
         double fa = a0 * 0.5, fb = b0 * 0.25;  // operands of the leading / filler MFMAs (never overwritten)
         asm volatile(
             "s_nop 7\n\t"
+            ".if %[chain] == 0\n\t"
             ".if %[k] > 0\n\t v_mfma_f64_16x16x4_f64 %[l0], %[fa], %[fb], %[l0]\n\t .endif\n\t"
             ".if %[k] > 1\n\t v_mfma_f64_16x16x4_f64 %[l1], %[fa], %[fb], %[l1]\n\t .endif\n\t"
             ".if %[k] > 2\n\t v_mfma_f64_16x16x4_f64 %[l2], %[fa], %[fb], %[l2]\n\t .endif\n\t"
+            ".else\n\t"  // dependent chain: the target's srcC is the result of the MFMA in front of it
+            ".if %[k] > 0\n\t v_mfma_f64_16x16x4_f64 %[t], %[fa], %[fb], %[t]\n\t .endif\n\t"
+            ".if %[k] > 1\n\t v_mfma_f64_16x16x4_f64 %[t], %[fa], %[fb], %[t]\n\t .endif\n\t"
+            ".if %[k] > 2\n\t v_mfma_f64_16x16x4_f64 %[t], %[fa], %[fb], %[t]\n\t .endif\n\t"
+            ".endif\n\t"
             "v_mfma_f64_16x16x4_f64 %[t], %[a], %[b], %[t]\n\t"
             ".if %[fill] == 0\n\t .rept %[d]\n\t s_nop 0\n\t .endr\n\t .endif\n\t"
             ".if %[fill] == 1\n\t"
@@ -74,11 +80,13 @@ __global__ __launch_bounds__(64) void probe_f64(const double* __restrict__ in, d
             "s_nop 15\n\t s_nop 15\n\t s_nop 15\n\t s_nop 15\n\t s_nop 15\n\t s_nop 15\n\t s_nop 15\n\t s_nop 15\n\t"
             "s_nop 15\n\t s_nop 15\n\t s_nop 15\n\t s_nop 15\n\t s_nop 15\n\t s_nop 15\n\t s_nop 15\n\t s_nop 15\n\t"
             "s_nop 15\n\t s_nop 15\n\t s_nop 15\n\t s_nop 15\n\t s_nop 15\n\t s_nop 15\n\t s_nop 15\n\t s_nop 15\n\t"
-            : [t] "+v"(accT), [a] "+v"(a), [b] "+v"(b), [l0] "+v"(l0), [l1] "+v"(l1), [l2] "+v"(l2), [f0] "+v"(f0), [f1] "+v"(f1)
+            : [t] "+a"(accT), [a] "+v"(a), [b] "+v"(b), [l0] "+a"(l0), [l1] "+a"(l1), [l2] "+a"(l2), [f0] "+a"(f0), [f1] "+a"(f1)
             : [fa] "v"(fa), [fb] "v"(fb), [addr] "v"(addr), [k] "n"(K), [d] "n"(D), [which] "n"(WHICH), [fill] "n"(FILL),
-              [by] "n"(BY)
+              [by] "n"(BY), [chain] "n"(CHAIN)
             : "memory");
         v4d ref = {0, 0, 0, 0};
+        if (CHAIN)
+            for (int q = 0; q < K; ++q) ref = __builtin_amdgcn_mfma_f64_16x16x4f64(fa, fb, ref, 0, 0, 0);
         ref = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, ref, 0, 0, 0);
         for (int j = 0; j < 4; ++j) bad += (accT[j] != ref[j]);
         // keep the side results alive
@@ -163,9 +171,9 @@ Result run(Kern kern, const double* d_in, double* d_out, int blocks, int iters) 
     return r;
 }
 
-template <int K, int WHICH, int FILL, int BY, int D>
+template <int K, int WHICH, int FILL, int BY, int D, int CHAIN = 0>
 void row_f64(const double* d_in, double* d_out, int blocks, int iters, char* buf, size_t n) {
-    Result r = run(probe_f64<K, D, WHICH, FILL, BY>, d_in, d_out, blocks, iters);
+    Result r = run(probe_f64<K, D, WHICH, FILL, BY, CHAIN>, d_in, d_out, blocks, iters);
     snprintf(buf + strlen(buf), n - strlen(buf), " %9ld/%-2d", r.wrong, r.lanes_hit);
 }
 template <int K, int WHICH, int FILL, int BY, int D>
@@ -174,12 +182,12 @@ void row_f32(const double* d_in, double* d_out, int blocks, int iters, char* buf
     snprintf(buf + strlen(buf), n - strlen(buf), " %9ld/%-2d", r.wrong, r.lanes_hit);
 }
 
-template <int K, int WHICH, int FILL, int BY>
+template <int K, int WHICH, int FILL, int BY, int CHAIN = 0>
 void sweep(const char* label, bool f64, const double* d_in, double* d_out, int blocks, int iters) {
     char buf[1024];
     buf[0] = 0;
 #define ROW(D)                                                                    \
-    if (f64) row_f64<K, WHICH, FILL, BY, D>(d_in, d_out, blocks, iters, buf, sizeof(buf)); \
+    if (f64) row_f64<K, WHICH, FILL, BY, D, CHAIN>(d_in, d_out, blocks, iters, buf, sizeof(buf)); \
     else row_f32<K, WHICH, FILL, BY, D>(d_in, d_out, blocks, iters, buf, sizeof(buf));
     if (FILL == FILL_NOP) {
         ROW(0) ROW(1) ROW(2) ROW(3) ROW(4) ROW(6) ROW(8) ROW(12) ROW(16) ROW(24) ROW(32) ROW(48)
@@ -212,6 +220,12 @@ int main() {
         sweep<1, OVER_B, FILL_NOP, BY_LDS>("LDS read -> srcB, K = 1", f64, d_in, d_out, blocks, iters);
         sweep<2, OVER_B, FILL_NOP, BY_LDS>("LDS read -> srcB, K = 2", f64, d_in, d_out, blocks, iters);
         sweep<3, OVER_B, FILL_NOP, BY_LDS>("LDS read -> srcB, K = 3", f64, d_in, d_out, blocks, iters);
+        if (f64) {
+            sweep<1, OVER_A, FILL_NOP, BY_LDS, 1>("LDS read -> srcA, K = 1, DEPENDENT chain (same accumulator)", f64, d_in, d_out, blocks, iters);
+            sweep<3, OVER_A, FILL_NOP, BY_LDS, 1>("LDS read -> srcA, K = 3, DEPENDENT chain", f64, d_in, d_out, blocks, iters);
+            sweep<1, OVER_B, FILL_NOP, BY_LDS, 1>("LDS read -> srcB, K = 1, DEPENDENT chain", f64, d_in, d_out, blocks, iters);
+            sweep<3, OVER_B, FILL_NOP, BY_LDS, 1>("LDS read -> srcB, K = 3, DEPENDENT chain", f64, d_in, d_out, blocks, iters);
+        }
         sweep<0, OVER_A, FILL_NOP, BY_VALU>("control: v_mov -> srcA (VALU write), K = 0", f64, d_in, d_out, blocks, iters);
         sweep<2, OVER_A, FILL_NOP, BY_VALU>("control: v_mov -> srcA (VALU write), K = 2", f64, d_in, d_out, blocks, iters);
         sweep<2, OVER_B, FILL_NOP, BY_VALU>("control: v_mov -> srcB (VALU write), K = 2", f64, d_in, d_out, blocks, iters);

@@ -1,17 +1,26 @@
 #!/usr/bin/env python3
-"""MFMA-operand write-after-read lint over the compiler's own assembly of the hand-laid kernels.
+"""Lint of the compiler's own assembly of the hand-laid kernels: the properties the hand-written instruction streams rely on
+and that nothing else checks (the LLVM hazard recognizer does not look inside ``asm volatile``; a compiler update can move
+registers and wait states silently).  Used by tests/test_isa_lint.py (CPU: hipcc cross-compiles) and from the command line.
 
-The hazard (tools/hazard_probe.hip measures it, profiles/r04_hazard_probe.txt records it): the A / B operand registers of a
-``v_mfma_*`` are not all read when the instruction issues; an LDS (or memory) load whose data returns into one of them shortly
-afterwards changes the product.  The hardware interlocks VALU writes, the LLVM hazard recognizer knows nothing of this one, and
-with the instruction stream pinned by ``sched_barrier`` (panel1_kernel, syrk1_kernel, syrk1f_kernel) the register allocator is
-free to hand a just-read operand register to the next fragment read.  This script finds every
+Rules (``check_rules``):
+  m0          an LDS-DMA (``global_load_lds_*``) reads M0: the instruction in front of it must not be the one that writes M0
+              (one wait state; the kernels put ``s_nop 0`` inside the asm statement).
+  sgpr-vmem   a scalar register written by a VECTOR instruction (``v_readfirstlane_b32`` of the DMA base addresses) needs five
+              wait states in front of a memory instruction that reads it as its scalar base; the kernels make the bases scalar
+              at the START of a chunk, three k-steps before use.
+  scratch     no scratch access in any basic block that holds MFMAs of the one-workgroup-per-CU kernels (512 registers per
+              wave: the whole point of that launch bound; a scratch access in the stream also waits for the LDS-DMA in flight).
 
-    v_mfma  D, srcA, srcB, C   ...  <= WINDOW instructions later ...   ds_read* / global_load* / buffer_load*  -> overlaps srcA|srcB
+And one REPORT (``scan``), no longer a rule: MFMA-operand write-after-read sites.  Round 3 believed that a ``ds_read`` landing
+in an A / B operand register of a ``v_mfma_f64_16x16x4_f64`` issued just before it corrupted results, and kept such reads apart
+by convention.  Round 4 measured it (tools/hazard_probe.hip, profiles/r04_hazard_probe.txt): no window exists -- not with an
+idle pipe, not behind one to three MFMAs in flight, not in a dependent accumulator chain, AGPR or VGPR accumulators, fp64 or
+fp32 -- and a build of panel1_kernel with the A fragments read FIRST and the registers released at once (-DTSVGP_HAZARD_AFIRST:
+100-190 sites at distance 1 in every instantiation) passes every kernel parity test and the bitwise-repeatability check.  The
+operands are read when the MFMA issues.  The scan stays as a report so that a future anomaly can be correlated with it.
 
-following fall-through and branch edges backwards (loop back-edges included), and prints / returns the sites.
-
-    python tools/isa_hazards.py [--window N] [--asm k.s]        exits 1 when a site is found inside the window
+    python tools/isa_hazards.py [--window N] [--asm k.s]        exits 1 when a RULE is violated
 """
 import argparse
 import os
@@ -134,6 +143,119 @@ def scan(text, window):
     return sites
 
 
+SREG = re.compile(r"\bs\[(\d+):(\d+)\]|\bs(\d+)\b")
+
+
+def sregs(text):
+    out = set()
+    for m in SREG.finditer(text):
+        if m.group(1):
+            out |= set(range(int(m.group(1)), int(m.group(2)) + 1))
+        else:
+            out.add(int(m.group(3)))
+    return out
+
+
+def wait_states(t):
+    """Wait states an instruction provides to what follows it: s_nop N gives N + 1, everything else 1."""
+    m = re.match(r"s_nop\s+(\d+)", t)
+    return int(m.group(1)) + 1 if m else 1
+
+
+def all_kernels(text):
+    """Every kernel of the file that issues LDS-DMA or belongs to the hand-laid set."""
+    out = {}
+    for m in re.finditer(r"^(_Z\w+):", text, re.M):
+        end = text.find("s_endpgm", m.end())
+        body = text[m.end():end]
+        if "global_load_lds" in body or any(t in m.group(1) for t in KERNEL_TAGS):
+            out[m.group(1)] = body
+    return out
+
+
+def check_rules(text):
+    """[(rule, kernel, label, message)] for every violated rule."""
+    bad = []
+    ks = kernels(text)
+    extra = {k: None for k in all_kernels(text) if k not in ks}
+    for name in list(ks) + list(extra):
+        if name in ks:
+            blocks = ks[name]
+        else:  # a kernel outside the hand-laid set that issues LDS-DMA: same parsing
+            blocks = _blocks_of(text, name)
+        preds = predecessors(blocks)
+
+        def walk_back(bi, pos, budget, visit, seen):
+            """visit(instruction) for the instructions in front of (bi, pos), nearest first, while `budget` wait states last;
+            visit returns True to stop that path."""
+            _, ins = blocks[bi]
+            j = pos - 1
+            while j >= 0 and budget > 0:
+                if visit(ins[j], budget):
+                    return
+                budget -= wait_states(ins[j])
+                j -= 1
+            if budget > 0:
+                for p_ in preds[bi]:
+                    if (p_, budget) not in seen:
+                        seen.add((p_, budget))
+                        walk_back(p_, len(blocks[p_][1]), budget, visit, seen)
+
+        one_wg = ("panel1_kernel" in name or "syrk1_kernel" in name)
+        for bi, (label, ins) in enumerate(blocks):
+            if one_wg and any(t.startswith("v_mfma") for t in ins) and any(t.startswith("scratch_") for t in ins):
+                bad.append(("scratch", name, label, "scratch access in a basic block that holds MFMAs"))
+            for pos, t in enumerate(ins):
+                op = t.split()[0]
+                if op.startswith("global_load_lds") or (op.startswith("buffer_load") and " lds" in t):
+                    def m0_writer(prev, budget, t=t, label=label):
+                        if re.match(r"s_\w+\s+m0\b", prev):
+                            bad.append(("m0", name, label, f"'{prev}' directly in front of '{t}'"))
+                        return True  # only the instruction directly in front matters (one wait state)
+                    walk_back(bi, pos, 1, m0_writer, set())
+                if op.startswith(("global_load", "global_store", "buffer_load", "buffer_store", "global_atomic")):
+                    ops_ = split_operands(t)
+                    used = set()
+                    for o in ops_:
+                        if re.match(r"^s(\[|\d)", o.strip()):
+                            used |= sregs(o)
+                    if used:
+                        def valu_writer(prev, budget, t=t, label=label, used=used):
+                            if prev.startswith(("v_readfirstlane", "v_readlane")):
+                                dst = sregs(split_operands(prev)[0])
+                                if dst & used:
+                                    bad.append(("sgpr-vmem", name, label,
+                                                f"'{prev}' only {5 - budget + 1} wait state(s) in front of '{t}' (needs 5)"))
+                                    return True
+                            return False
+                        walk_back(bi, pos, 5, valu_writer, set())
+    return bad
+
+
+def _blocks_of(text, name):
+    m = re.search(r"^" + re.escape(name) + r":", text, re.M)
+    body = text[m.end():text.find("s_endpgm", m.end())].split("\n")
+    blocks, cur = [], ("entry", [])
+    for ln in body:
+        t = ln.split(";")[0].strip()
+        lab = re.match(r"^(\.LBB\d+_\d+):", ln.strip())
+        if lab:
+            blocks.append(cur)
+            cur = (lab.group(1), [])
+        elif t and not t.startswith("."):
+            cur[1].append(t)
+    blocks.append(cur)
+    return blocks
+
+
+def vgpr_counts(text):
+    """{kernel symbol: VGPRs} from the metadata of the assembly (.vgpr_count)."""
+    out = {}
+    for m in re.finditer(r"\.name:\s+(\S+)\s*\n(?:.*\n)*?\s*\.vgpr_count:\s+(\d+)", text):
+        out[m.group(1)] = int(m.group(2))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--window", type=int, default=8, help="instructions between the MFMA and the load that count as a site")
@@ -156,8 +278,12 @@ def main():
         print(f"  {name}: {len(found)} site(s)" + (f", by distance {dict(sorted(hist.items()))}" if found else ""))
         for s in sorted(found, key=lambda s: s[2])[:6]:
             print(f"      {s[1]}: distance {s[2]} ({s[3]} MFMAs between)   {s[4]}   ->   {s[5]}")
+    bad = check_rules(text)
+    print(f"rules (m0 wait state, VALU-written SGPR -> VMEM base, no scratch in the MFMA stream): {len(bad)} violation(s)")
+    for b in bad[:40]:
+        print("   ", *b)
     lim = args.fail_within
-    if lim is not None and any(s[2] <= lim for s in sites):
+    if bad or (lim is not None and any(s[2] <= lim for s in sites)):
         sys.exit(1)
 
 
