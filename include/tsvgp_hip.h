@@ -239,6 +239,21 @@ int tsvgp_site_accum_batched_f32(const float *B, int64_t strideB, const float *g
 int tsvgp_potrf_f64(double *A, int M, int lda, int batch, int64_t stride, int32_t *info, double *work, int flags,
                     void *stream);
 
+/* (6a) Factor AND solve in one pass: the buffer of matrix b holds, directly below its M rows, `rhs_rows` further rows B
+ *     [rhs_rows x M] (same lda; stride >= (M + rhs_rows) * lda).  They ride through the factorisation as panel rows -- every
+ *     block step solves them against the diagonal block and applies the trailing update to them with the same tile kernels --
+ *     and come out as  B L^-T  (= (L^-1 B^T)^T: the triangular solve of reference src/util.py:173, D = chol(W)^-1 L^T, without
+ *     the inverse factor of (6b), its recursion levels and the GEMM that applied it).  rhs_rows a multiple of 128.
+ *     TSVGP_POTRF_RHS_UPPER: B is block upper triangular (row block i zero in the column blocks < i), as J L J of a lower
+ *     triangular L is -- the zero blocks are skipped.  work, info, TSVGP_POTRF_SUBST as in (6). */
+#define TSVGP_POTRF_RHS_UPPER 2
+int tsvgp_potrf_solve_f64(double *A, int M, int lda, int batch, int64_t stride, int32_t *info, double *work, int rhs_rows,
+                          int flags, void *stream);
+/*     dst[b][i][j] = i <= j ? src[b][M-1-j][M-1-i] : 0  on the leading M x M block: transpose + index reversal + upper triangle
+ *     in one pass -- what turns the solved rows (J L J) C^-T of (6a) into the upper triangular D = U_W^-1 L^T. */
+int tsvgp_flip_transpose_f64(const double *src, int lds, int64_t sstride, double *dst, int ldd, int64_t dstride, int M, int batch,
+                             void *stream);
+
 /* (6b) The same factorisation plus the inverse factor: X[b] = inv(L[b]) (lower triangular, exact zeros above) and
  *     Xt[b] = X[b]^T, both [batch x M x M] row-major (leading dimension M).  The inverted diagonal blocks the panel
  *     solve needs anyway are combined by the 2x2 block recursion inv([[A,0],[C,B]]) = [[A^-1,0],[-B^-1 C A^-1, B^-1]]
@@ -266,6 +281,17 @@ int tsvgp_tri_copy_f64(const double *src, int lds, int64_t sstride, double *dst,
  *     read.  All matrices [P x M x M] contiguous. */
 int tsvgp_site_target_f64(const double *G1, const double *LLt, double *target, double *G1s, int M, int P, double c_ll,
                           double c_g, double jitter, const double *rows, double num_data, void *stream);
+
+/* (7b') The elementwise part of the site update in one call (reference src/util.py:429-438, src/models/tsvgp.py:284-300):
+ *        Gs     = (G1 + G1^T) / 2
+ *        target = (1 - lr) LLt - 2 lr s Gs + jitter I                      (what (7b) writes)
+ *        l1_new = (1 - lr) l1_old + lr s (G0 - 2 Gs meanZ)                  (the chain rule of util.py:436 and the update of :296)
+ *     G1, LLt, target [P x M x M]; G0, meanZ, l1_old, l1_new [M x P]; all contiguous; s and `rows` as in (7b);
+ *     work: P * ceil(M / 32) * M doubles (per-tile partial row sums, added in a fixed order).  Replaces (7b), a matrix-vector
+ *     product and about ten elementwise launches on the replicated critical path of a step (two launches). */
+int tsvgp_site_update_f64(const double *G1, const double *G0, const double *LLt, const double *meanZ, const double *l1_old,
+                          double *target, double *l1_new, double *work, int M, int P, double lr, double jitter, const double *rows,
+                          double num_data, void *stream);
 
 /* (7c) Status word of one step: flags[0] = sum |info_a| (prelude factorisations), flags[1] = nonpos[0] (count of
  *     non-positive predictive variances, the assert_positive of :113; NULL = 0), flags[2] = sum |info_b| (the final

@@ -26,6 +26,7 @@ LIK_MEANONLY = 0x200
 KERNEL_SE, KERNEL_MATERN32, KERNEL_MATERN52 = 0, 2, 3
 TRI_LOWER, TRI_UPPER, TRI_DENSE = 0, 1, 2
 POTRF_SUBST = 1  # TSVGP_POTRF_SUBST
+POTRF_RHS_UPPER = 2  # TSVGP_POTRF_RHS_UPPER
 ABI_VERSION = 3  # TSVGP_ABI_VERSION of include/tsvgp_hip.h these prototypes were written for
 
 _lib = None
@@ -107,11 +108,15 @@ _PROTOTYPES = {
     "tsvgp_site_accum_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     "tsvgp_site_accum_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     "tsvgp_potrf_f64": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_void_p, c_int, c_void_p]),
+    "tsvgp_potrf_solve_f64": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "tsvgp_flip_transpose_f64": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int, c_int64, c_int, c_int, c_void_p]),
     "tsvgp_potrf_inv_f64": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_int, c_void_p]),
     "tsvgp_tri_copy_f64": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int, c_int64, c_int, c_int, c_double, c_int, c_void_p]),
     "tsvgp_site_target_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_double, c_double, c_double, c_void_p,
                                       c_double, c_void_p]),
+    "tsvgp_site_update_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                      c_double, c_double, c_void_p, c_double, c_void_p]),
     "tsvgp_step_status_f64": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "tsvgp_sym_pack_f64": (c_int, [c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "tsvgp_sym_unpack_f64": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p]),

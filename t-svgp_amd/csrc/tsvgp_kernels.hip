@@ -374,7 +374,10 @@ struct FillBatch {
 template <typename T, int KIND, int DT>
 __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, TSVGP_FILL_MAXWAVES))) void se_fill_kernel(
     const T* __restrict__ X, const T* __restrict__ Z, const T* __restrict__ inv_ls, FillBatch<T> var, T* __restrict__ K,
-    int64_t strideK, int64_t N, int M, int D, int64_t ldk, int64_t rows_pad, int cols_pad, int stream_out) {
+    int64_t strideK, int64_t N, int M, int D, int64_t ldk, int64_t rows_pad, int cols_pad, int stream_out, int rows_blk) {
+    // rows_blk <= FILL_ROWS: rows per block.  FILL_ROWS for the N-sized operand; a SMALL matrix -- K(Z, Z), which opens the
+    // replicated M x M chain of every step -- takes 8, i.e. eight times as many workgroups (M = 1024: 256 instead of 32:
+    // the launch was 50-60 us of a chain whose every microsecond is on the critical path of an 8-way shard)
     __shared__ __attribute__((aligned(16))) T Xs[FILL_ROWS][DT];  // pre-scaled by inv_ls
     typedef typename Mfma<T>::pair_t pair_t;
 
@@ -396,10 +399,10 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, TSV
     }
     // Row blocks are dealt round-robin to the workgroups of a column tile.  The default grid has one workgroup per
     // row block; a smaller grid (tsvgp_kernel_fill's cap) leaves CU slots free for work on another stream.
-    const int64_t nrb = (rows_pad + FILL_ROWS - 1) / FILL_ROWS;
+    const int64_t nrb = (rows_pad + rows_blk - 1) / rows_blk;
     for (int64_t rb = rb_first; rb < nrb; rb += rb_step) {
-        const int64_t n0 = rb * FILL_ROWS;
-        for (int idx = t; idx < FILL_ROWS * DT; idx += NTHREADS) {
+        const int64_t n0 = rb * rows_blk;
+        for (int idx = t; idx < rows_blk * DT; idx += NTHREADS) {
             const int rr = idx / DT, d = idx - rr * DT;
             const int64_t n = n0 + rr;
             Xs[rr][d] = (n < N && d < D) ? X[n * D + d] * inv_ls[d] : T(0);
@@ -409,8 +412,8 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, TSV
             // row counts of this block as wave-uniform ints: valid rows get kernel values, the padding rows up to
             // rows_pad zeros.  Invalid columns of the last pair come out as exact zeros through their variance factor.
             const int64_t left = N - n0, left_pad = rows_pad - n0;
-            const int nvalid = left >= FILL_ROWS ? FILL_ROWS : (left > 0 ? (int)left : 0);
-            const int nrows = left_pad >= FILL_ROWS ? FILL_ROWS : (int)left_pad;
+            const int nvalid = left >= rows_blk ? rows_blk : (left > 0 ? (int)left : 0);
+            const int nrows = left_pad >= rows_blk ? rows_blk : (int)left_pad;
             T* const Kp = K + n0 * ldk + m;
             for (int rr = 0; rr < nvalid; ++rr) {
                 T s0 = T(0), s1 = T(0);
@@ -2937,9 +2940,12 @@ __global__ __launch_bounds__(CH_THREADS) void potrf_diag_kernel(double* __restri
 //   OP 0 (panel):  A[i, k] <- A[i, k] * inv(L_kk)^T   one workgroup = the four 32-column tiles of a 32-row block; the
 //                  block is overwritten in place, so all four waves finish reading before any of them stores
 //   OP 1 (update): A[i, j] <- A[i, j] - A[i, k] * A[j, k]^T   over the lower 32x32 tiles of the trailing matrix
+//   Right-hand-side rows (tsvgp_potrf_solve_f64): `ext32` further 32-row blocks directly below row M of the same buffer ride along
+//   as panel rows -- OP 0 takes them as more row blocks of the panel (the grid is simply longer), OP 1 as a rectangle of
+//   ext32 x nb32 tiles behind the triangle -- so that after the last block step they hold  B L^-T.
 template <int OP>
 __global__ __launch_bounds__(NTHREADS) void chol_tile_kernel(double* __restrict__ Amat, int lda, int64_t stride, int k,
-                                                             int nt, const double* __restrict__ work) {
+                                                             int nt, const double* __restrict__ work, int ext32) {
     __builtin_amdgcn_s_setprio(TSVGP_CHOL_PRIO);
     const int lane = threadIdx.x & 63, li = lane & 15, g = lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -2954,12 +2960,19 @@ __global__ __launch_bounds__(NTHREADS) void chol_tile_kernel(double* __restrict_
         tj = w;
     } else {
         const int wid = blockIdx.x * (NTHREADS / 64) + w;
-        active = wid < nb32 * (nb32 + 1) / 2;
-        int r = (int)((sqrtf(8.0f * (float)wid + 1.0f) - 1.0f) * 0.5f);
-        while (r * (r + 1) / 2 > wid) --r;
-        while ((r + 1) * (r + 2) / 2 <= wid) ++r;
-        ti = r;
-        tj = wid - r * (r + 1) / 2;
+        const int ntri = nb32 * (nb32 + 1) / 2;
+        active = wid < ntri + ext32 * nb32;
+        if (wid < ntri) {
+            int r = (int)((sqrtf(8.0f * (float)wid + 1.0f) - 1.0f) * 0.5f);
+            while (r * (r + 1) / 2 > wid) --r;
+            while ((r + 1) * (r + 2) / 2 <= wid) ++r;
+            ti = r;
+            tj = wid - r * (r + 1) / 2;
+        } else {  // right-hand-side rows: row block nb32 + e (the first row behind the matrix is row base + 32 nb32 = M)
+            const int r = wid - ntri, q = nb32 > 0 ? r / nb32 : 0;
+            ti = nb32 + q;
+            tj = r - q * nb32;
+        }
     }
     v4d acc[2][2];
 #pragma unroll
@@ -3212,6 +3225,30 @@ __global__ __launch_bounds__(NTHREADS) void tri_copy_kernel(const double* __rest
     dst[(size_t)b * dstride + (size_t)i * ldd + j] = v;
 }
 
+// dst[b][i][j] = (i <= j) ? src[b][M - 1 - j][M - 1 - i] : 0  -- transpose and index reversal in one pass, through a padded
+// LDS tile so that both sides are coalesced.  What turns the solved right-hand-side rows of tsvgp_potrf_solve_f64,
+// (J L J) C^-T = (C^-1 J L^T J)^T, into the upper triangular D = U_W^-1 L^T = J (C^-1 J L^T J) J of reference src/util.py:173.
+__global__ __launch_bounds__(NTHREADS) void flip_transpose_kernel(const double* __restrict__ src, int lds_, int64_t sstride,
+                                                                  double* __restrict__ dst, int ldd, int64_t dstride, int M) {
+    __shared__ double tile[32][33];
+    const int b = blockIdx.z, i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    if (j0 + 31 < i0) {  // wholly below the diagonal: zeros
+        for (int r = ty; r < 32; r += 8)
+            if (i0 + r < M && j0 + tx < M) dst[(size_t)b * dstride + (size_t)(i0 + r) * ldd + j0 + tx] = 0.0;
+        return;
+    }
+    for (int r = ty; r < 32; r += 8) {  // tile[r][c] = src[M - 1 - (j0 + r)][M - 1 - (i0 + c)]: c runs along a source row
+        const int sr = M - 1 - (j0 + r), sc = M - 1 - (i0 + tx);
+        tile[r][tx] = (sr >= 0 && sc >= 0) ? src[(size_t)b * sstride + (size_t)sr * lds_ + sc] : 0.0;
+    }
+    __syncthreads();
+    for (int c = ty; c < 32; c += 8) {  // dst[i0 + c][j0 + r] = tile[r][c]
+        const int i = i0 + c, j = j0 + tx;
+        if (i < M && j < M) dst[(size_t)b * dstride + (size_t)i * ldd + j] = (i <= j) ? tile[tx][c] : 0.0;
+    }
+}
+
 // target[p][i][j] = c_ll * LLt[p][i][j] + c_g * s * G1s[i][j] + jitter * (i == j),  G1s = (G1 + G1^T) / 2 (also written out),
 // s = num_data / rows (rows: a device scalar, the all-reduced row count) or 1 when num_data <= 0.
 // The matrix of the final factorisation of one E-step, reference src/models/tsvgp.py:286-300:
@@ -3239,6 +3276,66 @@ __global__ __launch_bounds__(NTHREADS) void site_target_kernel(const double* __r
             target[o] = c_ll * LLt[o] + c_g * s * g + (i == j ? jitter : 0.0);
         }
     }
+}
+
+// The elementwise part of the site update in TWO launches (round 4; it was site_target_kernel + a gemv + ~10 torch launches of
+// 4-6 us each on the replicated critical path), reference src/util.py:429-438 and src/models/tsvgp.py:284-300:
+//   Gs      = (G1 + G1^T) / 2
+//   target  = (1 - lr) L L^T - 2 lr s Gs + jitter I                    (the matrix of the final factorisation, :293-300)
+//   l1_new  = (1 - lr) l1_old + lr s (G0 - 2 Gs meanZ)                  (:284, :296; util.py:436)
+// with s = num_data / rows (device scalar) or 1.  site_update_kernel: one workgroup per 32 x 32 tile (the transposed tile
+// through LDS, as site_target_kernel) writes the tile of `target` and the tile's share of Gs meanZ, 32 partial row sums, to
+// `part` [P][M/32 column tiles][M]; site_update_finish_kernel adds the column tiles in a fixed order (bitwise reproducible)
+// and finishes lambda_1.  (A first version swept a row block's tiles in ONE workgroup: 32 workgroups, 124 us at M = 1024.)
+__global__ __launch_bounds__(NTHREADS) void site_update_kernel(const double* __restrict__ G1, const double* __restrict__ LLt,
+                                                               const double* __restrict__ meanZ, double* __restrict__ target,
+                                                               double* __restrict__ part, int M, int P, double lr, double jitter,
+                                                               const double* __restrict__ rows, double num_data) {
+    __shared__ double tile[32][33];
+    __shared__ double mz[32];
+    const int p = blockIdx.z;
+    const size_t base = (size_t)p * M * M;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+    const double s = num_data > 0.0 ? num_data / rows[0] : 1.0;
+    const double c_ll = 1.0 - lr, c_g = -2.0 * lr * s;
+    for (int r = ty; r < 32; r += 8) {  // the transposed tile G1[j0.., i0..]
+        const int jj = j0 + r, ii = i0 + tx;
+        tile[r][tx] = (jj < M && ii < M) ? G1[base + (size_t)jj * M + ii] : 0.0;
+    }
+    if (threadIdx.x < 32) mz[threadIdx.x] = (j0 + threadIdx.x < M) ? meanZ[(size_t)(j0 + threadIdx.x) * P + p] : 0.0;
+    __syncthreads();
+    const int ntj = (M + 31) / 32;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = ty + 8 * q, i = i0 + r, j = j0 + tx;
+        double v = 0.0;
+        if (i < M && j < M) {
+            const size_t o = base + (size_t)i * M + j;
+            const double g = 0.5 * (G1[o] + tile[tx][r]);
+            target[o] = c_ll * LLt[o] + c_g * g + (i == j ? jitter : 0.0);
+            v = g * mz[tx];
+        }
+        v += __shfl_xor(v, 16);  // over the 32 columns of the tile (a half wave): fixed order
+        v += __shfl_xor(v, 8);
+        v += __shfl_xor(v, 4);
+        v += __shfl_xor(v, 2);
+        v += __shfl_xor(v, 1);
+        if (tx == 0 && i < M) part[((size_t)p * ntj + blockIdx.x) * M + i] = v;
+    }
+}
+__global__ __launch_bounds__(NTHREADS) void site_update_finish_kernel(const double* __restrict__ part, const double* __restrict__ G0,
+                                                                      const double* __restrict__ l1_old, double* __restrict__ l1_new,
+                                                                      int M, int P, double lr, const double* __restrict__ rows,
+                                                                      double num_data) {
+    const int i = blockIdx.x * NTHREADS + threadIdx.x, p = blockIdx.y;
+    if (i >= M) return;
+    const double s = num_data > 0.0 ? num_data / rows[0] : 1.0;
+    const int ntj = (M + 31) / 32;
+    double v = 0.0;
+    for (int jb = 0; jb < ntj; ++jb) v += part[((size_t)p * ntj + jb) * M + i];
+    const size_t o = (size_t)i * P + p;
+    l1_new[o] = (1.0 - lr) * l1_old[o] + lr * s * (G0[o] - 2.0 * v);
 }
 
 // flags[0] = sum |info_a|, flags[1] = nonpos (as is, NaN included), flags[2] = sum |info_b|   (t_SVGP._status_flags)
@@ -3440,7 +3537,8 @@ int kernel_fill(int kind, const T* X, const T* Z, const T* inv_ls, const T* vari
     if (D > 32) return TSVGP_EINVAL;  // input dimensions are padded to a compile-time size (1, 2, 4, 8, 16, 32)
     FillBatch<T> var{};
     for (int q = 0; q < P; ++q) var.v[q] = variance[q];
-    dim3 grid((unsigned)((rows_pad + FILL_ROWS - 1) / FILL_ROWS), (unsigned)((cols_pad + FILL_COLS - 1) / FILL_COLS),
+    const int rows_blk = rows_pad <= 4096 ? 8 : FILL_ROWS;  // (rows_pad is a multiple of 128: both divide it)
+    dim3 grid((unsigned)((rows_pad + rows_blk - 1) / rows_blk), (unsigned)((cols_pad + FILL_COLS - 1) / FILL_COLS),
               (unsigned)P);
 #ifdef TSVGP_FILL_GRID_CAP  // experiment build (tools/exp_overlap2.py): fewer, looping workgroups
     if ((unsigned)(TSVGP_FILL_GRID_CAP) < grid.x) grid.x = (unsigned)(TSVGP_FILL_GRID_CAP);
@@ -3457,7 +3555,7 @@ int kernel_fill(int kind, const T* X, const T* Z, const T* inv_ls, const T* vari
 #endif
 #define TSVGP_FILL_LAUNCH(KIND_, DT_)                                                                                 \
     hipLaunchKernelGGL((se_fill_kernel<T, KIND_, DT_>), grid, dim3(NTHREADS), 0, (hipStream_t)stream, X, Z, inv_ls,   \
-                       var, K, strideK, N, M, D, ldk, rows_pad, cols_pad, stream_out)
+                       var, K, strideK, N, M, D, ldk, rows_pad, cols_pad, stream_out, rows_blk)
 #define TSVGP_FILL_DT(KIND_)                          \
     switch (DT) {                                     \
         case 1: TSVGP_FILL_LAUNCH(KIND_, 1); break;   \
@@ -3722,9 +3820,12 @@ int site_accum_slots() {
 }
 
 int potrf(double* A, int M, int lda, int batch, int64_t stride, int* info, double* work, int flags, void* stream,
-          double* X = nullptr, double* Xt = nullptr, double* T = nullptr) {
-    if (!A || !info || !work || M <= 0 || (M % CH_NB) || lda < M || batch <= 0 || (flags & ~TSVGP_POTRF_SUBST))
+          double* X = nullptr, double* Xt = nullptr, double* T = nullptr, int rhs_rows = 0) {
+    if (!A || !info || !work || M <= 0 || (M % CH_NB) || lda < M || batch <= 0 ||
+        (flags & ~(TSVGP_POTRF_SUBST | TSVGP_POTRF_RHS_UPPER)) || rhs_rows < 0 || (rhs_rows % CH_NB) ||
+        (rhs_rows > 0 && stride < (int64_t)(M + rhs_rows) * lda))
         return TSVGP_EINVAL;
+    const bool rhs_upper = (flags & TSVGP_POTRF_RHS_UPPER) != 0;
     const bool inv = X != nullptr, subst = (flags & TSVGP_POTRF_SUBST) != 0;
     if (inv && (!Xt || !T)) return TSVGP_EINVAL;
     const int nt = M / CH_NB;
@@ -3751,19 +3852,24 @@ int potrf(double* A, int M, int lda, int batch, int64_t stride, int* info, doubl
     // three workgroups of the K(X, Z) fill on one CU (with 18 KB it no longer fits and waits: 1.22 vs 0.96 ms under the fill).
     const int wpb = NTHREADS / 64;
     for (int k = 0; k < nt; ++k) {
-        hipLaunchKernelGGL(potrf_diag_kernel, dim3(batch), dim3(CH_THREADS), smem, st, A, lda, stride, k, work, info,
-                           (inv || (k + 1 < nt && !subst)) ? 1 : 0, X, Xt, M, xstride);
+        // right-hand-side rows that column block k can reach: all of them, or (block upper triangular B) its row blocks 0 .. k
+        const int ext_rows = rhs_upper ? (rhs_rows < (k + 1) * CH_NB ? rhs_rows : (k + 1) * CH_NB) : rhs_rows;
         const int below = nt - k - 1;
-        if (below > 0) {
-            const int nb32 = below * (CH_NB / CH_WT), ntile = nb32 * (nb32 + 1) / 2;
+        hipLaunchKernelGGL(potrf_diag_kernel, dim3(batch), dim3(CH_THREADS), smem, st, A, lda, stride, k, work, info,
+                           (inv || ((below > 0 || ext_rows > 0) && !subst)) ? 1 : 0, X, Xt, M, xstride);
+        if (below > 0 || ext_rows > 0) {
+            // the panel: the matrix rows below the diagonal block and, contiguous with them (row M on), the right-hand-side rows
+            const int nb32 = below * (CH_NB / CH_WT), ext32 = ext_rows / CH_WT;
+            const int ntile = nb32 * (nb32 + 1) / 2 + ext32 * nb32;
             if (subst)
-                hipLaunchKernelGGL(chol_panel_subst_kernel, dim3(below * (CH_NB / PS_ROWS), batch), dim3(NTHREADS), 0, st, A,
-                                   lda, stride, k);
+                hipLaunchKernelGGL(chol_panel_subst_kernel, dim3((below * CH_NB + ext_rows) / PS_ROWS, batch), dim3(NTHREADS), 0,
+                                   st, A, lda, stride, k);
             else
-                hipLaunchKernelGGL(chol_tile_kernel<0>, dim3(nb32, batch), dim3(NTHREADS), 0, st, A, lda, stride, k, nt,
-                                   work);
-            hipLaunchKernelGGL(chol_tile_kernel<1>, dim3((ntile + wpb - 1) / wpb, batch), dim3(NTHREADS), 0, st, A,
-                               lda, stride, k, nt, work);
+                hipLaunchKernelGGL(chol_tile_kernel<0>, dim3(nb32 + ext32, batch), dim3(NTHREADS), 0, st, A, lda, stride, k, nt,
+                                   work, ext32);
+            if (ntile > 0)
+                hipLaunchKernelGGL(chol_tile_kernel<1>, dim3((ntile + wpb - 1) / wpb, batch), dim3(NTHREADS), 0, st, A,
+                                   lda, stride, k, nt, work, ext32);
         }
     }
     if (inv) {
@@ -3957,6 +4063,19 @@ int tsvgp_potrf_f64(double* A, int M, int lda, int batch, int64_t stride, int* i
                     void* stream) {
     return potrf(A, M, lda, batch, stride, info, work, flags, stream);
 }
+int tsvgp_potrf_solve_f64(double* A, int M, int lda, int batch, int64_t stride, int* info, double* work, int rhs_rows,
+                          int flags, void* stream) {
+    if (rhs_rows <= 0) return TSVGP_EINVAL;
+    return potrf(A, M, lda, batch, stride, info, work, flags, stream, nullptr, nullptr, nullptr, rhs_rows);
+}
+int tsvgp_flip_transpose_f64(const double* src, int lds, int64_t sstride, double* dst, int ldd, int64_t dstride, int M, int batch,
+                             void* stream) {
+    if (!src || !dst || M <= 0 || lds < M || ldd < M || batch <= 0 || batch > 65535) return TSVGP_EINVAL;
+    const unsigned nb = (unsigned)((M + 31) / 32);
+    hipLaunchKernelGGL(flip_transpose_kernel, dim3(nb, nb, (unsigned)batch), dim3(NTHREADS), 0, (hipStream_t)stream, src, lds,
+                       sstride, dst, ldd, dstride, M);
+    return launch_status();
+}
 int tsvgp_potrf_inv_f64(double* A, int M, int lda, int batch, int64_t stride, int* info, double* work, double* X,
                         double* Xt, double* T, int flags, void* stream) {
     if (!X || !Xt || !T) return TSVGP_EINVAL;
@@ -3978,6 +4097,19 @@ int tsvgp_site_target_f64(const double* G1, const double* LLt, double* target, d
     const unsigned nb = (unsigned)((M + 31) / 32);
     hipLaunchKernelGGL(site_target_kernel, dim3(nb, nb, (unsigned)P), dim3(NTHREADS), 0, (hipStream_t)stream, G1, LLt, target,
                        G1s, M, c_ll, c_g, jitter, rows, num_data);
+    return launch_status();
+}
+int tsvgp_site_update_f64(const double* G1, const double* G0, const double* LLt, const double* meanZ, const double* l1_old,
+                          double* target, double* l1_new, double* work, int M, int P, double lr, double jitter,
+                          const double* rows, double num_data, void* stream) {
+    if (!G1 || !G0 || !LLt || !meanZ || !l1_old || !target || !l1_new || !work || M <= 0 || P <= 0 || P > 65535 ||
+        (num_data > 0.0 && !rows))
+        return TSVGP_EINVAL;
+    const unsigned nb = (unsigned)((M + 31) / 32);
+    hipLaunchKernelGGL(site_update_kernel, dim3(nb, nb, (unsigned)P), dim3(NTHREADS), 0, (hipStream_t)stream, G1, LLt, meanZ,
+                       target, work, M, P, lr, jitter, rows, num_data);
+    hipLaunchKernelGGL(site_update_finish_kernel, dim3((unsigned)((M + NTHREADS - 1) / NTHREADS), (unsigned)P), dim3(NTHREADS), 0,
+                       (hipStream_t)stream, work, G0, l1_old, l1_new, M, P, lr, rows, num_data);
     return launch_status();
 }
 int tsvgp_step_status_f64(const int32_t* info_a, int na, const int32_t* info_b, int nb, const double* nonpos, double* flags,

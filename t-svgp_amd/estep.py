@@ -241,15 +241,65 @@ class EStepEngine:
         self.se_fill(Z, Z, inv_ls, kernel.variance.item(), out, kernel.kind)
         return out[:M, :M].contiguous()
 
-    def tri_copy(self, src: torch.Tensor, M: int, scale: float = 1.0, flip: int = 0) -> torch.Tensor:
+    def tri_copy(self, src: torch.Tensor, M: int, scale: float = 1.0, flip: int = 0, out: torch.Tensor = None) -> torch.Tensor:
         """[nb, M, M] contiguous <- triangle / index reversal of the leading M x M block of src [nb, R, C]
-        (``tsvgp_tri_copy_f64``: flip 0 = lower triangle, 1 = reversed indices, upper triangle, 2 = reversed, everything)."""
+        (``tsvgp_tri_copy_f64``: flip 0 = lower triangle, 1 = reversed indices, upper triangle, 2 = reversed, everything).
+        ``out``: a [nb, >= M, >= M] view (unit element stride) whose leading M x M blocks are written instead."""
         nb, R, C = src.shape
-        out = torch.empty((nb, M, M), dtype=torch.float64, device=self.device)
+        if out is None:
+            out = torch.empty((nb, M, M), dtype=torch.float64, device=self.device)
+        assert src.stride(2) == 1 and out.stride(2) == 1 and out.shape[0] == nb
         with torch.cuda.device(self.device):
-            B.check(self.lib.tsvgp_tri_copy_f64(src.data_ptr(), src.stride(1), src.stride(0), out.data_ptr(), M, M * M, M, nb,
-                                                float(scale), int(flip), self._stream()), "tsvgp_tri_copy")
+            B.check(self.lib.tsvgp_tri_copy_f64(src.data_ptr(), src.stride(1), src.stride(0), out.data_ptr(), out.stride(1),
+                                                out.stride(0), M, nb, float(scale), int(flip), self._stream()), "tsvgp_tri_copy")
         return out
+
+    def cholesky_solve_upper(self, A: torch.Tensor, Lrhs, robust: bool = False):
+        """Upper-form factorisation AND the triangular solve behind it in one pass (``tsvgp_potrf_solve_f64``):
+            A = U U^T (U upper triangular, as ``cholesky(upper_form=True)``),   D = U^-1 Lrhs^T   (upper triangular)
+        for A [.., M, M] and a lower triangular Lrhs [.., M, M] -- reference src/util.py:168-175 with W = I + L^T K L for A and the
+        site factor L for Lrhs; with the identity for Lrhs, D = U^-1 is the inverse factor (what K_uu + jitter I needs, reference
+        src/models/tsvgp.py:270-271: the same batch, the same launches).  The index-reversed right-hand side J L J rides through
+        the factorisation of J A J as extra panel rows and comes out as (J L J) C^-T = (C^-1 J L^T J)^T; one transposing pass turns
+        that into D.  Replaces the inverse recursion (three levels of launch pairs), two triangle copies, a 1024^3 GEMM and a triu
+        pass on the critical path of the replicated M x M chain.  ``Lrhs`` may be a LIST of [n_i, M, M] tensors, one run of the
+        batch each.  Returns (U, info, D); no host synchronisation."""
+        A = A.to(device=self.device, dtype=torch.float64)
+        M = A.shape[-1]
+        batch_shape = A.shape[:-2]
+        Mp = B.round_up(M)
+        nb = 1
+        for d in batch_shape:
+            nb *= int(d)
+        tall = (torch.empty if Mp == M else torch.zeros)((nb, 2 * Mp, Mp), dtype=torch.float64, device=self.device)
+        A3 = A.reshape(nb, M, M)
+        if A3.stride(2) != 1:
+            A3 = A3.contiguous()
+        self.tri_copy(A3, M, 1.0, 2, out=tall[:, :Mp])  # J A J
+        # J tril(L) J: upper triangular, the rows the solve carries along
+        parts, b0 = (list(Lrhs) if isinstance(Lrhs, (list, tuple)) else [Lrhs]), 0
+        for part in parts:
+            L3 = part.to(device=self.device, dtype=torch.float64).reshape(-1, M, M)
+            if L3.stride(2) != 1:
+                L3 = L3.contiguous()
+            self.tri_copy(L3, M, 1.0, 1, out=tall[b0:b0 + L3.shape[0], Mp:])
+            b0 += L3.shape[0]
+        assert b0 == nb, "one right-hand side per matrix of the batch"
+        if Mp != M:
+            tall[:, :Mp].diagonal(dim1=-2, dim2=-1)[:, M:] = 1.0  # chol([[A, 0], [0, I]]) = [[C, 0], [0, I]]
+        info = torch.empty(nb, dtype=torch.int32, device=self.device)
+        work = self._get("potrf_work", (nb, 128 * 128), torch.float64)
+        flags = (B.POTRF_SUBST if robust else 0) | B.POTRF_RHS_UPPER
+        with torch.cuda.device(self.device):
+            self._launch("tsvgp_potrf", lambda: self.lib.tsvgp_potrf_solve_f64(
+                tall.data_ptr(), Mp, Mp, nb, 2 * Mp * Mp, info.data_ptr(), work.data_ptr(), Mp, flags, self._stream()))
+        out_shape = tuple(batch_shape) + (M, M)
+        U = self.tri_copy(tall[:, :Mp], M, 1.0, 1).reshape(out_shape)
+        Dm = torch.empty((nb, M, M), dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            B.check(self.lib.tsvgp_flip_transpose_f64(tall[:, Mp:].data_ptr(), Mp, 2 * Mp * Mp, Dm.data_ptr(), M, M * M, M, nb,
+                                                      self._stream()), "tsvgp_flip_transpose")
+        return U, info, Dm.reshape(out_shape)
 
     def cholesky(self, A: torch.Tensor, inverse: bool = False, overwrite: bool = False, robust: bool = False,
                  scale: float = 1.0, upper_form: bool = False):
@@ -324,6 +374,23 @@ class EStepEngine:
                                                    float(num_data) if num_data is not None else 0.0, self._stream()),
                     "tsvgp_site_target")
         return target, G1s
+
+    def site_update(self, G1, G0, LLt, meanZ, l1_old, lr, jitter, rows, num_data):
+        """(target [P, M, M], lambda_1_new [M, P]) of ``tsvgp_site_update_f64``: the symmetrised G1 goes straight into the matrix of
+        the final factorisation (1 - lr) LLt - 2 lr s sym(G1) + jitter I and into the chain rule G0 - 2 sym(G1) meanZ, whose
+        convex combination with the old lambda_1 comes out of the same call."""
+        G1, LLt = G1.contiguous(), LLt.contiguous()
+        G0, meanZ, l1_old = G0.contiguous(), meanZ.contiguous(), l1_old.contiguous()
+        P, M = G1.shape[0], G1.shape[-1]
+        target, l1_new = torch.empty_like(G1), torch.empty_like(l1_old)
+        work = self._get("site_update_work", (P * ((M + 31) // 32) * M,), torch.float64)
+        with torch.cuda.device(self.device):
+            B.check(self.lib.tsvgp_site_update_f64(G1.data_ptr(), G0.data_ptr(), LLt.data_ptr(), meanZ.data_ptr(), l1_old.data_ptr(),
+                                                   target.data_ptr(), l1_new.data_ptr(), work.data_ptr(), M, P, float(lr),
+                                                   float(jitter), rows.data_ptr() if num_data is not None else None,
+                                                   float(num_data) if num_data is not None else 0.0, self._stream()),
+                    "tsvgp_site_update")
+        return target, l1_new
 
     def step_status(self, infos_a, infos_b, nonpos):
         """[3] fp64 device tensor (sum |info| of the prelude factorisations, nonpos, sum |info| of the final one)."""

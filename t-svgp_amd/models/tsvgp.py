@@ -304,7 +304,7 @@ class t_SVGP(base_SVGP):
     def _use_direct(self, jitter) -> list:
         return [r == "direct" for r in self._routes(jitter)]
 
-    def _site_operands(self, whiten_jitter=None, warm_key=None, routes=None, latents=None, fork=True):
+    def _site_operands(self, whiten_jitter=None, warm_key=None, routes=None, latents=None, fork=True, Kzz=None):
         """Everything the N-pass needs that depends only on (theta, Z, lambda): O(M^3), fp64, replicated.
         No host synchronisation happens here: Cholesky statuses are collected in ops["infos"] and checked once per
         call by ``_check_step`` (TF raises immediately; here the raise comes at the end of the same call).
@@ -327,7 +327,10 @@ class t_SVGP(base_SVGP):
             idx = torch.as_tensor(list(latents), device=l1.device)
             kernel = SeparateIndependent([self.kernel.kernels[p] for p in latents])
             l1, L = l1.index_select(1, idx), L.index_select(0, idx)
-        Kzz = warm[1]["Kzz"] if warm else eng.kuu(Z, kernel)  # HIP fill kernel, no jitter
+        if warm:
+            Kzz = warm[1]["Kzz"]
+        elif Kzz is None or latents is not None:
+            Kzz = eng.kuu(Z, kernel)  # HIP fill kernel, no jitter (``Kzz``: the caller already has it, see _step_front)
         Id = self._eye(M)
         if warm and "K6" in warm[1]:
             K6 = warm[1]["K6"]  # read only from here on (40 us of copy + strided add per step otherwise)
@@ -336,7 +339,8 @@ class t_SVGP(base_SVGP):
             K6.diagonal(dim1=-2, dim2=-1).add_(default_jitter())  # tsvgp.py:209-211
         P_ = L.shape[0]
         potrf = getattr(eng, "cholesky", None)  # HIP blocked Cholesky (tsvgp_potrf_f64)
-        if potrf is not None and routes is not None and any(r == "projected" for r in routes):
+        robust = potrf is not None and routes is not None and any(r == "projected" for r in routes)
+        if robust:
             # cond(K_uu + jitter I) beyond 1e7: K9 and the new Lambda_2 are barely definite in fp64 there, and the
             # factorisation that follows the reference's success / failure is the one with substitution panels
             # (TSVGP_POTRF_SUBST through EStepEngine.cholesky(robust=True))
@@ -359,8 +363,21 @@ class t_SVGP(base_SVGP):
         if with_k9:
             batch[P_:].copy_(Kzz if Kzz.dim() == 3 else Kzz[None])
             batch[P_:].diagonal(dim1=-2, dim2=-1).add_(whiten_jitter)  # K9 = K_uu + jitter I, tsvgp.py:270
-        both, inv_both = rev_cholesky(batch, infos, potrf, inverse=True)
-        U_W, Uinv_W = both[:P_], inv_both[:P_]
+        # Factor AND solve in one pass (EStepEngine.cholesky_solve_upper): D = U_W^-1 L^T comes out of the factorisation itself,
+        # J L J riding along as panel rows -- and with the identity riding along K_uu + jitter I, its inverse factor -- instead of
+        # from the inverse recursion (three levels of launch pairs), two triangle copies, a 1024^3 GEMM and a triu pass.
+        # (Measured and NOT kept, profiles/r04_chain_ab.txt: K_uu + jitter I factored on the side stream, off the chain -- its 24
+        # dependent launches then queue behind the moments kernel's workgroups: 4 ms per call at N = 1e6, the step 0.2 ms slower.)
+        solve = potrf is not None and hasattr(eng, "cholesky_solve_upper") and os.environ.get("TSVGP_POTRF_SOLVE", "1") != "0"
+        Dm = None
+        if solve:
+            rhs = [L] + ([Id.expand(n9, M, M)] if n9 else [])
+            both, info_w, sol = eng.cholesky_solve_upper(batch, rhs, robust=robust)
+            infos.append(info_w.reshape(-1).to(torch.int32))
+            U_W, Dm, Uinv_W, inv_both = both[:P_], sol[:P_], None, sol
+        else:
+            both, inv_both = rev_cholesky(batch, infos, potrf, inverse=True)
+            U_W, Uinv_W = both[:P_], inv_both[:P_]
         L9inv = None
         if with_k9:
             U9, Uinv9 = (both[P_:], inv_both[P_:]) if Kzz.dim() == 3 else (both[-1], inv_both[-1])
@@ -374,7 +391,8 @@ class t_SVGP(base_SVGP):
             U9, Uinv9 = warm[1]["U9"], warm[1]["Uinv9"]
         else:
             U9, Uinv9 = None, None
-        Dm = (Uinv_W @ L.transpose(-1, -2)).triu()  # D = U_W^-1 L^T, [P, M, M], upper triangular
+        if Dm is None:
+            Dm = (Uinv_W @ L.transpose(-1, -2)).triu()  # D = U_W^-1 L^T, [P, M, M], upper triangular
         DKl = bmv(Dm, _kmv(K6, l1))  # [M, P]
         beta = l1 - bmv(Dm, DKl, transpose=True)  # K6^-1 m = l1 - D^T D K6 l1
         ops = dict(Z=Z, Kzz=Kzz, K6=K6, D=Dm, U_W=U_W, beta=beta, Id=Id, infos=infos, potrf=potrf,
@@ -714,10 +732,15 @@ class t_SVGP(base_SVGP):
         # (inside a capture of a launch-bound size the fork / join costs a replay more than the overlap gains: in line there)
         fork = not (self.device.type == "cuda" and torch.cuda.is_current_stream_capturing()
                     and X.shape[0] * self.num_inducing < self.GRAPH_FORK_MIN_NM)
+        Kzz = None
         if self.overlap_fill and fork and hasattr(eng, "start_fill"):
+            # K(Z, Z) opens the M x M chain and is a launch of a few microseconds: it goes out BEFORE the N-sized fill, whose
+            # workgroups otherwise take every CU first (the small fill then waited for slots: 54 us instead of ~8 at M = 1024)
+            if not (warm_key is not None and self._warm is not None and self._warm[0] == warm_key):
+                Kzz = eng.kuu(self._Z(), self.kernel)
             pre = eng.start_fill(X, self._Z(), self.kernel, b_tag=warm_key,
                                  want="Kfu" if all(r == "direct" for r in routes) else "B", routes=routes)
-        ops = self._site_operands(whiten_jitter=jitter, warm_key=warm_key, routes=routes, fork=fork)
+        ops = self._site_operands(whiten_jitter=jitter, warm_key=warm_key, routes=routes, fork=fork, Kzz=Kzz)
         st = eng.run(X, Y, ops["Z"], self.kernel, moment_Tm=ops["moment_Tm"], prefill=pre,
                      moment_mode=ops["moment_mode"], gamma=ops["gamma"],
                      lik_id=self.likelihood.lik_id, lik_param=self.likelihood.lik_param,
@@ -1036,7 +1059,15 @@ class t_SVGP(base_SVGP):
         #   -2 [(1 - lr) lambda_2 + lr scale G1] + jitter I = (1 - lr) L L^T - 2 lr scale G1 + jitter I;
         # L L^T of the old factor comes from the prelude, `rows` (the global number of rows) is a device scalar: the
         # minibatch scale of :286-291 needs no synchronisation
-        if hasattr(eng, "site_target") and G1.is_cuda:
+        l1_old = self.lambda_1.value
+        if latents is not None:
+            l1_old = l1_old.index_select(1, torch.as_tensor(list(latents), device=l1_old.device))
+        fused = hasattr(eng, "site_update") and G1.is_cuda and os.environ.get("TSVGP_SITE_UPDATE", "1") != "0"
+        if fused:
+            # symmetrisation, the matrix of the final factorisation, the chain rule of util.py:429-438 and the convex update of
+            # lambda_1 (tsvgp.py:284-297) in ONE launch (tsvgp_site_update_f64; it was a kernel, a gemv and ~10 elementwise launches)
+            target, lambda_1 = eng.site_update(G1, G0, ops["LLt"], ops["meanZ"], l1_old, lr, jitter, rows, self.num_data)
+        elif hasattr(eng, "site_target") and G1.is_cuda:
             target, G1 = eng.site_target(G1, ops["LLt"], 1.0 - lr, -2.0 * lr, jitter, rows, self.num_data)
             scale = (float(self.num_data) / rows) if self.num_data is not None else 1.0
         else:
@@ -1044,11 +1075,9 @@ class t_SVGP(base_SVGP):
             scale = (float(self.num_data) / rows) if self.num_data is not None else 1.0
             target = (1.0 - lr) * ops["LLt"] + (-2.0 * lr * scale) * G1
             target.diagonal(dim1=-2, dim2=-1).add_(jitter)
-        grad_mu = gradient_transformation_mean_var_to_expectation(ops["meanZ"], [G0, G1])  # tsvgp.py:284
-        l1_old = self.lambda_1.value
-        if latents is not None:
-            l1_old = l1_old.index_select(1, torch.as_tensor(list(latents), device=l1_old.device))
-        lambda_1 = (1 - lr) * l1_old + lr * scale * grad_mu[0]  # tsvgp.py:296
+        if not fused:
+            grad_mu = gradient_transformation_mean_var_to_expectation(ops["meanZ"], [G0, G1])  # tsvgp.py:284
+            lambda_1 = (1 - lr) * l1_old + lr * scale * grad_mu[0]  # tsvgp.py:296
         final_info = []
         # tsvgp.py:300; the leading minus rides on the factorisation's triangle copy, which also leaves exact zeros above
         lambda_2_sqrt = cholesky_deferred(target, final_info, ops["potrf"], overwrite=True, scale=-1.0)

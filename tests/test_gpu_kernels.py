@@ -275,6 +275,32 @@ def test_site_accum_rejects_misaligned_operands(engines):
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("M,P,num_data", [(96, 1, None), (200, 3, 5000.0), (1024, 1, 1.0e6), (33, 2, 77.0)])
+def test_site_update_and_target_kernels(engines, M, P, num_data):
+    """``tsvgp_site_update_f64`` (one launch: symmetrised G1 -> the matrix of the final factorisation, the chain rule of reference
+    src/util.py:429-438 and the convex update of lambda_1, src/models/tsvgp.py:284-297) and ``tsvgp_site_target_f64`` against
+    NumPy; repeated launches bit-identical (fixed-order row sums)."""
+    eng = engines[torch.float64]
+    rng = np.random.RandomState(M + P)
+    G1, LLt = rng.randn(P, M, M), rng.randn(P, M, M)
+    LLt = LLt @ np.swapaxes(LLt, -1, -2)
+    G0, meanZ, l1 = rng.randn(M, P), rng.randn(M, P), rng.randn(M, P)
+    lr, jitter, rows_n = 0.7, 1e-9, 1234.0
+    t = lambda a: torch.as_tensor(a, device="cuda:0")
+    rows = torch.full((), rows_n, dtype=torch.float64, device="cuda:0")
+    target, l1_new = eng.site_update(t(G1), t(G0), t(LLt), t(meanZ), t(l1), lr, jitter, rows, num_data)
+    s = 1.0 if num_data is None else num_data / rows_n
+    Gs = 0.5 * (G1 + np.swapaxes(G1, -1, -2))
+    want_t = (1 - lr) * LLt - 2 * lr * s * Gs + jitter * np.eye(M)
+    want_l = (1 - lr) * l1 + lr * s * (G0 - 2.0 * np.einsum("pmo,op->mp", Gs, meanZ))
+    assert relerr(target.cpu().numpy(), want_t) < 1e-14
+    assert relerr(l1_new.cpu().numpy(), want_l) < 1e-13
+    target2, l1_new2 = eng.site_update(t(G1), t(G0), t(LLt), t(meanZ), t(l1), lr, jitter, rows, num_data)
+    assert torch.equal(target, target2) and torch.equal(l1_new, l1_new2)
+    tt, Gsym = eng.site_target(t(G1), t(LLt), 1 - lr, -2 * lr, jitter, rows, num_data)
+    assert relerr(tt.cpu().numpy(), want_t) < 1e-14 and relerr(Gsym.cpu().numpy(), Gs) < 1e-15
+
+
 def test_invalid_arguments_are_rejected(engines):
     eng = engines[torch.float64]
     lib = eng.lib
@@ -344,6 +370,39 @@ def test_potrf_inverse(engines, M, batch):
     assert np.array_equal(np.triu(X, 1), np.zeros_like(A))
     assert relerr(X, np.linalg.inv(ref)) < 1e-11
     assert np.max(np.abs(X @ ref - np.eye(M))) < 1e-11
+
+
+@pytest.mark.parametrize("robust", [False, True])
+@pytest.mark.parametrize("M,batch", [(128, 1), (256, 3), (1024, 1), (640, 2), (200, 2), (33, 1)])
+def test_potrf_solve_upper(engines, M, batch, robust):
+    """tsvgp_potrf_solve_f64 + tsvgp_flip_transpose_f64 (``EStepEngine.cholesky_solve_upper``): the upper-form factor A = U U^T and
+    D = U^-1 L^T for a lower triangular L in ONE pass (the right-hand side rides through the factorisation as panel rows) --
+    reference src/util.py:168-175 (chol_W, then triangular_solve(chol_W, L^T)) -- against NumPy; D exactly upper triangular;
+    the upper part of the L it is handed is ignored (sites.py:63: only the lower triangle is the parameter); a non-positive
+    pivot reports info like potrf."""
+    eng = engines[torch.float64]
+    rng = np.random.RandomState(7 + M)
+    A = rng.randn(batch, M, M)
+    A = A @ np.swapaxes(A, -1, -2) / M + 0.5 * np.eye(M)
+    L = np.tril(rng.randn(batch, M, M)) / np.sqrt(M)
+    junk = L + np.triu(rng.randn(batch, M, M), 1)  # what sits above the diagonal must not matter
+    U, info, Dm = eng.cholesky_solve_upper(torch.as_tensor(A, device="cuda:0"), torch.as_tensor(junk, device="cuda:0"), robust=robust)
+    torch.cuda.synchronize()
+    assert int(info.abs().sum()) == 0
+    J = np.eye(M)[::-1]
+    C = np.linalg.cholesky(J @ A @ J)
+    U_ref = J @ C @ J  # A = U U^T, U upper
+    assert relerr(U.cpu().numpy(), U_ref) < 1e-12
+    D_ref = np.linalg.solve(U_ref, np.swapaxes(L, -1, -2))
+    Dn = Dm.cpu().numpy()
+    assert relerr(Dn, D_ref) < 1e-11
+    assert np.array_equal(np.tril(Dn, -1), np.zeros_like(Dn))
+    # the variance identity the moments kernel relies on: D^T D = L W^-1 L^T (util.py:176-184)
+    assert relerr(np.swapaxes(Dn, -1, -2) @ Dn, L @ np.linalg.solve(A, np.swapaxes(L, -1, -2))) < 1e-10
+    bad = A.copy()
+    bad[0, M // 2, M // 2] = -1.0
+    _, info, _ = eng.cholesky_solve_upper(torch.as_tensor(bad, device="cuda:0"), torch.as_tensor(L, device="cuda:0"), robust=robust)
+    assert int(info[0]) != 0 and (batch == 1 or int(info[1:].abs().sum()) == 0)
 
 
 @pytest.mark.parametrize("dtype,tol", DTYPES)

@@ -230,8 +230,11 @@ def test_warm_cache_matches_cold_and_invalidates():
         warm.natgrad_step((Xd, Yd), lr=0.7, jitter=jit)
         if i == 1:
             warm.predict_f(Xd[:100])  # overwrites the work buffers: the cache must notice
-        assert relerr(warm.lambda_1.numpy(), cold.lambda_1.numpy()) < 1e-12
-        assert relerr(warm.lambda_2.cpu().numpy(), cold.lambda_2.cpu().numpy()) < 1e-12
+        # (not bit for bit: the cold step takes D = U_W^-1 L^T out of the factorisation itself, by substitution, and factors
+        # K_uu + jitter I on the side stream; the warm one keeps the batched factorisation with inverse factors -- the same
+        # algebra rounded differently, ~cond(W) eps apart)
+        assert relerr(warm.lambda_1.numpy(), cold.lambda_1.numpy()) < 1e-9
+        assert relerr(warm.lambda_2.cpu().numpy(), cold.lambda_2.cpu().numpy()) < 1e-9
     assert warm._get_engine()._b_tag is not None
 
 
