@@ -293,6 +293,12 @@ int tsvgp_site_update_f64(const double *G1, const double *G0, const double *LLt,
                           double *target, double *l1_new, double *work, int M, int P, double lr, double jitter, const double *rows,
                           double num_data, void *stream);
 
+/* (7b'') beta = l1 - D^T (D v) per latent: D [P x M x M] upper triangular (only that triangle is read), v, l1, beta [M x P]
+ *     contiguous; work: P * M doubles.  With v = (K_uu + 1e-6 I) lambda_1 this is K^-1 m of reference src/util.py:176-179 -- the two
+ *     triangular matrix-vector products between the factorisation and the moments kernel, one launch each. */
+int tsvgp_site_beta_f64(const double *D, const double *v, const double *l1, double *work, double *beta, int M, int P,
+                        void *stream);
+
 /* (7c) Status word of one step: flags[0] = sum |info_a| (prelude factorisations), flags[1] = nonpos[0] (count of
  *     non-positive predictive variances, the assert_positive of :113; NULL = 0), flags[2] = sum |info_b| (the final
  *     factorisation, :300).  One device->host read of these three doubles ends a step. */

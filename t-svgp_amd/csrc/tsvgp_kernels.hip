@@ -3338,6 +3338,38 @@ __global__ __launch_bounds__(NTHREADS) void site_update_finish_kernel(const doub
     l1_new[o] = (1.0 - lr) * l1_old[o] + lr * s * (G0[o] - 2.0 * v);
 }
 
+// beta = l1 - D^T (D v) per latent, D [P][M][M] upper triangular, v = K6 l1 [M][P]  (K6^-1 m of reference src/util.py:176-179 in the
+// form of t_SVGP._site_operands): the two triangular matrix-vector products that stand between the factorisation and the
+// moments kernel, each one launch (they were gemv + copy + gemv + copy + multiply + fill + reduce + copy + add: ~75 us of 5-14 us
+// launches).  STAGE 0: t[i] = sum_{j >= i} D[i][j] v[j], one wave per row.  STAGE 1: beta[j] = l1[j] - sum_{i <= j} D[i][j] t[i],
+// one workgroup per 64 columns, four row groups per workgroup summed in a fixed order.
+template <int STAGE>
+__global__ __launch_bounds__(NTHREADS) void site_beta_kernel(const double* __restrict__ D, const double* __restrict__ v,
+                                                             const double* __restrict__ l1, double* __restrict__ tvec,
+                                                             double* __restrict__ beta, int M, int P) {
+    const int p = blockIdx.y;
+    const double* Dp = D + (size_t)p * M * M;
+    if (STAGE == 0) {
+        const int lane = threadIdx.x & 63, i = blockIdx.x * (NTHREADS / 64) + (threadIdx.x >> 6);
+        if (i >= M) return;
+        double acc = 0.0;
+        for (int j = (i & ~63) + lane; j < M; j += 64)
+            if (j >= i) acc += Dp[(size_t)i * M + j] * v[(size_t)j * P + p];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        if (lane == 0) tvec[(size_t)p * M + i] = acc;
+    } else {
+        __shared__ double part[4][64];
+        const int c = threadIdx.x & 63, g = threadIdx.x >> 6, j = blockIdx.x * 64 + c;
+        double acc = 0.0;
+        if (j < M)
+            for (int i = g; i <= j; i += 4) acc += Dp[(size_t)i * M + j] * tvec[(size_t)p * M + i];
+        part[g][c] = acc;
+        __syncthreads();
+        if (g == 0 && j < M) beta[(size_t)j * P + p] = l1[(size_t)j * P + p] - (((part[0][c] + part[1][c]) + part[2][c]) + part[3][c]);
+    }
+}
+
 // flags[0] = sum |info_a|, flags[1] = nonpos (as is, NaN included), flags[2] = sum |info_b|   (t_SVGP._status_flags)
 __global__ void step_status_kernel(const int* __restrict__ info_a, int na, const int* __restrict__ info_b, int nb,
                                    const double* __restrict__ nonpos, double* __restrict__ flags) {
@@ -4110,6 +4142,16 @@ int tsvgp_site_update_f64(const double* G1, const double* G0, const double* LLt,
                        target, work, M, P, lr, jitter, rows, num_data);
     hipLaunchKernelGGL(site_update_finish_kernel, dim3((unsigned)((M + NTHREADS - 1) / NTHREADS), (unsigned)P), dim3(NTHREADS), 0,
                        (hipStream_t)stream, work, G0, l1_old, l1_new, M, P, lr, rows, num_data);
+    return launch_status();
+}
+int tsvgp_site_beta_f64(const double* D, const double* v, const double* l1, double* work, double* beta, int M, int P,
+                        void* stream) {
+    if (!D || !v || !l1 || !work || !beta || M <= 0 || P <= 0 || P > 65535) return TSVGP_EINVAL;
+    const int wpb = NTHREADS / 64;
+    hipLaunchKernelGGL(site_beta_kernel<0>, dim3((unsigned)((M + wpb - 1) / wpb), (unsigned)P), dim3(NTHREADS), 0,
+                       (hipStream_t)stream, D, v, l1, work, beta, M, P);
+    hipLaunchKernelGGL(site_beta_kernel<1>, dim3((unsigned)((M + 63) / 64), (unsigned)P), dim3(NTHREADS), 0, (hipStream_t)stream, D, v,
+                       l1, work, beta, M, P);
     return launch_status();
 }
 int tsvgp_step_status_f64(const int32_t* info_a, int na, const int32_t* info_b, int nb, const double* nonpos, double* flags,

@@ -190,6 +190,18 @@ class EStepEngine:
         M = 512, 29 slices = one round 4.33 ms against 4.20 for two)."""
         return site_sum_slices(Mp, P, Np, self.slots(), self.dtype == torch.float64, self.syrk_oversubscribe)
 
+    def _padded_gamma(self, gamma: torch.Tensor, Mp: int, P: int) -> torch.Tensor:
+        """gamma [M, P] fp64 -> [Mp, P] in the compute dtype, rows >= M zero: a cached buffer whose padding is zeroed once (it was a
+        fill and a copy per pass in front of the moments kernel)."""
+        M = gamma.shape[0]
+        if M == Mp and gamma.dtype == self.dtype and gamma.is_contiguous():
+            return gamma
+        out = self._buf.get("pad_gamma")
+        if out is None or tuple(out.shape) != (Mp, P) or out.dtype != self.dtype:
+            out = self._buf["pad_gamma"] = torch.zeros((Mp, P), dtype=self.dtype, device=self.device)
+        out[:M].copy_(gamma)
+        return out
+
     def _pad_square(self, A: torch.Tensor, Mp: int, key: str = None) -> torch.Tensor:
         """[.., M, M] fp64 -> zero-padded contiguous [.., Mp, Mp] in the compute dtype (a cached buffer per key)."""
         M = A.shape[-1]
@@ -391,6 +403,17 @@ class EStepEngine:
                                                    float(num_data) if num_data is not None else 0.0, self._stream()),
                     "tsvgp_site_update")
         return target, l1_new
+
+    def site_beta(self, Dm, v, l1):
+        """beta [M, P] = l1 - D^T (D v) per latent (``tsvgp_site_beta_f64``): D [P, M, M] upper triangular, v = K6 l1 and l1 [M, P]."""
+        Dm, v, l1 = Dm.contiguous(), v.contiguous(), l1.contiguous()
+        P, M = Dm.shape[0], Dm.shape[-1]
+        beta = torch.empty_like(l1)
+        work = self._get("site_beta_work", (P * M,), torch.float64)
+        with torch.cuda.device(self.device):
+            B.check(self.lib.tsvgp_site_beta_f64(Dm.data_ptr(), v.data_ptr(), l1.data_ptr(), work.data_ptr(), beta.data_ptr(), M, P,
+                                                 self._stream()), "tsvgp_site_beta")
+        return beta
 
     def step_status(self, infos_a, infos_b, nonpos):
         """[3] fp64 device tensor (sum |info| of the prelude factorisations, nonpos, sum |info| of the final one)."""
@@ -606,8 +629,7 @@ class EStepEngine:
                                                            KfuP[lo].data_ptr(), stride, Np, Mp, B.TRI_UPPER, hi - lo,
                                                            self._stream()))
         Tm = self._pad_square(moment_Tm, Mp, "pad_Tm")
-        gam = torch.zeros((Mp, P), dtype=T, device=dev)
-        gam[:M] = gamma
+        gam = self._padded_gamma(gamma, Mp, P)
         nblk = Np // B.TILE
         ve_partial = self._get("ve_partial", (nblk,), torch.float64)
         nonpos_partial = self._get("nonpos_partial", (nblk,), torch.int32)
@@ -863,8 +885,7 @@ class EStepEngine:
                 self._b_tag = (want, b_tag)
 
         Tm = self._pad_square(moment_Tm, Mp, "pad_Tm")
-        gam = torch.zeros((Mp, P), dtype=T, device=dev)
-        gam[:M] = gamma
+        gam = self._padded_gamma(gamma, Mp, P)
         nblk = Np // B.TILE
         ve_partial = self._get("ve_partial", (nblk,), torch.float64)
         nonpos_partial = self._get("nonpos_partial", (nblk,), torch.int32)

@@ -245,6 +245,13 @@ class t_SVGP(base_SVGP):
             e = self._eye_cache = torch.eye(M, dtype=torch.float64, device=self.device)
         return e
 
+    @staticmethod
+    def _k6_of(Kzz: torch.Tensor) -> torch.Tensor:
+        """K_uu + default_jitter() I (tsvgp.py:209-211) as a fresh tensor."""
+        K6 = Kzz.clone()
+        K6.diagonal(dim1=-2, dim2=-1).add_(default_jitter())
+        return K6
+
     def _warm_key(self, X, jitter):
         """Cache key of everything B = K(X, Z) U9^-T depends on; None when caching is off or X is not a device tensor."""
         if not self.cache_whitened or not isinstance(X, torch.Tensor) or X.device != self.device:
@@ -304,7 +311,7 @@ class t_SVGP(base_SVGP):
     def _use_direct(self, jitter) -> list:
         return [r == "direct" for r in self._routes(jitter)]
 
-    def _site_operands(self, whiten_jitter=None, warm_key=None, routes=None, latents=None, fork=True, Kzz=None):
+    def _site_operands(self, whiten_jitter=None, warm_key=None, routes=None, latents=None, fork=True, Kzz=None, K6=None):
         """Everything the N-pass needs that depends only on (theta, Z, lambda): O(M^3), fp64, replicated.
         No host synchronisation happens here: Cholesky statuses are collected in ops["infos"] and checked once per
         call by ``_check_step`` (TF raises immediately; here the raise comes at the end of the same call).
@@ -334,9 +341,8 @@ class t_SVGP(base_SVGP):
         Id = self._eye(M)
         if warm and "K6" in warm[1]:
             K6 = warm[1]["K6"]  # read only from here on (40 us of copy + strided add per step otherwise)
-        else:
-            K6 = Kzz.clone()
-            K6.diagonal(dim1=-2, dim2=-1).add_(default_jitter())  # tsvgp.py:209-211
+        elif K6 is None or latents is not None:
+            K6 = self._k6_of(Kzz)
         P_ = L.shape[0]
         potrf = getattr(eng, "cholesky", None)  # HIP blocked Cholesky (tsvgp_potrf_f64)
         robust = potrf is not None and routes is not None and any(r == "projected" for r in routes)
@@ -358,8 +364,11 @@ class t_SVGP(base_SVGP):
                   and all(r == "projected" for r in routes))
         with_k9 = whiten_jitter is not None and not warm and not lower9
         n9 = (Kzz.shape[0] if Kzz.dim() == 3 else 1) if with_k9 else 0
+        K6l = _kmv(K6, l1)  # [M, P]: needed behind the factorisation (beta) -- issued in front of it, off the path to the moments
         batch = torch.empty((P_ + n9, M, M), dtype=torch.float64, device=Kzz.device)
-        torch.baddbmm(Id.expand(P_, M, M), L.transpose(-1, -2), K6 @ L, out=batch[:P_])
+        # (bmm + a strided add of the identity: baddbmm first copies its [P, M, M] addend into the output, 8 MB per latent)
+        torch.bmm(L.transpose(-1, -2), K6 @ L, out=batch[:P_])
+        batch[:P_].diagonal(dim1=-2, dim2=-1).add_(1.0)
         if with_k9:
             batch[P_:].copy_(Kzz if Kzz.dim() == 3 else Kzz[None])
             batch[P_:].diagonal(dim1=-2, dim2=-1).add_(whiten_jitter)  # K9 = K_uu + jitter I, tsvgp.py:270
@@ -393,8 +402,10 @@ class t_SVGP(base_SVGP):
             U9, Uinv9 = None, None
         if Dm is None:
             Dm = (Uinv_W @ L.transpose(-1, -2)).triu()  # D = U_W^-1 L^T, [P, M, M], upper triangular
-        DKl = bmv(Dm, _kmv(K6, l1))  # [M, P]
-        beta = l1 - bmv(Dm, DKl, transpose=True)  # K6^-1 m = l1 - D^T D K6 l1
+        if hasattr(eng, "site_beta") and Dm.is_cuda and os.environ.get("TSVGP_SITE_BETA", "1") != "0":
+            beta = eng.site_beta(Dm, K6l, l1)  # K6^-1 m = l1 - D^T D K6 l1: two triangular matrix-vector launches
+        else:
+            beta = l1 - bmv(Dm, bmv(Dm, K6l), transpose=True)
         ops = dict(Z=Z, Kzz=Kzz, K6=K6, D=Dm, U_W=U_W, beta=beta, Id=Id, infos=infos, potrf=potrf,
                    routes=["whitened"] * P_, moment_mode=B.TRI_UPPER, whiten_mode=B.TRI_UPPER,
                    whiten_T=None, project_T=None)
@@ -732,15 +743,16 @@ class t_SVGP(base_SVGP):
         # (inside a capture of a launch-bound size the fork / join costs a replay more than the overlap gains: in line there)
         fork = not (self.device.type == "cuda" and torch.cuda.is_current_stream_capturing()
                     and X.shape[0] * self.num_inducing < self.GRAPH_FORK_MIN_NM)
-        Kzz = None
+        Kzz = K6 = None
         if self.overlap_fill and fork and hasattr(eng, "start_fill"):
             # K(Z, Z) opens the M x M chain and is a launch of a few microseconds: it goes out BEFORE the N-sized fill, whose
             # workgroups otherwise take every CU first (the small fill then waited for slots: 54 us instead of ~8 at M = 1024)
             if not (warm_key is not None and self._warm is not None and self._warm[0] == warm_key):
                 Kzz = eng.kuu(self._Z(), self.kernel)
+                K6 = self._k6_of(Kzz)
             pre = eng.start_fill(X, self._Z(), self.kernel, b_tag=warm_key,
                                  want="Kfu" if all(r == "direct" for r in routes) else "B", routes=routes)
-        ops = self._site_operands(whiten_jitter=jitter, warm_key=warm_key, routes=routes, fork=fork, Kzz=Kzz)
+        ops = self._site_operands(whiten_jitter=jitter, warm_key=warm_key, routes=routes, fork=fork, Kzz=Kzz, K6=K6)
         st = eng.run(X, Y, ops["Z"], self.kernel, moment_Tm=ops["moment_Tm"], prefill=pre,
                      moment_mode=ops["moment_mode"], gamma=ops["gamma"],
                      lik_id=self.likelihood.lik_id, lik_param=self.likelihood.lik_param,

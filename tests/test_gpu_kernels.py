@@ -301,6 +301,22 @@ def test_site_update_and_target_kernels(engines, M, P, num_data):
     assert relerr(tt.cpu().numpy(), want_t) < 1e-14 and relerr(Gsym.cpu().numpy(), Gs) < 1e-15
 
 
+@pytest.mark.parametrize("M,P", [(96, 1), (200, 3), (1024, 1), (33, 2), (1, 1)])
+def test_site_beta_kernel(engines, M, P):
+    """``tsvgp_site_beta_f64``: beta = l1 - D^T (D v) with D upper triangular (what lies below the diagonal is never read) --
+    K^-1 m of reference src/util.py:176-179 -- against NumPy; repeated launches bit-identical."""
+    eng = engines[torch.float64]
+    rng = np.random.RandomState(3 * M + P)
+    D = np.triu(rng.randn(P, M, M)) / np.sqrt(M)
+    junk = D + np.tril(rng.randn(P, M, M), -1)
+    v, l1 = rng.randn(M, P), rng.randn(M, P)
+    t = lambda a: torch.as_tensor(a, device="cuda:0")
+    beta = eng.site_beta(t(junk), t(v), t(l1))
+    want = l1 - np.einsum("pij,pi->jp", D, np.einsum("pij,jp->pi", D, v))
+    assert relerr(beta.cpu().numpy(), want) < 1e-13
+    assert torch.equal(beta, eng.site_beta(t(junk), t(v), t(l1)))
+
+
 def test_invalid_arguments_are_rejected(engines):
     eng = engines[torch.float64]
     lib = eng.lib

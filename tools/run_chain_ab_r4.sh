@@ -15,7 +15,7 @@ print('$4', '$1', $2, 'ms/step', d['ms_per_step'], 'hipgraph' if d.get('hipgraph
 for rep in 1 2; do
   for spec in "ns 125000 40" "c3 125000 40" "ns 1000000 20"; do
     set -- $spec
-    TSVGP_POTRF_SOLVE=0 TSVGP_SITE_UPDATE=0 line $1 $2 $3 old
+    TSVGP_POTRF_SOLVE=0 TSVGP_SITE_UPDATE=0 TSVGP_SITE_BETA=0 line $1 $2 $3 old
     line $1 $2 $3 new
   done
 done
