@@ -294,8 +294,9 @@ int tsvgp_site_update_f64(const double *G1, const double *G0, const double *LLt,
                           double num_data, void *stream);
 
 /* (7b'') beta = l1 - D^T (D v) per latent: D [P x M x M] upper triangular (only that triangle is read), v, l1, beta [M x P]
- *     contiguous; work: P * M doubles.  With v = (K_uu + 1e-6 I) lambda_1 this is K^-1 m of reference src/util.py:176-179 -- the two
- *     triangular matrix-vector products between the factorisation and the moments kernel, one launch each. */
+ *     contiguous; work: P * M * (1 + ceil(M / 64)) doubles.  With v = (K_uu + 1e-6 I) lambda_1 this is K^-1 m of reference
+ *     src/util.py:176-179 -- the two triangular matrix-vector products between the factorisation and the moments kernel, three
+ *     small launches, summation in a fixed order. */
 int tsvgp_site_beta_f64(const double *D, const double *v, const double *l1, double *work, double *beta, int M, int P,
                         void *stream);
 

@@ -3340,15 +3340,17 @@ __global__ __launch_bounds__(NTHREADS) void site_update_finish_kernel(const doub
 
 // beta = l1 - D^T (D v) per latent, D [P][M][M] upper triangular, v = K6 l1 [M][P]  (K6^-1 m of reference src/util.py:176-179 in the
 // form of t_SVGP._site_operands): the two triangular matrix-vector products that stand between the factorisation and the
-// moments kernel, each one launch (they were gemv + copy + gemv + copy + multiply + fill + reduce + copy + add: ~75 us of 5-14 us
-// launches).  STAGE 0: t[i] = sum_{j >= i} D[i][j] v[j], one wave per row.  STAGE 1: beta[j] = l1[j] - sum_{i <= j} D[i][j] t[i],
-// one workgroup per 64 columns, four row groups per workgroup summed in a fixed order.
+// moments kernel, in three small launches (they were gemv + copy + gemv + copy + multiply + fill + reduce + copy + add: ~75 us of
+// 5-14 us launches).  STAGE 0: t[i] = sum_{j >= i} D[i][j] v[j], one wave per row.  STAGE 1: the column sums of D[i][j] t[i]
+// over 64-row groups, one workgroup per (64 columns, 64 rows) -- many small workgroups: under the N-sized fill of the same step a
+// launch of 16 workgroups took 79 us -- to part [P][M / 64][M].  STAGE 2: beta[j] = l1[j] - sum of the row groups in order.
 template <int STAGE>
 __global__ __launch_bounds__(NTHREADS) void site_beta_kernel(const double* __restrict__ D, const double* __restrict__ v,
                                                              const double* __restrict__ l1, double* __restrict__ tvec,
-                                                             double* __restrict__ beta, int M, int P) {
-    const int p = blockIdx.y;
+                                                             double* __restrict__ part, double* __restrict__ beta, int M, int P) {
+    const int p = blockIdx.z;
     const double* Dp = D + (size_t)p * M * M;
+    const int nrg = (M + 63) / 64;
     if (STAGE == 0) {
         const int lane = threadIdx.x & 63, i = blockIdx.x * (NTHREADS / 64) + (threadIdx.x >> 6);
         if (i >= M) return;
@@ -3358,15 +3360,24 @@ __global__ __launch_bounds__(NTHREADS) void site_beta_kernel(const double* __res
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
         if (lane == 0) tvec[(size_t)p * M + i] = acc;
-    } else {
-        __shared__ double part[4][64];
-        const int c = threadIdx.x & 63, g = threadIdx.x >> 6, j = blockIdx.x * 64 + c;
+    } else if (STAGE == 1) {
+        __shared__ double sums[4][64];
+        const int c = threadIdx.x & 63, g = threadIdx.x >> 6, j = blockIdx.x * 64 + c, rg = blockIdx.y;
         double acc = 0.0;
-        if (j < M)
-            for (int i = g; i <= j; i += 4) acc += Dp[(size_t)i * M + j] * tvec[(size_t)p * M + i];
-        part[g][c] = acc;
+        if (rg <= (int)blockIdx.x && j < M) {  // row groups beyond the column strip lie below the diagonal
+            const int i_end = (rg * 64 + 64 < M ? rg * 64 + 64 : M);
+            for (int i = rg * 64 + g; i < i_end; i += 4)
+                if (i <= j) acc += Dp[(size_t)i * M + j] * tvec[(size_t)p * M + i];
+        }
+        sums[g][c] = acc;
         __syncthreads();
-        if (g == 0 && j < M) beta[(size_t)j * P + p] = l1[(size_t)j * P + p] - (((part[0][c] + part[1][c]) + part[2][c]) + part[3][c]);
+        if (g == 0 && j < M) part[((size_t)p * nrg + rg) * M + j] = ((sums[0][c] + sums[1][c]) + sums[2][c]) + sums[3][c];
+    } else {
+        const int j = blockIdx.x * NTHREADS + threadIdx.x;
+        if (j >= M) return;
+        double acc = 0.0;
+        for (int rg = 0; rg <= j / 64; ++rg) acc += part[((size_t)p * nrg + rg) * M + j];
+        beta[(size_t)j * P + p] = l1[(size_t)j * P + p] - acc;
     }
 }
 
@@ -4147,11 +4158,15 @@ int tsvgp_site_update_f64(const double* G1, const double* G0, const double* LLt,
 int tsvgp_site_beta_f64(const double* D, const double* v, const double* l1, double* work, double* beta, int M, int P,
                         void* stream) {
     if (!D || !v || !l1 || !work || !beta || M <= 0 || P <= 0 || P > 65535) return TSVGP_EINVAL;
-    const int wpb = NTHREADS / 64;
-    hipLaunchKernelGGL(site_beta_kernel<0>, dim3((unsigned)((M + wpb - 1) / wpb), (unsigned)P), dim3(NTHREADS), 0,
-                       (hipStream_t)stream, D, v, l1, work, beta, M, P);
-    hipLaunchKernelGGL(site_beta_kernel<1>, dim3((unsigned)((M + 63) / 64), (unsigned)P), dim3(NTHREADS), 0, (hipStream_t)stream, D, v,
-                       l1, work, beta, M, P);
+    const int wpb = NTHREADS / 64, nrg = (M + 63) / 64;
+    double* part = work + (size_t)P * M;  // work: t [P][M], then the partial sums [P][nrg][M]
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(site_beta_kernel<0>, dim3((unsigned)((M + wpb - 1) / wpb), 1, (unsigned)P), dim3(NTHREADS), 0, st, D, v, l1, work,
+                       part, beta, M, P);
+    hipLaunchKernelGGL(site_beta_kernel<1>, dim3((unsigned)nrg, (unsigned)nrg, (unsigned)P), dim3(NTHREADS), 0, st, D, v, l1, work, part,
+                       beta, M, P);
+    hipLaunchKernelGGL(site_beta_kernel<2>, dim3((unsigned)((M + NTHREADS - 1) / NTHREADS), 1, (unsigned)P), dim3(NTHREADS), 0, st, D, v,
+                       l1, work, part, beta, M, P);
     return launch_status();
 }
 int tsvgp_step_status_f64(const int32_t* info_a, int na, const int32_t* info_b, int nb, const double* nonpos, double* flags,

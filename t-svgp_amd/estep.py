@@ -409,7 +409,7 @@ class EStepEngine:
         Dm, v, l1 = Dm.contiguous(), v.contiguous(), l1.contiguous()
         P, M = Dm.shape[0], Dm.shape[-1]
         beta = torch.empty_like(l1)
-        work = self._get("site_beta_work", (P * M,), torch.float64)
+        work = self._get("site_beta_work", (P * M * (1 + (M + 63) // 64),), torch.float64)
         with torch.cuda.device(self.device):
             B.check(self.lib.tsvgp_site_beta_f64(Dm.data_ptr(), v.data_ptr(), l1.data_ptr(), work.data_ptr(), beta.data_ptr(), M, P,
                                                  self._stream()), "tsvgp_site_beta")
