@@ -218,6 +218,22 @@ def test_sharded_estep_gloo_world2_matches_single_process_oracle(tmp_path, lik, 
     assert abs(float(got["elbo"]) - ora.elbo((X, Y))) < 1e-9 * abs(ora.elbo((X, Y)))
 
 
+def test_sharded_estep_gloo_world8_matches_single_process_oracle(tmp_path):
+    """The rank count of the metric's largest point (8): 401 rows over eight ranks (shards of 51 and 50 rows), one packed
+    all-reduce per step, against the oracle's single-process steps -- rehearsed here on CPU over gloo because no 8-GPU node has
+    been available (reference src/models/tsvgp.py:278-281, :95 summed over the ranks)."""
+    out = str(tmp_path / "r0.npz")
+    mp.spawn(_worker, args=(8, free_port(), "bernoulli", 1, out), nprocs=8, join=True)
+    got = np.load(out)
+    X, Y, Z = synthetic(N=401, M=20, D=2, P=1, lik="bernoulli", seed=4)
+    _, ora = _pair(Z, "bernoulli", 1, num_data=401)
+    for _ in range(3):
+        ora.natgrad_step((X, Y), lr=0.8)
+    assert relerr(got["l1"], ora.lambda_1) < 1e-9
+    assert relerr(got["L2"], ora.lambda_2) < 1e-9
+    assert abs(float(got["elbo"]) - ora.elbo((X, Y))) < 1e-9 * abs(ora.elbo((X, Y)))
+
+
 @pytest.mark.parametrize("kind,lik,P", [("white", "bernoulli", 1), ("separate", "gaussian", 2), ("separate", "bernoulli", 3)])
 def test_sharded_variants_gloo_world2(tmp_path, kind, lik, P):
     """The same world_size-2 shard + all-reduce path for t_SVGP_white, and separate per-latent kernels, whose M x M algebra is

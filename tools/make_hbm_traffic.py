@@ -17,9 +17,9 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # device kernels (anonymous namespace) behind each C-ABI launch of the E-step
 LAUNCH = {
-    "tsvgp_moments": [r"^panel1_kernel(<(double|float), 1>)?$", r"^panel_kernel<(double|float), 1, \d, (true|false)>$"],
+    "tsvgp_moments": [r"^panel1_kernel(<(double|float), 1(, \d, \d)?>)?$", r"^panel_kernel<(double|float), 1, \d, (true|false)>$"],
     "tsvgp_site_accum": [r"^syrk1f?_kernel$", r"^syrk_kernel<", r"^syrk_reduce_kernel<"],
-    "tsvgp_trmm": [r"^panel1_kernel<(double|float), 0>$", r"^panel_kernel<(double|float), 0, "],
+    "tsvgp_trmm": [r"^panel1_kernel<(double|float), 0(, \d, \d)?>$", r"^panel_kernel<(double|float), 0, "],
     "tsvgp_se_fill": [r"^se_fill_kernel<"],
     "tsvgp_moments_mean_only": [r"^mean_lik_kernel<"],
 }
