@@ -379,6 +379,9 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, TSV
     // replicated M x M chain of every step -- takes 8, i.e. eight times as many workgroups (M = 1024: 256 instead of 32:
     // the launch was 50-60 us of a chain whose every microsecond is on the critical path of an 8-way shard)
     __shared__ __attribute__((aligned(16))) T Xs[FILL_ROWS][DT];  // pre-scaled by inv_ls
+#ifdef TSVGP_FILL_EXPANDED
+    __shared__ T Xn[FILL_ROWS];  // |x~|^2 of the staged rows
+#endif
     typedef typename Mfma<T>::pair_t pair_t;
 
     const T variance = var.v[blockIdx.z];
@@ -397,6 +400,23 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, TSV
         z0[d] = (v0 && d < D) ? Z[(int64_t)m * D + d] * il : T(0);
         z1[d] = (v1 && d < D) ? Z[(int64_t)(m + 1) * D + d] * il : T(0);
     }
+#ifdef TSVGP_FILL_EXPANDED
+    // Round 4 experiment (-DTSVGP_FILL_EXPANDED, measured and NOT the default: profiles/r04_fill_expanded_ab.txt): the scaled squared
+    // distance in the expanded form r2 = |x~|^2 + |z~|^2 - 2 x~.z~ -- GPflow's square_distance [ext] -- instead of
+    // sum_d (x~_d - z~_d)^2: one FMA per dimension and column instead of a subtraction and an FMA (D = 8: 18 instead of 32 of the
+    // ~81 instructions per row pair; D = 16: 34 instead of 64).  fp64, D = 8: 1.93 -> 1.87 ms alone, nothing in the step; fp32,
+    // D = 16: 1.76 -> 1.68 ms, the step 18.83 -> 18.62 ms -- the kernel is not purely VALU-issue bound -- and in fp32 the expanded
+    // form costs accuracy exactly where the E-step has its inducing points (Z = X[:M]: r2 = 0 becomes +-1e-6).  The difference
+    // form stays.
+    T zz0 = T(0), zz1 = T(0);
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+        zz0 += z0[d] * z0[d];
+        zz1 += z1[d] * z1[d];
+        z0[d] *= T(-2);
+        z1[d] *= T(-2);
+    }
+#endif
     // Row blocks are dealt round-robin to the workgroups of a column tile.  The default grid has one workgroup per
     // row block; a smaller grid (tsvgp_kernel_fill's cap) leaves CU slots free for work on another stream.
     const int64_t nrb = (rows_pad + rows_blk - 1) / rows_blk;
@@ -408,6 +428,15 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, TSV
             Xs[rr][d] = (n < N && d < D) ? X[n * D + d] * inv_ls[d] : T(0);
         }
         __syncthreads();
+#ifdef TSVGP_FILL_EXPANDED
+        if (t < rows_blk) {
+            T acc = T(0);
+#pragma unroll
+            for (int d = 0; d < DT; ++d) acc += Xs[t][d] * Xs[t][d];
+            Xn[t] = acc;
+        }
+        __syncthreads();
+#endif
         if (active) {
             // row counts of this block as wave-uniform ints: valid rows get kernel values, the padding rows up to
             // rows_pad zeros.  Invalid columns of the last pair come out as exact zeros through their variance factor.
@@ -416,6 +445,16 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, TSV
             const int nrows = left_pad >= rows_blk ? rows_blk : (int)left_pad;
             T* const Kp = K + n0 * ldk + m;
             for (int rr = 0; rr < nvalid; ++rr) {
+#ifdef TSVGP_FILL_EXPANDED
+                const T xn = Xn[rr];
+                T s0 = xn + zz0, s1 = xn + zz1;
+#pragma unroll
+                for (int d = 0; d < DT; ++d) {
+                    const T x = Xs[rr][d];
+                    s0 = fma(x, z0[d], s0);
+                    s1 = fma(x, z1[d], s1);
+                }
+#else
                 T s0 = T(0), s1 = T(0);
 #pragma unroll
                 for (int d = 0; d < DT; ++d) {
@@ -424,6 +463,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, TSV
                     s0 += d0 * d0;
                     s1 += d1 * d1;
                 }
+#endif
                 pair_t out;
 #ifdef TSVGP_EXP_NOEXP  // ablation switch (tools/exp_fill.py): the store-bound floor of the kernel
                 out[0] = var0 * (T(1) - T(0.5) * s0);

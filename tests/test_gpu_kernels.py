@@ -51,8 +51,9 @@ def test_se_fill(engines, dtype, tol, N, M, D):
 
 def test_se_fill_exp_is_the_library_exp_bit_for_bit(engines):
     """The fill's own fp64 exp (same reduction and polynomial as the device library's, fewer instructions) against
-    torch.exp on the device, D = 1 so that the exponent's argument is formed identically on both sides: exact equality
-    over arguments from 0 down into the underflow range, and zeros (not NaN) far below it."""
+    torch.exp on the device, D = 1 and Z = 0 so that the exponent's argument is formed identically on both sides (the expanded
+    form x^2 + z^2 - 2 x z is then x^2 exactly): exact equality over arguments from 0 down into the underflow range, and zeros
+    (not NaN) far below it."""
     eng = engines[torch.float64]
     B = pkg()._backend
     N, M = 4096, 128
@@ -60,11 +61,9 @@ def test_se_fill_exp_is_the_library_exp_bit_for_bit(engines):
     X = (torch.rand(N, 1, generator=g, dtype=torch.float64) * 80.0).to("cuda:0")  # -0.5 s down to -3200
     X[:8, 0] = torch.tensor([0.0, 1e-9, 1.0, 38.6, 38.7, 46.4, 46.6, 1e6], dtype=torch.float64)
     Z = torch.zeros(M, 1, dtype=torch.float64, device="cuda:0")
-    Z[1:, 0] = torch.rand(M - 1, generator=g, dtype=torch.float64).to("cuda:0")
     out = torch.empty((B.round_up(N), B.round_up(M)), dtype=torch.float64, device="cuda:0")
     eng.se_fill(X, Z, torch.ones(1, dtype=torch.float64, device="cuda:0"), 1.0, out)
-    d = X - Z.t()
-    ref = torch.exp(-0.5 * (d * d))
+    ref = torch.exp(-0.5 * (X * X)).expand(N, M)
     assert torch.equal(out[:N, :M], ref)
     assert float(out[7, 0]) == 0.0 and int((ref == 0).sum()) > 0 and int((ref > 0.5).sum()) > 0
 
