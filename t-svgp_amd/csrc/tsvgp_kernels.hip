@@ -1483,6 +1483,15 @@ __global__ __launch_bounds__(NTHREADS, 1) void panel1_kernel(PanelArgs<T> a) {
                     }
                 continue;
             }
+#ifdef TSVGP_EXP_NOEPI  // ablation (profiles/r04_moments_epilogue_ablation.txt): the column tile's square-sum epilogue left out --
+            // what a second accumulator set could at most hide.  The accumulators stay live (the MFMAs are not dead code); results wrong.
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int n = 0; n < NB; ++n) asm volatile("" ::"a"(acc[s][n]));
+            rs_mine += (double)acc[0][0][0];
+            continue;
+#endif
             // the column tile is complete: squares of its entries, summed per row (as panel_kernel)
             double keep = 0.0;
 #pragma unroll
