@@ -1064,6 +1064,25 @@ constexpr size_t P1W_GAMMA_LDS_MAX = 32 * 1024;  // two tiles per pass: beside t
 #define TSVGP_MOMENTS_OLD_F32 0
 #endif
 
+// Sum over the 16 lanes of a DPP row (lanes 16 g .. 16 g + 15), left in every lane of the row: four rotate-and-add steps through
+// v_mov_b32_dpp row_ror (two per double), no LDS crossbar and no s_waitcnt -- the xor butterfly of __shfl_xor compiles to
+// ds_bpermute_b32 pairs, each waited for: 64 of them and 32 waits per column-tile epilogue of panel1_kernel (round 4: that
+// epilogue is 1.8 % of the fp64 moments kernel, 3.7 % of the fp32 one -- profiles/r04_moments_epilogue_ablation.txt).  All lanes of
+// a row end with bit-identical sums (every step adds the same two partial sums in either order).
+template <int CTRL>
+__device__ __forceinline__ double dpp_row_mov(double v) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, true);  // (every lane of a rotation has a source:
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, true);  //  no "old" value to initialise)
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row16_sum(double q) {
+    q += dpp_row_mov<0x128>(q);  // row_ror:8
+    q += dpp_row_mov<0x124>(q);  // row_ror:4
+    q += dpp_row_mov<0x122>(q);  // row_ror:2
+    q += dpp_row_mov<0x121>(q);  // row_ror:1
+    return q;
+}
+
 template <int I, int N, class F>
 __device__ __forceinline__ void cfor(F&& f) {
     if constexpr (I < N) {
@@ -1499,15 +1518,29 @@ __global__ __launch_bounds__(NTHREADS, 1) void panel1_kernel(PanelArgs<T> a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     double q = 0.0;
+                    if constexpr (sizeof(T) == 4) {
+                        // fp32 N-arrays: the tile's entries ARE fp32 accumulators (relative error ~1e-6 from the fp32 MFMAs); the
+                        // squares of a row's NB entries are summed in fp32 (1e-7) and converted once -- it was a conversion and an
+                        // fp64 FMA per entry: 64 v_cvt_f64_f32 per lane and tile in an epilogue that is 3.7 % of this kernel
+                        float q32 = 0.0f;
 #pragma unroll
-                    for (int n = 0; n < NB; ++n) {
-                        const double v = (double)acc[s][n][r];
-                        q += v * v;
+                        for (int n = 0; n < NB; ++n) q32 = fmaf(acc[s][n][r], acc[s][n][r], q32);
+                        q = (double)q32;
+                    } else {
+#pragma unroll
+                        for (int n = 0; n < NB; ++n) {
+                            const double v = (double)acc[s][n][r];
+                            q += v * v;
+                        }
                     }
+#ifdef TSVGP_EPI_SHFL  // (A/B builds: round 3's butterfly through the LDS crossbar)
                     q += __shfl_xor(q, 1);
                     q += __shfl_xor(q, 2);
                     q += __shfl_xor(q, 4);
                     q += __shfl_xor(q, 8);
+#else
+                    q = row16_sum(q);
+#endif
                     keep = ((lane & 7) == s * 4 + r) ? q : keep;
                 }
             rs_mine += keep;
