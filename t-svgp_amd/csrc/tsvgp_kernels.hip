@@ -1057,6 +1057,17 @@ constexpr int P1_OPS = TILE * 16;    // 8-byte fragment units per operand image 
 constexpr int P1_BUFS = 2 * P1_OPS;  // fragment units per chunk buffer (A image + T image, 32 KB)
 constexpr size_t P1_GAMMA_LDS_MAX = 64 * 1024;  // dynamic LDS for gamma_p beside the 64 KB ring: Mp <= 8192 (fp32: 16384)
 constexpr size_t P1W_GAMMA_LDS_MAX = 32 * 1024;  // two tiles per pass: beside the 96 KB ring (Mp <= 4096 in fp64)
+// Upper form, one tile per pass: the chunks of a tile's DIAGONAL k-tile in the order 8, 1, 7, 2, 6, 3, 5, 4 column blocks (fp32: 8, 2,
+// 6, 4) instead of 1, 2, ... 8 (round 4).  A chunk of c + 2 is requested while chunk c runs and must have landed when chunk c + 1
+// ends: behind two SHORT chunks (1 and 2 column blocks: 8 + 16 MFMAs per wave, ~0.7 us) it has not -- the ascending order stalled
+// on chunks 2, 3, 4 of every diagonal k-tile, ~2.5 us per column tile (phase accounting of round 3: the diagonal chunks at 0.81 of
+// their MFMA time) -- while a long and a short chunk together last as long as a full one.  All of a tile's accumulators are then
+// first touched by its first chunk (srcC = 0 folds into those MFMAs).  Measured (profiles/r04_moments_epilogue_ablation.txt,
+// moments alone at N = 1e6): fp64 M = 512 4.20 -> 4.10 ms (-2.5 %), fp64 M = 1024 unchanged (15.18 ms), fp32 (four diagonal chunks of
+// 2, 4, 6, 8 column blocks) 7.71 -> 7.81 ms SLOWER -- so fp64 only.  -DTSVGP_DIAG_ORDER=0: the ascending order (A/B builds).
+#ifndef TSVGP_DIAG_ORDER
+#define TSVGP_DIAG_ORDER 1
+#endif
 #ifndef TSVGP_MOMENTS_WIDE  // (-DTSVGP_MOMENTS_WIDE=0: A/B builds keep one column tile per pass)
 #define TSVGP_MOMENTS_WIDE 0
 #endif
@@ -1215,8 +1226,16 @@ __global__ __launch_bounds__(NTHREADS, 1) void panel1_kernel(PanelArgs<T> a) {
         const unsigned lds_u = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_base);
         unsigned dma_vo = 0;
         uint64_t tb_u = 0;
+        constexpr bool REORDER = TSVGP_DIAG_ORDER && W2 == 1 && TRI == TSVGP_TRI_UPPER && sizeof(T) == 8;
+        // REORDER: cu.c counts POSITIONS in the tile's stream; position q < CPT of the diagonal k-tile is its chunk
+        // (q even ? CPT - 1 - q / 2 : q / 2), i.e. 7, 0, 6, 1, 5, 2, 4, 3
+        auto kchunk = [&](const Cursor cu) TSVGP_AI {
+            if constexpr (!REORDER) return cu.c;
+            const int q = cu.c - cu.it * CPT;
+            return q < CPT ? cu.it * CPT + ((q & 1) ? (q >> 1) : CPT - 1 - (q >> 1)) : cu.c;
+        };
         auto dma_setup = [&](const Cursor cu) TSVGP_AI {
-            dma_vo = dvoff + (unsigned)(cu.c * KC * sizeof(T));
+            dma_vo = dvoff + (unsigned)(kchunk(cu) * KC * sizeof(T));
             tb_u = uni64(Tp + ((size_t)cu.it * TILE + 8 * w) * Mp);
         };
         // piece I of a chunk: I < 8: I even -> A piece I / 2, I odd -> piece I / 2 of the first T image; I >= 8: piece I - 8 of the second
@@ -1369,7 +1388,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void panel1_kernel(PanelArgs<T> a) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __syncthreads();  // both chunks and gamma are in LDS for every wave
         // a0, a1, b0 (fp32: and b1) of chunk (0, 0); lower form: tile 0 starts with its diagonal k-tile, all eight column blocks
-        cfor<0, (TRI == TSVGP_TRI_UPPER ? 2 + BPC : 10)>([&](auto i) TSVGP_AI { rd1(fx, i, TSVGP_IC(0), TSVGP_IC(0)); });
+        cfor<0, ((TRI == TSVGP_TRI_UPPER && !REORDER) ? 2 + BPC : 10)>([&](auto i) TSVGP_AI { rd1(fx, i, TSVGP_IC(0), TSVGP_IC(0)); });
 
         for (int it = 0; it < ntile; it += W2) {
             const int cd = it * CPT;
@@ -1377,6 +1396,23 @@ __global__ __launch_bounds__(NTHREADS, 1) void panel1_kernel(PanelArgs<T> a) {
             // an accumulator is zeroed in front of the diagonal chunk that first touches its column block
 #define TSVGP_ZACC(n_) { acc[0][n_] = acc_t{0, 0, 0, 0}; acc[1][n_] = acc_t{0, 0, 0, 0}; }
             auto diag = [&](auto gc) TSVGP_AI {
+                if constexpr (REORDER) {
+                    cfor<0, 8>([&](auto n) TSVGP_AI {
+                        acc[0][decltype(n)::value] = acc_t{0, 0, 0, 0};
+                        acc[1][decltype(n)::value] = acc_t{0, 0, 0, 0};
+                    });
+                    // position q: chunk j(q) of the diagonal k-tile, column blocks 0 .. BPC (j + 1) - 1
+                    cfor<0, CPT - 1>([&](auto q_tag) TSVGP_AI {
+                        constexpr int Q = decltype(q_tag)::value;
+                        constexpr int J = (Q & 1) ? (Q >> 1) : CPT - 1 - (Q >> 1);
+                        constexpr int JN = ((Q + 1) & 1) ? ((Q + 1) >> 1) : CPT - 1 - ((Q + 1) >> 1);
+                        chunk(TSVGP_IC((1 << (BPC * (J + 1))) - 1), TSVGP_IC((1 << (BPC * (JN + 1))) - 1), TSVGP_IC(Q & 1), gc, cd + J);
+                    });
+                    constexpr int JL = ((CPT - 1) & 1) ? ((CPT - 1) >> 1) : CPT - 1 - ((CPT - 1) >> 1);  // the last position's chunk
+                    if (!last_tile) chunk(TSVGP_IC((1 << (BPC * (JL + 1))) - 1), TSVGP_IC(0xFF), TSVGP_IC(1), gc, cd + JL);
+                    else chunk(TSVGP_IC((1 << (BPC * (JL + 1))) - 1), TSVGP_IC(0), TSVGP_IC(1), gc, cd + JL);  // the end of the stream
+                    return;
+                }
                 if constexpr (CPT == 8) {
                     TSVGP_ZACC(0) chunk(TSVGP_IC(0x01), TSVGP_IC(0x03), TSVGP_IC(0), gc, cd);
                     TSVGP_ZACC(1) chunk(TSVGP_IC(0x03), TSVGP_IC(0x07), TSVGP_IC(1), gc, cd + 1);
@@ -1402,7 +1438,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void panel1_kernel(PanelArgs<T> a) {
                     chunk(TSVGP_IC(0xFF), TSVGP_IC(0xFF), TSVGP_IC(1), gc, c + 1);
                 }
                 chunk(TSVGP_IC(0xFF), TSVGP_IC(0xFF), TSVGP_IC(0), gc, c_last - 1);
-                chunk(TSVGP_IC(0xFF), TSVGP_IC((1 << BPC) - 1), TSVGP_IC(1), gc, c_last);
+                chunk(TSVGP_IC(0xFF), TSVGP_IC(REORDER ? 0xFF : (1 << BPC) - 1), TSVGP_IC(1), gc, c_last);
             };
 #undef TSVGP_ZACC
             // lower form: the full k-tiles 0 .. it - 1 first, then the diagonal one, whose chunk j meets the column blocks from
