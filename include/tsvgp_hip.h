@@ -334,13 +334,6 @@ int tsvgp_kernel_grad_f32(int kind, const float *X, const float *Z, const float 
 int tsvgp_selftest_mfma_f64(const double *a, const double *b, double *c, void *stream);
 int tsvgp_selftest_mfma_f32(const float *a, const float *b, float *c, void *stream);
 
-/* A stream for work that runs BESIDE the caller's stream (the K(X, Z) fill next to the M x M prelude; the reference has no
- * counterpart: TensorFlow schedules its ops itself).  priority_class: -1 the lowest priority the device offers, 0 the
- * default, +1 the highest.  The stream is non-blocking (no implicit ordering with the null stream); order it against the
- * caller's stream with events.  Destroy it with tsvgp_stream_destroy once its work has completed. */
-int tsvgp_stream_create(int priority_class, void **stream_out);
-int tsvgp_stream_destroy(void *stream);
-
 #ifdef __cplusplus
 }
 #endif

@@ -123,8 +123,6 @@ _PROTOTYPES = {
     "tsvgp_sym_unpack_f64": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p]),
     "tsvgp_selftest_mfma_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "tsvgp_selftest_mfma_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
-    "tsvgp_stream_create": (c_int, [c_int, c_void_p]),
-    "tsvgp_stream_destroy": (c_int, [c_void_p]),
 }
 
 

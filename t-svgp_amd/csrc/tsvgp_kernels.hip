@@ -4331,19 +4331,5 @@ int tsvgp_selftest_mfma_f32(const float* a, const float* b, float* c, void* stre
     hipLaunchKernelGGL(selftest_kernel<float>, dim3(1), dim3(64), 0, (hipStream_t)stream, a, b, c);
     return launch_status();
 }
-int tsvgp_stream_create(int priority_class, void** stream_out) {
-    if (!stream_out || priority_class < -1 || priority_class > 1) return TSVGP_EINVAL;
-    int least = 0, greatest = 0;  // numerically: least >= greatest (lower number = higher priority)
-    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return TSVGP_ELAUNCH;
-    const int pr = priority_class < 0 ? least : priority_class > 0 ? greatest : 0;
-    hipStream_t st = nullptr;
-    if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, pr) != hipSuccess) return TSVGP_ELAUNCH;
-    *stream_out = st;
-    return TSVGP_OK;
-}
-int tsvgp_stream_destroy(void* stream) {
-    if (!stream) return TSVGP_EINVAL;
-    return hipStreamDestroy((hipStream_t)stream) == hipSuccess ? TSVGP_OK : TSVGP_ELAUNCH;
-}
 
 }  // extern "C"

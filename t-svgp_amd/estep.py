@@ -30,7 +30,6 @@ from .distributed import world_size
 from .kernels import SeparateIndependent
 
 MAX_INPUT_DIM = 32  # the fill kernel pads D to a compile-time size (1, 2, 4, 8, 16, 32)
-FILL_PRIORITY = "normal"  # priority class of the fill's side stream (low | normal | high); TSVGP_FILL_PRIORITY overrides
 MAX_INPUT_DIM_GRAD = 16  # tsvgp_kernel_grad_* (M-step): 1, 2, 4, 8, 16; beyond: GEMM form (tsvgp_gram_to_gradw_*)
 
 
@@ -715,21 +714,6 @@ class EStepEngine:
         return out
 
     # ------------------------------------------------------------------ K(X, Z) fill beside the M x M prelude
-    def _side_stream(self, dev):
-        """The stream of the fill.  TSVGP_FILL_PRIORITY = low | high asks the C-ABI library for a HIP stream of that priority
-        class (tsvgp_stream_create) and hands it to torch as an external stream; anything else is a pool stream of torch's."""
-        if self._side is None:
-            cls = {"low": -1, "high": 1}.get(os.environ.get("TSVGP_FILL_PRIORITY", FILL_PRIORITY))
-            if cls is None:
-                self._side = torch.cuda.Stream(dev)
-            else:
-                raw = ctypes.c_void_p()
-                with torch.cuda.device(dev):
-                    B.check(B.lib().tsvgp_stream_create(cls, ctypes.byref(raw)), "tsvgp_stream_create")
-                self._side_raw = raw  # lives as long as the engine (the process, for the model's engine)
-                self._side = torch.cuda.ExternalStream(raw.value, device=dev)
-        return self._side
-
     def start_fill(self, X, Z, kernel, b_tag=None, want="Kfu", routes=None):
         """Starts the K(X, Z) fill of the next ``run`` on a side stream and returns a ticket for ``run(prefill=...)``.
         The fill needs only X, Z and the kernel parameters, so it can run beside the latency-bound M x M prelude
@@ -756,7 +740,9 @@ class EStepEngine:
             if self._batch_plan(N, M, kernel, P, None, B.TRI_UPPER, None, False, D=D) is None:
                 return None
             main = torch.cuda.current_stream(dev)
-            side = self._side_stream(dev)
+            if self._side is None:
+                self._side = torch.cuda.Stream(dev)
+            side = self._side
             Xc = X.to(device=dev, dtype=T).contiguous()
             Zc = Z.to(device=dev, dtype=T).contiguous()
             self._b_tag = None
@@ -777,7 +763,9 @@ class EStepEngine:
                 and tuple(self._buf[want].shape) == (Np, Mp)):
             return None
         main = torch.cuda.current_stream(dev)
-        side = self._side_stream(dev)
+        if self._side is None:
+            self._side = torch.cuda.Stream(dev)
+        side = self._side
         Xc = X.to(device=dev, dtype=T).contiguous()
         Zc = Z.to(device=dev, dtype=T).contiguous()
         inv_ls = kernel.inv_lengthscales(D, T, dev)
