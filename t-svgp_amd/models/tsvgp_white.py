@@ -312,12 +312,10 @@ class t_SVGP_white(base_SVGP):
 
         return self._routed(go)
 
-    def _kuu_grad_mu(self, X, Y, jitter=1e-9, kuu_jitter=0.0, direct=False, two_product=False):
-        """compute_data_natural_params (tsvgp_white.py:183-212) with K_uu + kuu_jitter I already applied, which is how both
-        callers use it: returns (K grad_mu[0] [M, 1], K grad_mu[1] K [1, M, M], rows, nonpos, ops).
-        With s1 = sum g0 k, S2 = sum g1 k k^T and K9 = K_uu + jitter I:  grad_mu[0] = K9^-1 (s1 - 2 S2 K9^-1 meanZ),
-        grad_mu[1] = K9^-1 S2 K9^-1, so K grad_mu = (I - (jitter - kuu_jitter) K9^-1)(...): no product with an
-        ill-conditioned inverse is ever formed."""
+    def _site_sums_k(self, X, Y, jitter=1e-9, direct=False, two_product=False):
+        """The N-pass of compute_data_natural_params (tsvgp_white.py:183-206) in terms of k_n = K(Z, x_n):
+        returns (S2 = sum g1 k k^T [1, M, M], s1 = sum g0 k [M, 1], K9^-1 meanZ [M, 1], rows, nonpos, ops) with
+        K9 = K_uu + jitter I and meanZ = predict_f(Z) (:186)."""
         ops = self._operands(jitter=jitter, direct=direct, two_product=two_product)
         # tsvgp_white.py:188-191: no crop of d ve / d var in this class
         st = self._run(X, Y, ops, self.likelihood.lik_id | B.LIK_NOCROP, sites=True)
@@ -330,11 +328,39 @@ class t_SVGP_white(base_SVGP):
             S2 = U6 @ acc2 @ U6.transpose(-1, -2)  # sum g1 k k^T   [1, M, M]
             s1 = U6 @ acc1.transpose(-1, -2)  # sum g0 k     [M, 1]
             gamma_k = Uinv6.transpose(-1, -2) @ ops["gamma"]  # R^-1 lambda_1
-        Mj = Id - (jitter - kuu_jitter) * K9inv  # (Kuu + kuu_jitter I) K9^-1
         a_meanZ = (Id - jitter * K9inv) @ gamma_k  # K9^-1 meanZ, meanZ = Kuu R^-1 lambda_1 (predict_f at Z, :186)
+        return S2, s1, a_meanZ, rows, nonpos, ops
+
+    def _kuu_grad_mu(self, X, Y, jitter=1e-9, kuu_jitter=0.0, direct=False, two_product=False):
+        """compute_data_natural_params (tsvgp_white.py:183-212) with K_uu + kuu_jitter I already applied, which is how both
+        callers use it: returns (K grad_mu[0] [M, 1], K grad_mu[1] K [1, M, M], rows, nonpos, ops).
+        With s1 = sum g0 k, S2 = sum g1 k k^T and K9 = K_uu + jitter I:  grad_mu[0] = K9^-1 (s1 - 2 S2 K9^-1 meanZ),
+        grad_mu[1] = K9^-1 S2 K9^-1, so K grad_mu = (I - (jitter - kuu_jitter) K9^-1)(...): no product with an
+        ill-conditioned inverse is ever formed."""
+        S2, s1, a_meanZ, rows, nonpos, ops = self._site_sums_k(X, Y, jitter, direct, two_product)
+        Mj = ops["Id"] - (jitter - kuu_jitter) * ops["K9inv"]  # (Kuu + kuu_jitter I) K9^-1
         KG1K = Mj @ S2 @ Mj.transpose(-1, -2)  # K G1 K
         Kg0 = Mj @ s1 - 2.0 * (Mj @ (S2[0] @ a_meanZ))  # K (G0 - 2 G1 meanZ), util.py:429-438
         return Kg0, KG1K, rows, nonpos, ops
+
+    def compute_data_natural_params(self, data, jitter=1e-9, nat_params=None):
+        """The data term's gradient with respect to the expectation parameters at the inducing points
+        (tsvgp_white.py:181-209):  returns [grad_mu[0] [M, 1], grad_mu[1] [1, M, M]] with, for A = K(X, Z) K9^-1
+        (K9 = K_uu + jitter I, :196-199),  G0 = A^T g0, G1 = A^T diag(g1) A (:203-206) and
+        grad_mu = [G0 - 2 G1 meanZ, G1] (util.py:429-438).  Unlike natgrad_step and predict_f_extra_data, which only ever
+        need K grad_mu, this forms the products with K9^-1 themselves, as the reference does: the result carries
+        cond(K9) times the rounding of the sums.  ``nat_params`` is accepted and ignored, as in the reference.  The state is
+        not touched.  With more than one rank ``data`` is this rank's row shard (the sums are all-reduced)."""
+        X, Y = self._as_device(data[0]), self._as_device(data[1])
+
+        def go(direct, two_product):
+            S2, s1, a_meanZ, _, nonpos, ops = self._site_sums_k(X, Y, jitter, direct, two_product)
+            self._check(ops, nonpos)  # predict_f(X) asserts positivity (:131)
+            K9inv = ops["K9inv"]
+            G1 = K9inv @ S2 @ K9inv
+            return [K9inv @ (s1 - 2.0 * (S2[0] @ a_meanZ)), 0.5 * (G1 + G1.transpose(-1, -2))]
+
+        return self._routed(go)
 
     def natgrad_step(self, dataset, lr=0.1, jitter=1e-9):
         """One natural-gradient step on (lambda_1, Lambda_2) (tsvgp_white.py:183-248); returns None."""

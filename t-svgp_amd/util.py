@@ -159,6 +159,78 @@ def conditional_from_precision_sites(Kuu, Kff, Kuf, l, L=None, L2=None):
     return mean, cov
 
 
+def _dense_site(L, L2, who):
+    if L is None and L2 is None:
+        raise ValueError(f"{who}: one of L (a factor of the precision site) and L2 (the site itself) is needed")
+    return L @ L.transpose(-1, -2) if L2 is None else L2
+
+
+def conditional_from_precision_sites_white(Kuu, Kff, Kuf, l, L=None, L2=None, jitter=1e-9):
+    """Predictive moments for sites stored pre-multiplied by K_uu (reference src/util.py:11-88), dense torch form for small N.
+
+    With R = L2 + Kuu + jitter I:  mean = Kuf^T R^-1 l,  cov = Kff - |chol(Kuu)^-1 Kuf|^2 + |chol(R)^-1 Kuf|^2 (column sums).
+    Kuu [M, M], Kff [N, 1], Kuf [M, N], l [M, 1], L / L2 [1, M, M] -> mean [N, 1], cov [N, 1] (one latent, as the
+    reference's ``[0]`` at :87).  ``t_SVGP_white.predict_f`` runs the same algebra through the HIP moments kernel instead.
+    """
+    L2 = _dense_site(L, L2, "conditional_from_precision_sites_white()")
+    if Kuf.dim() != 2 or Kuf.shape[0] != Kuu.shape[-1] or Kff.shape != (Kuf.shape[1], 1):
+        raise ValueError("conditional_from_precision_sites_white(): Kuf must be [M, N] and Kff [N, 1]")
+    Id = torch.eye(Kuu.shape[-1], dtype=Kuu.dtype, device=Kuu.device)
+    LR = cholesky(L2 + Kuu + jitter * Id)  # [1, M, M]
+    LA = cholesky(Kuu)
+    a = torch.linalg.solve_triangular(LA, Kuf, upper=False)  # [M, N]
+    r = torch.linalg.solve_triangular(LR, Kuf.expand(LR.shape[0], -1, -1), upper=False)  # [1, M, N]
+    cov = Kff - (torch.sum(a * a, dim=-2) - torch.sum(r * r, dim=-2)).transpose(-1, -2)
+    mean = (Kuf.transpose(-1, -2) @ torch.cholesky_solve(l, LR))[0]
+    return mean, cov
+
+
+def kl_from_precision_sites_white(A, l, L=None, L2=None):
+    """KL[q(u) || p(u)] for q(u) ~ N(u; A R^-1 l, A R^-1 A), R = L2 + A, p(u) = N(0, A)   (reference src/util.py:239-291):
+        1/2 [ log|R| - log|A| + tr(R^-1 A) - M + |chol(A)^T R^-1 l|^2 ].   A [M, M], l [M, 1], L / L2 [1, M, M] -> scalar."""
+    L2 = _dense_site(L, L2, "kl_from_precision_sites_white()")
+    LR = cholesky(L2 + A)
+    LA = cholesky(A)
+    logdet = lambda C: 2.0 * torch.sum(torch.log(torch.diagonal(C, dim1=-2, dim2=-1)))
+    t = torch.linalg.solve_triangular(LR, LA.expand(LR.shape[0], -1, -1), upper=False)
+    maha = LA.transpose(-1, -2) @ torch.cholesky_solve(l, LR)
+    return 0.5 * (logdet(LR) - logdet(LA) + torch.sum(t * t) - float(A.shape[-1]) + torch.sum(maha * maha))
+
+
+# the reference keeps a second copy of the same function under this name (src/util.py:294-346)
+kl_from_precision_sites = kl_from_precision_sites_white
+
+
+def posterior_from_dense_site_white(K, lambda_1, lambda_2, jitter=1e-9):
+    """Mean and Cholesky factor of q(u) for sites stored pre-multiplied by K (reference src/util.py:394-426):
+    R = K + lambda_2 (+ jitter I in its factor),  S = K R^-1 K,  m = K R^-1 lambda_1.
+    K [M, M], lambda_1 [M, 1], lambda_2 [1, M, M] -> m [M, 1], chol(S) [1, M, M]."""
+    Id = torch.eye(K.shape[-1], dtype=K.dtype, device=K.device)
+    LR = cholesky(K + lambda_2 + jitter * Id)
+    t = torch.linalg.solve_triangular(LR, K.expand(LR.shape[0], -1, -1), upper=False)
+    S_q = t.transpose(-1, -2) @ t
+    m_q = (K @ torch.cholesky_solve(lambda_1, LR))[0]
+    return m_q, cholesky(S_q)
+
+
+_factor = cholesky  # project_diag_sites keeps the reference's keyword ``cholesky``, which hides the function inside it
+
+
+def project_diag_sites(Kuf, lambda_1, lambda_2, Kuu=None, cholesky=True):
+    """Per-datum (diagonal) sites projected onto the inducing points (reference src/util.py:188-236):
+        l = P lambda_1,  L2 = P diag(lambda_2) P^T,  P = Kuf, or Kuu^-1 Kuf when ``Kuu`` is given;  returns (l, chol(L2)) or (l, L2).
+    Kuf [M, N] or [P, M, N], lambda_1 / lambda_2 [N, P], Kuu [M, M] or [P, M, M] -> l [M, P], L [P, M, M].  Dense torch form:
+    the reference uses it in its per-datum-site model (t_SVGP_sites, out of this package's scope) and its tests."""
+    nl = lambda_1.shape[-1]
+    Pm = Kuf[None].expand(nl, -1, -1) if Kuf.dim() == 2 else Kuf
+    if Kuu is not None:
+        Kb = Kuu[None] if Kuu.dim() == 2 else Kuu
+        Pm = torch.cholesky_solve(Pm, _factor(Kb).expand(nl, -1, -1))
+    l = torch.einsum("lmn,nl->ml", Pm, lambda_1)
+    L2 = torch.einsum("lmn,lon,nl->lmo", Pm, Pm, lambda_2)
+    return l, (_factor(L2) if cholesky else L2)
+
+
 def site_projection_D(K, L, return_chol=False, infos=None, potrf=None):
     """D = chol(W)^-1 L^T with W = I + L^T K L  (reference src/util.py:168-175); [P, M, M].
 

@@ -135,6 +135,38 @@ def test_white_predict_f_extra_data(lik):
 
 
 @pytest.mark.parametrize("lik", ["gaussian", "bernoulli"])
+def test_white_compute_data_natural_params(lik):
+    """compute_data_natural_params (tsvgp_white.py:181-209) on the HIP path, every projection route, against the oracle:
+    [G0 - 2 G1 meanZ [M, 1], G1 [1, M, M]]; K_uu applied to it is what natgrad_step adds to the sites (:244-245)."""
+    p = pkg()
+    rng = np.random.RandomState(43)
+    X, Y, _ = synthetic(N=800, M=40, D=3, P=1, lik=lik, seed=8)
+    Z = rng.randn(40, 3) * 1.3
+    mk = lambda mod: mod.t_SVGP_white(mod.SquaredExponential(1.1, 1.0), mod.Gaussian(0.2) if lik == "gaussian" else mod.Bernoulli(), Z)
+    hip, ora = mk(p), mk(O)
+    for _ in range(2):
+        hip.natgrad_step((X, Y), lr=0.8)
+        ora.natgrad_step((X, Y), lr=0.8)
+    l1, L2 = hip.lambda_1.numpy().copy(), hip.lambda_2.numpy().copy()
+    want = ora.compute_data_natural_params((X, Y))
+    K = O.Kuu(ora.inducing_variable, ora.kernel)
+    tol = max(1e-8, 1000 * np.linalg.cond(K + 1e-9 * np.eye(40)) * 2.2e-16)  # explicit K9^-1 products on both sides
+    for projection in ("auto", "whitened", "direct"):
+        hip.projection = projection
+        got = hip.compute_data_natural_params((X, Y))
+        assert tuple(got[0].shape) == (40, 1) and tuple(got[1].shape) == (1, 40, 40)
+        assert relerr(got[0].cpu().numpy(), want[0]) < tol and relerr(got[1].cpu().numpy(), want[1]) < tol
+    assert np.array_equal(hip.lambda_1.numpy(), l1) and np.array_equal(hip.lambda_2.numpy(), L2)
+    # a full step (lr = 1) from these sums is the state natgrad_step itself reaches
+    hip.projection = "auto"
+    got = hip.compute_data_natural_params((X, Y))
+    hip.natgrad_step((X, Y), lr=1.0)
+    Kt = hip.lambda_1.value.new_tensor(K)
+    assert relerr(hip.lambda_1.numpy(), (Kt @ got[0]).cpu().numpy()) < tol
+    assert relerr(hip.lambda_2.numpy(), (-2.0 * Kt @ got[1] @ Kt).cpu().numpy()) < tol
+
+
+@pytest.mark.parametrize("lik", ["gaussian", "bernoulli"])
 @pytest.mark.parametrize("projection", ["direct", "whitened", "auto"])
 def test_white_projection_routes_match_oracle(lik, projection):
     """The direct route of t_SVGP_white (no N-sized whitening: moments on K(X, Z) with the factor of Q = K6^-1 - R^-1,

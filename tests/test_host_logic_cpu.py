@@ -99,6 +99,30 @@ def test_white_predict_f_extra_data_host_logic():
         assert np.array_equal(hip.lambda_1.numpy(), l1)
 
 
+def test_white_compute_data_natural_params_host_logic():
+    """t_SVGP_white.compute_data_natural_params (tsvgp_white.py:181-209): [G0 - 2 G1 meanZ, G1] in the reference's shapes,
+    on every projection route, against the oracle; the state is not touched and ``nat_params`` is ignored."""
+    for lik in ("gaussian", "bernoulli"):
+        X, Y, Z = synthetic(N=200, M=16, D=2, P=1, lik=lik, seed=3)
+        hip, ora = _pair(Z, lik, 1, num_data=200, kind="white")
+        for _ in range(2):
+            hip.natgrad_step((X, Y), lr=0.8)
+            ora.natgrad_step((X, Y), lr=0.8)
+        l1, L2 = hip.lambda_1.numpy().copy(), hip.lambda_2.numpy().copy()
+        want = ora.compute_data_natural_params((X, Y))
+        assert want[0].shape == (16, 1) and want[1].shape == (1, 16, 16)
+        for projection in ("auto", "whitened", "direct"):
+            hip.projection = projection
+            got = hip.compute_data_natural_params((X, Y), nat_params="ignored")
+            assert tuple(got[0].shape) == (16, 1) and tuple(got[1].shape) == (1, 16, 16)
+            assert relerr(got[0].numpy(), want[0]) < 1e-8 and relerr(got[1].numpy(), want[1]) < 1e-8
+        want5 = ora.compute_data_natural_params((X, Y), jitter=1e-5)
+        got5 = hip.compute_data_natural_params((X, Y), jitter=1e-5)
+        assert relerr(got5[0].numpy(), want5[0]) < 1e-8 and relerr(got5[1].numpy(), want5[1]) < 1e-8
+        assert relerr(want5[1], want[1]) > 1e-7  # the jitter argument reaches the projection (:198)
+        assert np.array_equal(hip.lambda_1.numpy(), l1) and np.array_equal(hip.lambda_2.numpy(), L2)
+
+
 @pytest.mark.parametrize("lik", ["gaussian", "bernoulli"])
 def test_white_direct_route_host_logic(lik):
     """t_SVGP_white(projection="direct"): moments on k with the factor of Q = K6^-1 - R^-1, sums over k k^T -- the same
@@ -158,6 +182,37 @@ def test_util_functions_match_oracle():
         p.util.cholesky(t(-np.eye(3)))
     with pytest.raises(ValueError):
         p.util.posterior_from_dense_site(t(K), t(l1[:, :1]), t(L))  # shape mismatch (util.py:368-372)
+    # the forms for sites stored pre-multiplied by K_uu (util.py:11-88, 239-291, 294-346, 394-426), one latent
+    lw = rng.randn(M, 1)
+    Lw = np.tril(rng.randn(1, M, M)) * 0.3 + np.eye(M)
+    L2w = Lw @ np.swapaxes(Lw, -1, -2)
+    for kw_t, kw_o in ((dict(L=t(Lw)), dict(L=Lw)), (dict(L2=t(L2w)), dict(L2=L2w))):
+        mu, cov = p.util.conditional_from_precision_sites_white(t(K), t(Kff), t(Kuf), t(lw), **kw_t)
+        muo, covo = O.conditional_from_precision_sites_white(K, Kff, Kuf, lw, **kw_o)
+        assert mu.shape == (N, 1) and cov.shape == (N, 1)
+        assert relerr(mu.numpy(), muo) < 1e-11 and relerr(cov.numpy(), covo) < 1e-11
+        for fn in (p.util.kl_from_precision_sites_white, p.util.kl_from_precision_sites):
+            assert abs(float(fn(t(K), t(lw), **kw_t)) - O.kl_from_precision_sites_white(K, lw, **kw_o)) < 1e-11
+    mu5, cov5 = p.util.conditional_from_precision_sites_white(t(K), t(Kff), t(Kuf), t(lw), L2=t(L2w), jitter=1e-2)
+    muo5, covo5 = O.conditional_from_precision_sites_white(K, Kff, Kuf, lw, L2=L2w, jitter=1e-2)
+    assert relerr(mu5.numpy(), muo5) < 1e-11 and relerr(cov5.numpy(), covo5) < 1e-11 and relerr(muo5, muo) > 1e-6
+    mw, cSw = p.util.posterior_from_dense_site_white(t(K), t(lw), t(L2w))
+    mwo, cSwo = O.posterior_from_dense_site_white(K, lw, L2w)
+    assert relerr(mw.numpy(), mwo) < 1e-11 and relerr(cSw.numpy(), cSwo) < 1e-11
+    # the same posterior in the other parameterisation: sites K^-1 lw, K^-1 L2w K^-1 (tests/models/test_condit.py:27-66)
+    Ki = np.linalg.inv(K)
+    m_p, cS_p = O.posterior_from_dense_site(K, Ki @ lw, np.linalg.cholesky(Ki @ L2w[0] @ Ki)[None])
+    assert relerr(mw.numpy(), m_p) < 1e-9 and relerr((cSw @ cSw.transpose(-1, -2)).numpy(), cS_p @ np.swapaxes(cS_p, -1, -2)) < 1e-9
+    with pytest.raises(ValueError):
+        p.util.kl_from_precision_sites_white(t(K), t(lw))  # neither L nor L2
+    # per-datum sites projected onto the inducing points (util.py:188-236)
+    d1, d2 = rng.randn(12, P), rng.rand(12, P) + 0.5  # 12 data points > M: the projected site has a factor
+    Kuf7 = rng.randn(M, 12)
+    for kuu in (None, K):
+        for chol in (False, True):
+            lo, Lo = O.project_diag_sites(Kuf7, d1, d2, Kuu_=kuu, cholesky=chol)
+            lh, Lh = p.util.project_diag_sites(t(Kuf7), t(d1), t(d2), Kuu=None if kuu is None else t(kuu), cholesky=chol)
+            assert relerr(lh.numpy(), lo) < 1e-11 and relerr(Lh.numpy(), Lo) < 1e-11
 
 
 def test_containers_follow_the_reference():
@@ -196,9 +251,13 @@ def _worker(rank, world, port, lik, P, out, kind="plain"):
         for _ in range(3):
             hip.natgrad_step((Xs, Ys), lr=0.8)
         elbo = float(hip.elbo((Xs, Ys)))
+        extra = {}
+        if kind == "white":  # compute_data_natural_params of the rank's shard: sums all-reduced, every rank gets the full-data result
+            g = hip.compute_data_natural_params((Xs, Ys))
+            extra = dict(gm0=g[0].numpy(), gm1=g[1].numpy())
         if rank == 0:
             L2 = hip.lambda_2
-            np.savez(out, l1=hip.lambda_1.numpy(), L2=L2.numpy(), elbo=elbo)
+            np.savez(out, l1=hip.lambda_1.numpy(), L2=L2.numpy(), elbo=elbo, **extra)
     finally:
         dist.destroy_process_group()
 
@@ -250,6 +309,12 @@ def test_sharded_variants_gloo_world2(tmp_path, kind, lik, P):
     assert relerr(got["l1"], ora.lambda_1) < 1e-9
     assert relerr(got["L2"], ora.lambda_2) < 1e-9
     assert abs(float(got["elbo"]) - ora.elbo((X, Y))) < 1e-9 * abs(ora.elbo((X, Y)))
+    if kind == "white":
+        # products with K9^-1 themselves (as in the reference): both sides carry cond(K9) times their rounding (4.8e5 here;
+        # 1000 cond eps is the whitened model's tolerance in tools/fuzz_parity.py too)
+        g = ora.compute_data_natural_params((X, Y))
+        tol = max(1e-8, 1000 * np.linalg.cond(O.Kuu(ora.inducing_variable, ora.kernel) + 1e-9 * np.eye(20)) * 2.2e-16)
+        assert relerr(got["gm0"], g[0]) < tol and relerr(got["gm1"], g[1]) < tol
 
 
 def _worker_split3(rank, world, port, out, inject_failure):
