@@ -1129,9 +1129,18 @@ struct Frag1 {
 // W2: column tiles per pass (1, or 2 for the upper-form moments at an even number of tiles): with two, the A fragments of a
 // k-step serve 32 MFMAs instead of 16, a barrier and a set of DMA issues come once per 128 MFMAs, and the row panel is swept
 // 2.5 instead of 4.5 times (M = 1024); the accumulators are then all 256 AGPRs of the wave (fp64).
+#ifdef TSVGP_DIAG_PANEL1  // diagnostic build (tools/diag_panel1.py): when and where every workgroup of panel1_kernel ran, and the
+// shader cycles of its prologue, tile epilogues and tail.  8 words per workgroup behind a one-word slot count; null: no stamps.
+__device__ unsigned long long* g_panel1_stamps = nullptr;
+#endif
 template <typename T, int MODE = MODE_MOMENTS, int TRI = TSVGP_TRI_UPPER, int W2 = 1>
 __global__ __launch_bounds__(NTHREADS, 1) void panel1_kernel(PanelArgs<T> a) {
     static_assert(W2 == 1 || (W2 == 2 && MODE == MODE_MOMENTS && TRI == TSVGP_TRI_UPPER), "two tiles per pass: upper-form moments");
+#ifdef TSVGP_DIAG_PANEL1
+    const unsigned long long dg_t0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long dg_c0 = __builtin_amdgcn_s_memtime();
+    unsigned long long dg_pro = 0, dg_epi = 0, dg_loop_end = 0, dg_e0 = 0;
+#endif
     constexpr int NB = 8 * W2;                // column blocks of a pass
     constexpr int BUFS = (1 + W2) * P1_OPS;   // fragment units per chunk buffer: the A image + W2 T images
     constexpr int NDMA = 4 + 4 * W2;          // DMA pieces per wave and chunk
@@ -1389,6 +1398,9 @@ __global__ __launch_bounds__(NTHREADS, 1) void panel1_kernel(PanelArgs<T> a) {
         __syncthreads();  // both chunks and gamma are in LDS for every wave
         // a0, a1, b0 (fp32: and b1) of chunk (0, 0); lower form: tile 0 starts with its diagonal k-tile, all eight column blocks
         cfor<0, ((TRI == TSVGP_TRI_UPPER && !REORDER) ? 2 + BPC : 10)>([&](auto i) TSVGP_AI { rd1(fx, i, TSVGP_IC(0), TSVGP_IC(0)); });
+#ifdef TSVGP_DIAG_PANEL1
+        if (p == 0) dg_pro = __builtin_amdgcn_s_memtime() - dg_c0;
+#endif
 
         for (int it = 0; it < ntile; it += W2) {
             const int cd = it * CPT;
@@ -1548,6 +1560,9 @@ __global__ __launch_bounds__(NTHREADS, 1) void panel1_kernel(PanelArgs<T> a) {
             continue;
 #endif
             // the column tile is complete: squares of its entries, summed per row (as panel_kernel)
+#ifdef TSVGP_DIAG_PANEL1
+            dg_e0 = __builtin_amdgcn_s_memtime();
+#endif
             double keep = 0.0;
 #pragma unroll
             for (int s = 0; s < 2; ++s)
@@ -1580,8 +1595,15 @@ __global__ __launch_bounds__(NTHREADS, 1) void panel1_kernel(PanelArgs<T> a) {
                     keep = ((lane & 7) == s * 4 + r) ? q : keep;
                 }
             rs_mine += keep;
+#ifdef TSVGP_DIAG_PANEL1
+            asm volatile("" : "+v"(rs_mine));
+            dg_epi += __builtin_amdgcn_s_memtime() - dg_e0;
+#endif
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the saturated re-fetches of the last two chunks have landed
+#ifdef TSVGP_DIAG_PANEL1
+        dg_loop_end = __builtin_amdgcn_s_memtime();
+#endif
         if constexpr (MODE == MODE_STORE) return;
 
         // row sums and means to LDS, then the likelihood map of panel_kernel's epilogue (two threads per row)
@@ -1652,7 +1674,29 @@ __global__ __launch_bounds__(NTHREADS, 1) void panel1_kernel(PanelArgs<T> a) {
         if (a.ve_partial) a.ve_partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
         if (a.nonpos_partial) a.nonpos_partial[blockIdx.x] = redi[0] + redi[1] + redi[2] + redi[3];
     }
+#ifdef TSVGP_DIAG_PANEL1
+    if (t == 0 && g_panel1_stamps && blockIdx.y == 0 && (unsigned long long)blockIdx.x < g_panel1_stamps[0]) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned long long* d = g_panel1_stamps + 8 + (size_t)blockIdx.x * 8;
+        const unsigned long long c_end = __builtin_amdgcn_s_memtime();
+        d[0] = dg_t0;
+        d[1] = __builtin_amdgcn_s_memrealtime();
+        d[2] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)) |          // HW_REG_HW_ID
+               ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)) << 32);  // HW_REG_XCC_ID
+        d[3] = c_end - dg_c0;        // shader cycles of the workgroup (wave 0)
+        d[4] = dg_pro;               // entry -> first fragments of chunk (0, 0) in registers
+        d[5] = dg_epi;               // the column tiles' square-sum epilogues
+        d[6] = c_end - dg_loop_end;  // end of the chunk stream -> here: row sums to LDS, likelihood map, stores, reductions
+        d[7] = dg_loop_end - dg_c0;
+    }
+#endif
 }
+
+#ifdef TSVGP_DIAG_PANEL1
+extern "C" int tsvgp_diag_panel1_stamps(unsigned long long* buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_panel1_stamps), &buf, sizeof(buf)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------
 // lik_map_kernel: the likelihood-gradient map on its own: (mean, var, Y) -> g0 = d ve / d mean,
