@@ -92,10 +92,13 @@ def test_white_predict_f_extra_data_host_logic():
             hip.natgrad_step((X, Y), lr=0.8)
             ora.natgrad_step((X, Y), lr=0.8)
         l1 = hip.lambda_1.numpy().copy()
+        # the oracle forms K9^-1 products explicitly (tsvgp_white.py:196-206): its own rounding is cond(K9) eps times a modest
+        # factor, and the order of its BLAS sums moves the comparison by that much (the whitened model's tolerance everywhere)
+        tol = max(1e-8, 1000 * np.linalg.cond(O.Kuu(ora.inducing_variable, ora.kernel) + 1e-9 * np.eye(16)) * 2.2e-16)
         for kw in ({}, dict(jitter=1e-4)):
             mh, vh = hip.predict_f_extra_data(X[:50] + 0.1, (Xe, Ye), **kw)
             mo, vo = ora.predict_f_extra_data(X[:50] + 0.1, (Xe, Ye), **kw)
-            assert relerr(mh.numpy(), mo) < 1e-8 and relerr(vh.numpy(), vo) < 1e-8
+            assert relerr(mh.numpy(), mo) < tol and relerr(vh.numpy(), vo) < tol
         assert np.array_equal(hip.lambda_1.numpy(), l1)
 
 

@@ -446,3 +446,17 @@ def test_compensated_sum_recovers_what_plain_addition_loses():
     for x in parts:
         s.add(x)
     assert np.allclose(s.value(), [2e-3, 2.0], rtol=1e-15, atol=0)
+
+
+def test_site_sum_contractions_equal_the_einsums_they_lower():
+    """src/models/tsvgp.py:279-280: the oracle evaluates the two tf.einsum contractions as per-latent BLAS products (what
+    TensorFlow lowers them to); np.einsum's own loop for the same subscripts is the definition they are held to."""
+    rng = np.random.RandomState(11)
+    for n, m, P in ((37, 9, 1), (64, 12, 3)):
+        A = rng.randn(n, m, P)
+        g0, g1 = rng.randn(n, P), -rng.rand(n, P)
+        np.testing.assert_allclose(O._einsum_nml_nl(A, g0), np.einsum("nml,nl->ml", A, g0), rtol=1e-13, atol=1e-13)
+        want = np.einsum("nml,nol,nl->lmo", A, A, g1)
+        got = O._einsum_nml_nol_nl(A, g1)
+        assert got.shape == (P, m, m)
+        np.testing.assert_allclose(got, want, rtol=1e-13, atol=1e-13)
