@@ -112,7 +112,8 @@ def _T(a):
 
 def _einsum_nml_nl(A, g):
     """tf.einsum("nml,nl->ml", A, g) (src/models/tsvgp.py:279): per latent l the matrix-vector product A[:, :, l]^T g[:, l]."""
-    return np.stack([A[:, :, l].T @ g[:, l] for l in range(A.shape[2])], axis=1)
+    # (a latent's slice of [N, M, P] has no unit stride for P > 1: copied once, or the product leaves BLAS)
+    return np.stack([np.ascontiguousarray(A[:, :, l]).T @ g[:, l] for l in range(A.shape[2])], axis=1)
 
 
 def _einsum_nml_nol_nl(A, g):
@@ -123,7 +124,7 @@ def _einsum_nml_nol_nl(A, g):
     reference does not pay.  Same sums; the order inside a dot product is the BLAS library's."""
     out = np.empty((A.shape[2], A.shape[1], A.shape[1]), dtype=np.float64)
     for l in range(A.shape[2]):
-        Al = A[:, :, l]
+        Al = np.ascontiguousarray(A[:, :, l])  # P > 1: a strided slice would take the product out of BLAS
         out[l] = (Al * g[:, l:l + 1]).T @ Al
     return out
 
