@@ -489,7 +489,15 @@ def main():
 
     # Per-kernel HIP events are recorded in the timed region, except where the model's default replays the step from a
     # captured hipGraph (launch-bound sizes, configs[0]): events inside a replay would force the eager path.
-    replayed = args.model == "tsvgp" and world == 1 and model._wants_graph(Xd) and not w.get("separate")
+    replayed = args.model == "tsvgp" and model._wants_graph(Xd) and not w.get("separate")
+    if world > 1:
+        # With several ranks a replayed step is two graphs around the all-reduce (t_SVGP._graph_step).  The mode changes the number
+        # of steps this script takes (the eager pass for the per-kernel times), so the ranks AGREE on it: shards differ by a row and
+        # "auto" could fall on either side of its size limit.
+        flag = torch.tensor([1 if replayed else 0], dtype=torch.int32,
+                            device=device if os.environ.get("TSVGP_BENCH_BACKEND", "nccl") == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        replayed = bool(int(flag.item()))
     # The projection route ("auto": by cond(K_uu + jitter I)) is decided once per change of (theta, Z, jitter) and cached,
     # so the timed steps below do not pay for it; its cost is measured here and reported as `route_gate_ms`.
     routes, conds, route_gate_ms = None, None, None
@@ -584,6 +592,10 @@ def main():
     # there, so `value` above is the replayed rate; the other mode (eager) is reported beside it.  At the metric's
     # sizes "auto" runs eagerly and this block is skipped.
     graph_line = None
+    if world > 1 and replayed:
+        graph_line = {"headline_mode": "hipGraph replay (two graphs around the all-reduce of the packed accumulators)",
+                      "captured": any(isinstance(e, dict) for e in model._graphs.values()),
+                      "note": "\"auto\" (default) replays where this rank's rows * M <= 2e8; the eager mode is timed beside it on one GPU only"}
     if world == 1 and args.model == "tsvgp" and w["N"] * w["M"] <= 200_000_000 and not w.get("separate"):
         auto_on = model._wants_graph(Xd)
         model.use_graph = not auto_on
