@@ -7,13 +7,18 @@ import numpy as np, torch
 import bench
 pkg = importlib.import_module("t-svgp_amd")
 dev = torch.device("cuda", 0)
-for rows in [int(a) for a in sys.argv[1:]] or [125_000, 250_000, 500_000, 1_000_000]:
-    w = dict(bench.WORKLOADS["ns"], N=rows)
+argv = sys.argv[1:]
+wl = argv.pop(0) if argv and argv[0] in bench.WORKLOADS else "ns"  # usage: bench_graph_sizes.py [workload] [rows ...]
+for rows in [int(a) for a in argv] or [125_000, 250_000, 500_000, 1_000_000]:
+    w = dict(bench.WORKLOADS[wl], N=rows)
     X, Y, Z = bench.make_data(w)
-    Xd, Yd = torch.as_tensor(X).to(dev), torch.as_tensor(Y).to(dev)
+    dtype = torch.float64 if w["dtype"] == "f64" else torch.float32
+    Xd, Yd = torch.as_tensor(X, dtype=dtype).to(dev), torch.as_tensor(Y, dtype=dtype).to(dev)
     res = {}
     for mode in (False, True):
-        m = pkg.t_SVGP(pkg.SquaredExponential(1.0, 1.0), pkg.Gaussian(0.1), Z, num_data=rows, device=dev, use_graph=mode)
+        kernel, wrap = bench.make_kernel(pkg, w)
+        lik = pkg.Gaussian(variance=w.get("noise", 0.1)) if w["lik"] == "gaussian" else pkg.Bernoulli()
+        m = pkg.t_SVGP(kernel, lik, wrap(Z), num_latent_gps=w["P"], num_data=rows, compute_dtype=dtype, device=dev, use_graph=mode)
         for _ in range(4):
             m.natgrad_step((Xd, Yd), lr=0.8)
         torch.cuda.synchronize()
@@ -24,5 +29,5 @@ for rows in [int(a) for a in sys.argv[1:]] or [125_000, 250_000, 500_000, 1_000_
         res[mode] = ((time.perf_counter() - t0) / 20 * 1e3, float(m.elbo((Xd, Yd))))
         del m
         torch.cuda.empty_cache()
-    print(f"rows {rows:8d}: eager {res[False][0]:7.3f} ms   hipGraph replay {res[True][0]:7.3f} ms   ({res[False][0] - res[True][0]:+.3f} ms)   "
+    print(f"{wl} rows {rows:8d}: eager {res[False][0]:7.3f} ms   hipGraph replay {res[True][0]:7.3f} ms   ({res[False][0] - res[True][0]:+.3f} ms)   "
           f"elbo equal: {abs(res[False][1] - res[True][1]) <= 1e-12 * abs(res[False][1])}", flush=True)
