@@ -68,7 +68,7 @@ const char *tsvgp_version(void);
 /* Number of this header's calling conventions: bumped whenever an entry point's argument list changes without a new symbol
  * name.  A binding checks it against the TSVGP_ABI_VERSION it was written for before the first call (t-svgp_amd/_backend.py
  * refuses a library whose number differs: a shifted argument would otherwise hand a kernel a garbage stream or pointer). */
-#define TSVGP_ABI_VERSION 3
+#define TSVGP_ABI_VERSION 4
 int tsvgp_abi_version(void);
 
 /* Upper bound on the number of workgroup slots the site-accumulation kernel can keep resident
@@ -236,6 +236,11 @@ int tsvgp_site_accum_batched_f32(const float *B, int64_t strideB, const float *g
                                LAPACK factorisation on numerically barely definite matrices (cond ~ 1e14), where the
                                inverse-based panels lose cond(L_kk) digits of the trailing matrix.  The callers set it
                                when cond(K_uu + jitter I) is beyond 1e7. */
+#define TSVGP_POTRF_DIAG_V1 4 /* flags: round 4's block step -- the diagonal block's inverse assembled by the 2 x 2 recursion and
+                                 the panel rows multiplied by it -- instead of round 5's (inverted 16 x 16 diagonal tiles only,
+                                 panel rows by substitution on MFMA tile registers, tsvgp_chol.hip); for A/B measurements */
+#define TSVGP_POTRF_DIAG_V2 8 /* flags: factor the diagonal blocks with the MFMA tile-dataflow kernel of tsvgp_chol.hip
+                                 (experimental: measured slower than the row-per-lane kernel, profiles/r05_potrf_diag_lab.txt) */
 int tsvgp_potrf_f64(double *A, int M, int lda, int batch, int64_t stride, int32_t *info, double *work, int flags,
                     void *stream);
 

@@ -16,7 +16,11 @@ _ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libtsvgp_hip.so")
 HEADER_PATH = os.path.join(_ROOT, "include", "tsvgp_hip.h")
-SOURCES = [os.path.join(CSRC, "tsvgp_kernels.hip")]
+SOURCES = [os.path.join(CSRC, "tsvgp_kernels.hip"), os.path.join(CSRC, "tsvgp_chol.hip")]
+HEADERS = [HEADER_PATH, os.path.join(CSRC, "tsvgp_chol.h")]
+# per-source compiler switches: the small-matrix kernels keep their MFMA accumulators in VGPRs (the AGPR form the compiler
+# picks for a one-wave-per-SIMD kernel ran the panel kernel's dependent MFMA chains ~1.5x slower, tools/diag2_lab.hip)
+SOURCE_FLAGS = {"tsvgp_chol.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 TILE = 128
 MAX_BATCH = 32  # TSVGP_MAX_BATCH: latents per launch of the *_batched entry points
@@ -27,7 +31,9 @@ KERNEL_SE, KERNEL_MATERN32, KERNEL_MATERN52 = 0, 2, 3
 TRI_LOWER, TRI_UPPER, TRI_DENSE = 0, 1, 2
 POTRF_SUBST = 1  # TSVGP_POTRF_SUBST
 POTRF_RHS_UPPER = 2  # TSVGP_POTRF_RHS_UPPER
-ABI_VERSION = 3  # TSVGP_ABI_VERSION of include/tsvgp_hip.h these prototypes were written for
+POTRF_DIAG_V1 = 4  # TSVGP_POTRF_DIAG_V1
+POTRF_DIAG_V2 = 8  # TSVGP_POTRF_DIAG_V2
+ABI_VERSION = 4  # TSVGP_ABI_VERSION of include/tsvgp_hip.h these prototypes were written for
 
 _lib = None
 
@@ -37,24 +43,40 @@ class HipExtensionError(RuntimeError):
 
 
 def build_library(force: bool = False, verbose: bool = False) -> str:
-    """Compile the HIP sources for gfx950 with hipcc (cross-compiles without a GPU)."""
+    """Compile the HIP sources for gfx950 with hipcc (cross-compiles without a GPU): one object per source, compiled side
+    by side, then linked into the one shared library the C-ABI lives in."""
     if not force and os.path.exists(LIB_PATH):
-        newest = max(os.path.getmtime(p) for p in SOURCES + [HEADER_PATH])
+        newest = max(os.path.getmtime(p) for p in SOURCES + HEADERS)
         if os.path.getmtime(LIB_PATH) >= newest:
             return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC",
-           "-I", os.path.join(_ROOT, "include"), *SOURCES, "-o"]
+    flags = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-I", os.path.join(_ROOT, "include"), "-I", CSRC]
+    flags += os.environ.get("TSVGP_HIPCC_FLAGS", "").split()  # experiment builds (tools/): extra -D switches
     # build beside the target and rename: a concurrent loader (several ranks of one job) never maps a half-written file
-    tmp = f"{LIB_PATH}.{os.getpid()}.tmp"
-    if verbose:
-        print(" ".join(cmd + [LIB_PATH]))
-    res = subprocess.run(cmd + [tmp], capture_output=True, text=True)
-    if res.returncode != 0:
-        if os.path.exists(tmp):
-            os.remove(tmp)
-        raise HipExtensionError("hipcc failed:\n" + res.stdout + res.stderr)
-    os.replace(tmp, LIB_PATH)
+    tag = f"{os.getpid()}.tmp"
+    objs = [f"{src}.{tag}.o" for src in SOURCES]
+    tmp = f"{LIB_PATH}.{tag}"
+    procs = []
+    try:
+        for src, obj in zip(SOURCES, objs):
+            cmd = [hipcc, *flags, *SOURCE_FLAGS.get(os.path.basename(src), []), "-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+        outs = [p.communicate()[0] for p in procs]
+        if any(p.returncode != 0 for p in procs):
+            raise HipExtensionError("hipcc failed:\n" + "\n".join(outs))
+        link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", tmp]
+        if verbose:
+            print(" ".join(link))
+        res = subprocess.run(link, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise HipExtensionError("hipcc (link) failed:\n" + res.stdout + res.stderr)
+        os.replace(tmp, LIB_PATH)
+    finally:
+        for f in objs + [tmp]:
+            if os.path.exists(f):
+                os.remove(f)
     return LIB_PATH
 
 
@@ -156,6 +178,9 @@ def lib():
     if abi != ABI_VERSION:
         raise HipExtensionError(f"{path}: ABI version {abi}, these bindings are written for {ABI_VERSION} "
                                 "(include/tsvgp_hip.h: TSVGP_ABI_VERSION); rebuild the library from this tree")
+    missing = [name for name in _PROTOTYPES if not hasattr(handle, name)]
+    if missing:
+        raise HipExtensionError(f"{path} does not export {missing}: not a build of this tree (include/tsvgp_hip.h); rebuild it")
     for name, (restype, argtypes) in _PROTOTYPES.items():
         fn = getattr(handle, name)
         fn.restype = restype

@@ -32,6 +32,7 @@
 #include <stdint.h>
 
 #include "tsvgp_hip.h"
+#include "tsvgp_chol.h"
 
 namespace {
 
@@ -3051,7 +3052,26 @@ __global__ __launch_bounds__(CH_THREADS) void potrf_diag_kernel(double* __restri
     }
     if (t == 0 && fail != 0 && info[b] == 0) info[b] = fail;
     PSTAMP()
-    if (need_inverse) {  // the last block column has no panel below it
+    if (need_inverse == 2) {
+        // round 5: no assembled inverse.  The panel kernel (tsvgp_chol.hip: chol_panel2_kernel) solves by substitution over the
+        // 16-wide column blocks and wants the factor's off-diagonal tiles in MFMA register layout and the inverted diagonal
+        // sub-blocks (which the factor passes left in the strict upper triangles + dinv) -- tsvgp_chol.h: the `work` image
+        static_assert(CH_SB == 16 && CH_NB == 128, "work image of the panel kernel");
+        double* Wb = work + (size_t)b * CH_NB * CH_NB;
+        for (int idx = t; idx < 28 * 256; idx += CH_THREADS) {  // the 28 tiles below the diagonal tiles
+            int q = idx >> 8, j = 0;
+            while (q >= 7 - j) {
+                q -= 7 - j;
+                ++j;
+            }
+            const int i = j + 1 + q, r = (idx >> 6) & 3, l = idx & 63;
+            Wb[(size_t)tsvgp_chol::work_tile_index(j, i - j) * 256 + r * 64 + l] = S[(16 * i + (l & 15)) * CH_LD + 16 * j + 4 * r + (l >> 4)];
+        }
+        for (int idx = t; idx < 8 * 256; idx += CH_THREADS) {
+            const int s0 = 16 * (idx >> 8), r = (idx >> 4) & 15, c = idx & 15;
+            Wb[(size_t)tsvgp_chol::WORK_TILES * 256 + idx] = chol_xval(S, dinv, s0 + r, s0 + c);
+        }
+    } else if (need_inverse) {  // the last block column has no panel below it
         // level 1: the two 64x64 diagonal blocks, X_10 = -X_11 (L_10 X_00) with 32x32 blocks; level 2: the 64x64 block
         // levels n = CH_SB .. 64 of the 2x2 recursion; a level has 64 / n block pairs of n / 16 column tiles: four waves
         if constexpr (CH_SB == 16) {
@@ -4027,11 +4047,12 @@ int site_accum_slots() {
 int potrf(double* A, int M, int lda, int batch, int64_t stride, int* info, double* work, int flags, void* stream,
           double* X = nullptr, double* Xt = nullptr, double* T = nullptr, int rhs_rows = 0) {
     if (!A || !info || !work || M <= 0 || (M % CH_NB) || lda < M || batch <= 0 ||
-        (flags & ~(TSVGP_POTRF_SUBST | TSVGP_POTRF_RHS_UPPER)) || rhs_rows < 0 || (rhs_rows % CH_NB) ||
+        (flags & ~(TSVGP_POTRF_SUBST | TSVGP_POTRF_RHS_UPPER | TSVGP_POTRF_DIAG_V1 | TSVGP_POTRF_DIAG_V2)) || rhs_rows < 0 || (rhs_rows % CH_NB) ||
         (rhs_rows > 0 && stride < (int64_t)(M + rhs_rows) * lda))
         return TSVGP_EINVAL;
     const bool rhs_upper = (flags & TSVGP_POTRF_RHS_UPPER) != 0;
-    const bool inv = X != nullptr, subst = (flags & TSVGP_POTRF_SUBST) != 0;
+    const bool inv = X != nullptr, subst = (flags & TSVGP_POTRF_SUBST) != 0, diag_v1 = (flags & TSVGP_POTRF_DIAG_V1) != 0,
+               diag_v2 = (flags & TSVGP_POTRF_DIAG_V2) != 0;
     if (inv && (!Xt || !T)) return TSVGP_EINVAL;
     const int nt = M / CH_NB;
 #ifdef TSVGP_DIAG_POTRF
@@ -4060,8 +4081,16 @@ int potrf(double* A, int M, int lda, int batch, int64_t stride, int* info, doubl
         // right-hand-side rows that column block k can reach: all of them, or (block upper triangular B) its row blocks 0 .. k
         const int ext_rows = rhs_upper ? (rhs_rows < (k + 1) * CH_NB ? rhs_rows : (k + 1) * CH_NB) : rhs_rows;
         const int below = nt - k - 1;
-        hipLaunchKernelGGL(potrf_diag_kernel, dim3(batch), dim3(CH_THREADS), smem, st, A, lda, stride, k, work, info,
-                           (inv || ((below > 0 || ext_rows > 0) && !subst)) ? 1 : 0, X, Xt, M, xstride);
+        // what the panel step behind this block needs of it: nothing (last block / substitution panels), the assembled inverse
+        // (round 4's step, and tsvgp_potrf_inv_f64), or the `work` image of chol_panel2_kernel (round 5)
+        const bool panel2 = !inv && !diag_v1 && !subst;
+        const int need_inverse = inv ? 1 : ((below > 0 || ext_rows > 0) && !subst) ? (panel2 ? 2 : 1) : 0;
+        if (panel2 && diag_v2) {  // the diagonal block as an MFMA tile dataflow (tsvgp_chol.hip; experimental)
+            if (tsvgp_chol::launch_diag2(A, lda, stride, k, work, info, need_inverse, batch, st) != hipSuccess) return TSVGP_ELAUNCH;
+        } else {
+            hipLaunchKernelGGL(potrf_diag_kernel, dim3(batch), dim3(CH_THREADS), smem, st, A, lda, stride, k, work, info,
+                               need_inverse, X, Xt, M, xstride);
+        }
         if (below > 0 || ext_rows > 0) {
             // the panel: the matrix rows below the diagonal block and, contiguous with them (row M on), the right-hand-side rows
             const int nb32 = below * (CH_NB / CH_WT), ext32 = ext_rows / CH_WT;
@@ -4069,7 +4098,10 @@ int potrf(double* A, int M, int lda, int batch, int64_t stride, int* info, doubl
             if (subst)
                 hipLaunchKernelGGL(chol_panel_subst_kernel, dim3((below * CH_NB + ext_rows) / PS_ROWS, batch), dim3(NTHREADS), 0,
                                    st, A, lda, stride, k);
-            else
+            else if (panel2) {  // substitution on tile registers against the diagonal kernel's `work` image
+                if (tsvgp_chol::launch_panel2(A, lda, stride, k, work, (below * CH_NB + ext_rows) / 16, batch, st) != hipSuccess)
+                    return TSVGP_ELAUNCH;
+            } else
                 hipLaunchKernelGGL(chol_tile_kernel<0>, dim3(nb32 + ext32, batch), dim3(NTHREADS), 0, st, A, lda, stride, k, nt,
                                    work, ext32);
             if (ntile > 0)

@@ -107,6 +107,8 @@ class EStepEngine:
         self.last_trmm_batch = 1  # latents per whitening launch of that pass
         self.profile = None  # set to a dict to record (start, stop) HIP events per kernel launch on the launch stream
         self.profile_only = None  # a set of kernel names: bracket only these launches
+        # A/B switch (tools/dev_diag2.py): round 4's diagonal-block kernel instead of round 5's (TSVGP_POTRF_DIAG_V1)
+        self.potrf_flags = B.POTRF_DIAG_V1 if os.environ.get("TSVGP_POTRF_DIAG_V1") == "1" else 0
 
     # ------------------------------------------------------------------ helpers
     def _stream(self):
@@ -301,7 +303,7 @@ class EStepEngine:
             tall[:, :Mp].diagonal(dim1=-2, dim2=-1)[:, M:] = 1.0  # chol([[A, 0], [0, I]]) = [[C, 0], [0, I]]
         info = torch.empty(nb, dtype=torch.int32, device=self.device)
         work = self._get("potrf_work", (nb, 128 * 128), torch.float64)
-        flags = (B.POTRF_SUBST if robust else 0) | B.POTRF_RHS_UPPER
+        flags = (B.POTRF_SUBST if robust else 0) | B.POTRF_RHS_UPPER | self.potrf_flags
         with torch.cuda.device(self.device):
             self._launch("tsvgp_potrf", lambda: self.lib.tsvgp_potrf_solve_f64(
                 tall.data_ptr(), Mp, Mp, nb, 2 * Mp * Mp, info.data_ptr(), work.data_ptr(), Mp, flags, self._stream()))
@@ -328,7 +330,7 @@ class EStepEngine:
         ``upper_form``: A = U U^T with U upper triangular -- the input is read with reversed indices, factored, and the
         factor (and inverse) written back reversed (``util.rev_cholesky`` without its four flip passes)."""
         A = A.to(device=self.device, dtype=torch.float64)
-        flags = B.POTRF_SUBST if robust else 0
+        flags = (B.POTRF_SUBST if robust else 0) | self.potrf_flags
         M = A.shape[-1]
         batch_shape = A.shape[:-2]
         Mp = B.round_up(M)
