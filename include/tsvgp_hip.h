@@ -305,6 +305,11 @@ int tsvgp_site_update_f64(const double *G1, const double *G0, const double *LLt,
 int tsvgp_site_beta_f64(const double *D, const double *v, const double *l1, double *work, double *beta, int M, int P,
                         void *stream);
 
+/* (7b''') y[:, p] = A_p v[:, p]: row-major A_p [M x M] at A + p * strideA (strideA = 0: one matrix for every latent), v and y
+ *     [M x P] contiguous.  The matrix-vector products of the replicated chain -- (K_uu + 1e-6 I) lambda_1 and K_uu beta of
+ *     reference src/util.py:176-179 / src/models/tsvgp.py:249-254, K9^-1 acc1 of :279 -- one wave per row. */
+int tsvgp_gemv_f64(const double *A, int64_t strideA, const double *v, double *y, int M, int P, void *stream);
+
 /* (7c) Status word of one step: flags[0] = sum |info_a| (prelude factorisations), flags[1] = nonpos[0] (count of
  *     non-positive predictive variances, the assert_positive of :113; NULL = 0), flags[2] = sum |info_b| (the final
  *     factorisation, :300).  One device->host read of these three doubles ends a step. */

@@ -3135,7 +3135,7 @@ __global__ __launch_bounds__(NTHREADS) void chol_tile_kernel(double* __restrict_
     double* Ab = Amat + (size_t)b * stride;
     const int nb32 = (nt - k - 1) * (CH_NB / CH_WT);
     const int base = (k + 1) * CH_NB;  // first row / column of the trailing matrix
-    int ti, tj;
+    int ti = 0, tj = 0;
     bool active = true;
     if (OP == 0) {
         ti = blockIdx.x;
@@ -3161,6 +3161,17 @@ __global__ __launch_bounds__(NTHREADS) void chol_tile_kernel(double* __restrict_
     for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int n = 0; n < 2; ++n) acc[s][n] = v4d{0, 0, 0, 0};
+    double* Cb = Ab + (size_t)(base + CH_WT * ti) * lda + (OP == 0 ? (size_t)k * CH_NB : (size_t)base) + CH_WT * tj + li;
+    if (OP == 1 && active) {
+        // round 5: the tile itself is requested first and accumulated on (-A B^T with the sign on the A operand): its 16
+        // eight-byte loads per lane used to follow the products as a read-modify-write and sat on the kernel's tail
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) acc[s][n][r] = Cb[(size_t)(16 * s + g + 4 * r) * lda + 16 * n];
+    }
     if (active) {
         const double* Arow = Ab + (size_t)(base + CH_WT * ti + li) * lda + (size_t)k * CH_NB + 16 * g;
         const double* Brow = (OP == 0) ? work + (size_t)b * CH_NB * CH_NB + (size_t)(CH_WT * tj + li) * CH_NB + 16 * g
@@ -3182,24 +3193,19 @@ __global__ __launch_bounds__(NTHREADS) void chol_tile_kernel(double* __restrict_
                 for (int s = 0; s < 2; ++s)
 #pragma unroll
                     for (int n = 0; n < 2; ++n)
-                        acc[s][n] = Mfma<double>::run(ra[s][kk >> 1][kk & 1], rb[n][kk >> 1][kk & 1], acc[s][n]);
+                        acc[s][n] = Mfma<double>::run(OP == 1 ? -ra[s][kk >> 1][kk & 1] : ra[s][kk >> 1][kk & 1],
+                                                      rb[n][kk >> 1][kk & 1], acc[s][n]);
         }
     }
     if (OP == 0) __syncthreads();  // in place: every wave of the row block has its operands in registers
     if (!active) return;
-    double* Cb = Ab + (size_t)(base + CH_WT * ti) * lda + (OP == 0 ? (size_t)k * CH_NB : (size_t)base) + CH_WT * tj + li;
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             double* Cr = Cb + (size_t)(16 * s + g + 4 * r) * lda;
 #pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                if (OP == 0)
-                    Cr[16 * n] = acc[s][n][r];
-                else
-                    Cr[16 * n] -= acc[s][n][r];
-            }
+            for (int n = 0; n < 2; ++n) Cr[16 * n] = acc[s][n][r];
         }
 }
 
@@ -3547,9 +3553,18 @@ __global__ __launch_bounds__(NTHREADS) void site_beta_kernel(const double* __res
         const int c = threadIdx.x & 63, g = threadIdx.x >> 6, j = blockIdx.x * 64 + c, rg = blockIdx.y;
         double acc = 0.0;
         if (rg <= (int)blockIdx.x && j < M) {  // row groups beyond the column strip lie below the diagonal
-            const int i_end = (rg * 64 + 64 < M ? rg * 64 + 64 : M);
-            for (int i = rg * 64 + g; i < i_end; i += 4)
-                if (i <= j) acc += Dp[(size_t)i * M + j] * tvec[(size_t)p * M + i];
+            // the wave's 16 rows requested at once (round 4 walked them one load at a time: 69 us at M = 1024, all of it latency)
+            double d[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int i = rg * 64 + g + 4 * u;
+                d[u] = (i <= j && i < M) ? Dp[(size_t)i * M + j] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int i = rg * 64 + g + 4 * u;
+                acc = fma(d[u], i < M ? tvec[(size_t)p * M + i] : 0.0, acc);
+            }
         }
         sums[g][c] = acc;
         __syncthreads();
@@ -3561,6 +3576,36 @@ __global__ __launch_bounds__(NTHREADS) void site_beta_kernel(const double* __res
         for (int rg = 0; rg <= j / 64; ++rg) acc += part[((size_t)p * nrg + rg) * M + j];
         beta[(size_t)j * P + p] = l1[(size_t)j * P + p] - acc;
     }
+}
+
+// y[:, p] = A_p v[:, p] for row-major A_p [M x M] (p-th matrix at A + p * strideA; strideA = 0: one matrix for all latents) and
+// v, y [M x P]: one wave per row, 16-byte loads, eight in flight per lane.  (rocBLAS takes 24-30 us for this 8 MB read.)
+__global__ __launch_bounds__(NTHREADS) void gemv_rows_kernel(const double* __restrict__ A, int64_t strideA, const double* __restrict__ v,
+                                                             double* __restrict__ y, int M, int P) {
+    const int lane = threadIdx.x & 63, i = blockIdx.x * (NTHREADS / 64) + (threadIdx.x >> 6), p = blockIdx.y;
+    if (i >= M) return;
+    const double* row = A + (size_t)p * strideA + (size_t)i * M;
+    double acc = 0.0;
+    if ((M & 1) == 0 && (reinterpret_cast<uintptr_t>(row) & 15) == 0) {
+        for (int j0 = 0; j0 < M; j0 += 1024) {
+            v2d a[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = j0 + 2 * (lane + 64 * u);
+                a[u] = j < M ? *reinterpret_cast<const v2d*>(row + j) : v2d{0.0, 0.0};
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = j0 + 2 * (lane + 64 * u);
+                if (j < M) acc = fma(a[u][0], v[(size_t)j * P + p], fma(a[u][1], v[(size_t)(j + 1) * P + p], acc));
+            }
+        }
+    } else {
+        for (int j = lane; j < M; j += 64) acc = fma(row[j], v[(size_t)j * P + p], acc);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) y[(size_t)i * P + p] = acc;
 }
 
 // flags[0] = sum |info_a|, flags[1] = nonpos (as is, NaN included), flags[2] = sum |info_b|   (t_SVGP._status_flags)
@@ -4361,6 +4406,13 @@ int tsvgp_site_beta_f64(const double* D, const double* v, const double* l1, doub
                        beta, M, P);
     hipLaunchKernelGGL(site_beta_kernel<2>, dim3((unsigned)((M + NTHREADS - 1) / NTHREADS), 1, (unsigned)P), dim3(NTHREADS), 0, st, D, v,
                        l1, work, part, beta, M, P);
+    return launch_status();
+}
+int tsvgp_gemv_f64(const double* A, int64_t strideA, const double* v, double* y, int M, int P, void* stream) {
+    if (!A || !v || !y || M <= 0 || P <= 0 || P > 65535 || strideA < 0 || (strideA != 0 && strideA < (int64_t)M * M)) return TSVGP_EINVAL;
+    const int wpb = NTHREADS / 64;
+    hipLaunchKernelGGL(gemv_rows_kernel, dim3((unsigned)((M + wpb - 1) / wpb), (unsigned)P), dim3(NTHREADS), 0, (hipStream_t)stream, A,
+                       strideA, v, y, M, P);
     return launch_status();
 }
 int tsvgp_step_status_f64(const int32_t* info_a, int na, const int32_t* info_b, int nb, const double* nonpos, double* flags,

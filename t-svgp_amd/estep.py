@@ -417,6 +417,16 @@ class EStepEngine:
                                                  self._stream()), "tsvgp_site_beta")
         return beta
 
+    def gemv(self, A: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
+        """A v per latent (``tsvgp_gemv_f64``): A [M, M] (one matrix for every latent) or [P, M, M] row-major, v [M, P] -> [M, P]."""
+        A, v = A.contiguous(), v.contiguous()
+        M, P = v.shape
+        y = torch.empty_like(v)
+        with torch.cuda.device(self.device):
+            B.check(self.lib.tsvgp_gemv_f64(A.data_ptr(), 0 if A.dim() == 2 else M * M, v.data_ptr(), y.data_ptr(), M, P, self._stream()),
+                    "tsvgp_gemv")
+        return y
+
     def step_status(self, infos_a, infos_b, nonpos):
         """[3] fp64 device tensor (sum |info| of the prelude factorisations, nonpos, sum |info| of the final one)."""
         cat = lambda ts: None if len(ts) == 0 else (ts[0] if len(ts) == 1 else torch.cat(list(ts))).contiguous()

@@ -235,6 +235,14 @@ class t_SVGP(base_SVGP):
         return L @ L.transpose(-1, -2)
 
     # -- M x M prelude -----------------------------------------------------------------------------------------
+    def _kmv(self, K: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
+        """K v per latent on the engine's own one-wave-per-row kernel (``tsvgp_gemv_f64``) where there is one: rocBLAS takes
+        24-30 us for the 8 MB read of an M = 1024 matrix-vector product on the replicated chain."""
+        eng = self._get_engine()
+        if hasattr(eng, "gemv") and K.is_cuda and K.dtype == torch.float64 and v.dtype == torch.float64:
+            return eng.gemv(K, v)
+        return _kmv(K, v)
+
     def _Z(self) -> torch.Tensor:
         return self.inducing_variable.Z.value.to(self.device)
 
@@ -311,7 +319,8 @@ class t_SVGP(base_SVGP):
     def _use_direct(self, jitter) -> list:
         return [r == "direct" for r in self._routes(jitter)]
 
-    def _site_operands(self, whiten_jitter=None, warm_key=None, routes=None, latents=None, fork=True, Kzz=None, K6=None):
+    def _site_operands(self, whiten_jitter=None, warm_key=None, routes=None, latents=None, fork=True, Kzz=None, K6=None,
+                       after_w=None):
         """Everything the N-pass needs that depends only on (theta, Z, lambda): O(M^3), fp64, replicated.
         No host synchronisation happens here: Cholesky statuses are collected in ops["infos"] and checked once per
         call by ``_check_step`` (TF raises immediately; here the raise comes at the end of the same call).
@@ -364,11 +373,16 @@ class t_SVGP(base_SVGP):
                   and all(r == "projected" for r in routes))
         with_k9 = whiten_jitter is not None and not warm and not lower9
         n9 = (Kzz.shape[0] if Kzz.dim() == 3 else 1) if with_k9 else 0
-        K6l = _kmv(K6, l1)  # [M, P]: needed behind the factorisation (beta) -- issued in front of it, off the path to the moments
+        K6l = self._kmv(K6, l1)  # [M, P]: needed behind the factorisation (beta) -- issued in front of it, off the path to the moments
         batch = torch.empty((P_ + n9, M, M), dtype=torch.float64, device=Kzz.device)
         # (bmm + a strided add of the identity: baddbmm first copies its [P, M, M] addend into the output, 8 MB per latent)
-        torch.bmm(L.transpose(-1, -2), K6 @ L, out=batch[:P_])
+        # (the transposed-operand rocBLAS kernels take 60 us at M = 1024 where the plain one takes 40: L^T is copied out first,
+        # for this product and for L L^T below)
+        Lt = L.transpose(-1, -2).contiguous()
+        torch.bmm(Lt, K6 @ L, out=batch[:P_])
         batch[:P_].diagonal(dim1=-2, dim2=-1).add_(1.0)
+        if after_w is not None:
+            after_w()  # a small shard's K(X, Z) fill starts here, behind the two GEMMs it would otherwise starve (_step_front)
         if with_k9:
             batch[P_:].copy_(Kzz if Kzz.dim() == 3 else Kzz[None])
             batch[P_:].diagonal(dim1=-2, dim2=-1).add_(whiten_jitter)  # K9 = K_uu + jitter I, tsvgp.py:270
@@ -406,7 +420,10 @@ class t_SVGP(base_SVGP):
             beta = eng.site_beta(Dm, K6l, l1)  # K6^-1 m = l1 - D^T D K6 l1: two triangular matrix-vector launches
         else:
             beta = l1 - bmv(Dm, bmv(Dm, K6l), transpose=True)
-        ops = dict(Z=Z, Kzz=Kzz, K6=K6, D=Dm, U_W=U_W, beta=beta, Id=Id, infos=infos, potrf=potrf,
+        # (Lt rides along because the side stream reads it below: inside a capture nothing else keeps a block of the graph's pool
+        # from being handed to the next allocation of the capturing stream while the forked branch still reads it -- the race
+        # of profiles/r04_c4_fork_capture_race.txt, met again in round 5 through this very tensor)
+        ops = dict(Z=Z, Kzz=Kzz, K6=K6, D=Dm, U_W=U_W, beta=beta, Id=Id, infos=infos, potrf=potrf, Lt=Lt,
                    routes=["whitened"] * P_, moment_mode=B.TRI_UPPER, whiten_mode=B.TRI_UPPER,
                    whiten_T=None, project_T=None)
         if whiten_jitter is None:
@@ -420,8 +437,8 @@ class t_SVGP(base_SVGP):
         want_k9inv = routes is not None and "direct" in routes and Uinv9 is not None
 
         def epilogue_operands():
-            ops["LLt"] = L @ L.transpose(-1, -2)
-            ops["meanZ"] = _kmv(Kzz, beta)
+            ops["LLt"] = L @ Lt
+            ops["meanZ"] = self._kmv(Kzz, beta)
             if want_k9inv:
                 ops["K9inv"] = Uinv9.transpose(-1, -2) @ Uinv9
 
@@ -441,7 +458,7 @@ class t_SVGP(base_SVGP):
                 done = torch.cuda.Event()
                 done.record(side)
             if not capturing:
-                for t in (L, Kzz, beta) + ((Uinv9,) if want_k9inv else ()):
+                for t in (L, Lt, Kzz, beta) + ((Uinv9,) if want_k9inv else ()):
                     t.record_stream(side)  # blocks of the main stream's pool read on the side stream
                 for k in ("LLt", "meanZ", "K9inv"):
                     if k in ops:
@@ -739,7 +756,7 @@ class t_SVGP(base_SVGP):
         # (Starting it only behind the two GEMMs that assemble W -- they take 130-190 us each under the fill instead of 40 --
         # measured 0.1-0.2 ms SLOWER per step, and again 36.61 vs 36.46 ms after the fill and the factorisation were reworked:
         # the factorisation and the moments kernel behind a later fill lose more than the two GEMMs gain.)
-        pre = None
+        pre = ops = None
         # (inside a capture of a launch-bound size the fork / join costs a replay more than the overlap gains: in line there)
         fork = not (self.device.type == "cuda" and torch.cuda.is_current_stream_capturing()
                     and X.shape[0] * self.num_inducing < self.GRAPH_FORK_MIN_NM)
@@ -750,9 +767,21 @@ class t_SVGP(base_SVGP):
             if not (warm_key is not None and self._warm is not None and self._warm[0] == warm_key):
                 Kzz = eng.kuu(self._Z(), self.kernel)
                 K6 = self._k6_of(Kzz)
-            pre = eng.start_fill(X, self._Z(), self.kernel, b_tag=warm_key,
-                                 want="Kfu" if all(r == "direct" for r in routes) else "B", routes=routes)
-        ops = self._site_operands(whiten_jitter=jitter, warm_key=warm_key, routes=routes, fork=fork, Kzz=Kzz, K6=K6)
+            want = "Kfu" if all(r == "direct" for r in routes) else "B"
+            if self._late_fill(X):
+                # One rank's share of a large job: the fill is shorter than the factorisation chain, and its workgroups take every
+                # CU slot from the two M^3 GEMMs that assemble W (126 + 129 us under the fill against 40 + 40 alone at 125 000 x
+                # 1024, profiles/r05_v1_ns_mxm_timeline_rows125000.txt): it starts behind them and runs beside the factorisation.
+                # (At N = 1e6 the fill outlasts the whole chain and starts first -- measured in round 3, docs/history_r01-r03.md.)
+                box = {}
+                ops = self._site_operands(whiten_jitter=jitter, warm_key=warm_key, routes=routes, fork=fork, Kzz=Kzz, K6=K6,
+                                          after_w=lambda: box.update(pre=eng.start_fill(X, self._Z(), self.kernel, b_tag=warm_key,
+                                                                                        want=want, routes=routes)))
+                pre = box.get("pre")
+            else:
+                pre = eng.start_fill(X, self._Z(), self.kernel, b_tag=warm_key, want=want, routes=routes)
+        if ops is None:
+            ops = self._site_operands(whiten_jitter=jitter, warm_key=warm_key, routes=routes, fork=fork, Kzz=Kzz, K6=K6)
         st = eng.run(X, Y, ops["Z"], self.kernel, moment_Tm=ops["moment_Tm"], prefill=pre,
                      moment_mode=ops["moment_mode"], gamma=ops["gamma"],
                      lik_id=self.likelihood.lik_id, lik_param=self.likelihood.lik_param,
@@ -761,6 +790,11 @@ class t_SVGP(base_SVGP):
                      sites=True, b_tag=warm_key,
                      mean_only=self.skip_unused_variance and self.likelihood.lik_id == B.LIK_GAUSSIAN)
         return st, ops
+
+    LATE_FILL_MAX_NM = int(os.environ.get("TSVGP_LATE_FILL_MAX_NM", "300000000"))  # N * M up to which the fill starts behind W's GEMMs
+
+    def _late_fill(self, X) -> bool:
+        return X.shape[0] * self.num_inducing <= self.LATE_FILL_MAX_NM
 
     def _step_device(self, X, Y, lr, jitter, routes, inplace=False) -> torch.Tensor:
         """The whole E-step as device work, no host synchronisation: M x M prelude, N-pass, all-reduce, epilogue, state
@@ -1024,7 +1058,7 @@ class t_SVGP(base_SVGP):
             # (K9^-1 = U9^-T U9^-1 from the prelude, applied as GEMMs; torch.cholesky_solve is not an option: it returned
             # wrong values for small batched right-hand sides on this ROCm build -- tools/check_cholesky_solve.py)
             K9inv = ops["K9inv"]
-            forms["direct"] = (K9inv @ acc2 @ K9inv, _kmv(K9inv, acc1.transpose(-1, -2)))
+            forms["direct"] = (K9inv @ acc2 @ K9inv, self._kmv(K9inv, acc1.transpose(-1, -2).contiguous()))
         if "whitened" in routes:
             # G1 = U9^-T acc2 U9^-1,  G0 = U9^-T acc1   (tsvgp.py:279-280 in whitened coordinates)
             forms["whitened"] = (Uinv9t @ acc2 @ Uinv9, _kmv(Uinv9t, acc1.transpose(-1, -2)))
