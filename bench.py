@@ -105,6 +105,28 @@ def _blas_info():
         return int(os.cpu_count() or 1), "unknown"
 
 
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def _dgemm_gflops(n=4096, reps=3):
+    """A plain NumPy DGEMM of this box on the BLAS pool the oracle runs on: the context for the port's own GFLOP/s."""
+    a = np.random.RandomState(0).randn(n, n)
+    a @ a  # pool ramp, page faults
+    best = float("inf")
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        a @ a
+        best = min(best, time.perf_counter() - t0)
+    return round(2.0 * n ** 3 / best / 1e9, 1)
+
+
 class blas_threads:
     """The BLAS pools NumPy / SciPy run on, widened to every host core for the oracle's sections: a rank started by
     torch.distributed.run inherits OMP_NUM_THREADS=1 (its default for more than one process per node), which would time the
@@ -195,8 +217,8 @@ def cpu_baseline(w, budget_s=20.0, model_kind="tsvgp"):
         fit = f"measured at the full n = {n_big} (median of {kb})"
     t_full = a + b * w["N"] if len(med) == 2 else t_big
     return {
-        "value": 1.0 / t_full, "unit": "E-steps/s", "cores": cores, "kind": "port",
-        "blas": blas, "sample_gflops": round(oracle_step_flops(w, n_big) / t_big / 1e9, 1),
+        "value": 1.0 / t_full, "unit": "E-steps/s", "cores": cores, "threads": cores, "kind": "port",
+        "blas": blas, "cpu_model": _cpu_model(), "host_logical_cpus": os.cpu_count(), "sample_gflops": round(oracle_step_flops(w, n_big) / t_big / 1e9, 1),
         "extrapolated_ms_per_step": round(t_full * 1e3, 1),
         "sample": f"oracle natgrad_step (NumPy/SciPy fp64, the reference's op sequence incl. its redundancies) on the first rows of "
                   f"the same workload (same M, D, P, likelihood); {fit}; "
@@ -327,6 +349,8 @@ def state_match(model, w, X, Y, Z, Xd, Yd, budget_s):
     state = {"lambda_1": rel(model.lambda_1.numpy(), ora.lambda_1), "Lambda_2": rel(model.lambda_2.cpu().numpy(), ora.lambda_2)}
     e_o = float(last["elbo_before"])
     cores, blas = _blas_info()
+    t_extras = float(last.get("extras_seconds", 0.0))  # ELBO terms, |A| column sums, retained N-sized arrays: not the step's work
+    t_step = t_o - t_extras
     return {
         "elbo_match": {"hip": e_h, "hip_is": "one GPU", "oracle": e_o, "rel": abs(e_h - e_o) / abs(e_o), "rows": int(N), "full_N": True,
                        "oracle_seconds": round(t_o, 1), "sample_rows": int(N), "sample_max_rel_err": inter,
@@ -338,11 +362,20 @@ def state_match(model, w, X, Y, Z, Xd, Yd, budget_s):
                         "note": "oracle.natgrad_step_chunked (reference src/models/tsvgp.py:234-304, row-blocked) and the HIP "
                                 "natgrad_step, both from the HIP model's state after the timed steps, over all N rows: G0, G1 "
                                 "(tsvgp.py:279-280) and the updated (lambda_1, Lambda_2 = L L^T)"},
-        "cpu_measured": {"value": 1.0 / t_o, "unit": "E-steps/s", "cores": cores, "kind": "port", "measured": True, "blas": blas,
-                         "seconds_per_step": round(t_o, 1), "gflops": round(oracle_step_flops(w, N) / t_o / 1e9, 1),
+        "cpu_measured": {"value": 1.0 / t_step, "unit": "E-steps/s", "cores": cores, "threads": cores, "kind": "port", "measured": True,
+                         "blas": blas, "cpu_model": _cpu_model(), "host_logical_cpus": os.cpu_count(),
+                         "seconds_per_step": round(t_step, 1), "seconds_incl_parity_extras": round(t_o, 1),
+                         "parity_extras_seconds": round(t_extras, 1),
+                         "gflops": round(oracle_step_flops(w, N) / t_step / 1e9, 1), "dgemm_gflops_same_box": _dgemm_gflops(),
                          "sample": f"ONE oracle natgrad_step over ALL N = {N} rows of the workload (NumPy/SciPy fp64, the reference's "
                                    f"op sequence incl. its redundancies, row-blocked by {chunk}; M x M parts once), wall time "
-                                   f"measured on this box's host cores -- not extrapolated"},
+                                   f"measured on this box's host cores -- not extrapolated; the seconds the same pass spends on what "
+                                   f"the reference's step does not do (ELBO terms, |A| column sums, retained N-sized arrays for the "
+                                   f"parity checks) are timed apart and taken out",
+                         "caveat": "a NumPy/SciPy PORT of the reference's op sequence: `gflops` against `dgemm_gflops_same_box` "
+                                   "(a plain 4096^3 DGEMM on the same BLAS pool) says how far it is from what these cores deliver; "
+                                   "the reference's TensorFlow/Eigen path would likely be several times faster.  A reported "
+                                   "baseline, not the target"},
     }
 
 
@@ -443,10 +476,39 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("TSVGP_BENCH_BACKEND", "nccl")  # "gloo" only to rehearse the multi-rank path on one GPU
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
-        else:
-            dist.init_process_group(backend)
+        # a finite rendezvous / collective timeout: a rank whose peers never arrive raises and exits non-zero (the launcher then
+        # ends the job; the next attempt is a fresh process, never a re-exec of this one)
+        import datetime
+
+        pg_timeout = datetime.timedelta(seconds=int(os.environ.get("TSVGP_BENCH_PG_TIMEOUT", "600")))
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=device, timeout=pg_timeout)
+            else:
+                dist.init_process_group(backend, timeout=pg_timeout)
+            dist.barrier()
+        except Exception as exc:  # rendezvous or first collective failed / timed out
+            print(f"[bench] rank {rank}: process group ({backend}, world {world}) did not come up within "
+                  f"{pg_timeout.total_seconds():.0f} s: {exc}", file=sys.stderr, flush=True)
+            sys.exit(3)
+
+    collective = None
+    if world > 1:
+        # what the process group itself reports -- not what this script was asked for: the multi-GPU line proves by itself that
+        # `world` ranks on `world` devices took part and which backend moved the bytes
+        props = torch.cuda.get_device_properties(device)
+        me = {"rank": dist.get_rank(), "local_rank": local_rank, "device_index": device.index, "device_name": props.name,
+              "pci_bus_id": getattr(props, "pci_bus_id", None), "uuid": str(getattr(props, "uuid", "")) or None, "pid": os.getpid()}
+        everyone = [None] * world
+        dist.all_gather_object(everyone, me)
+        try:
+            rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            rccl = None
+        collective = {"backend": dist.get_backend(), "world_size_seen": dist.get_world_size(), "device_per_rank": everyone,
+                      "distinct_devices": len({(e["device_index"], e["pci_bus_id"], e["uuid"]) for e in everyone}),
+                      "rccl_version": rccl, "hip_version": getattr(torch.version, "hip", None),
+                      "pg_timeout_s": int(os.environ.get("TSVGP_BENCH_PG_TIMEOUT", "600"))}
 
     dtype = torch.float64 if w["dtype"] == "f64" else torch.float32
     esize = 8 if w["dtype"] == "f64" else 4
@@ -520,12 +582,20 @@ def main():
     # created inside the region); they cost 0.05-0.1 ms per step (A/B with the collector paused: 11.38 vs 11.44 ms at
     # M = 512, 37.14 vs 37.14-37.4 ms at the headline size).
     eng.profile = None if replayed else {}
+    D_ = pkg.distributed
+    if world > 1:
+        D_.reserve_timing(8 * args.steps + 16)
+        D_.TIMING = []  # HIP events around every collective of the timed steps (pooled; replayed steps take them too: the
+        #                 all-reduce sits BETWEEN the two graphs of a step)
     with timed_region():
         t0 = time.perf_counter()
         for _ in range(args.steps):
             model.natgrad_step((Xd, Yd), lr=0.8)
         barrier()
         elapsed = time.perf_counter() - t0
+    coll_times = None
+    if world > 1:
+        coll_times, D_.TIMING = D_.timing_summary(D_.TIMING, args.steps), None
     prof = {} if replayed else eng.profile_summary()
     eng.profile = None
     if replayed:
@@ -745,6 +815,27 @@ def main():
                 fit = cpu_baseline(w, args.cpu_budget if sm is None else min(args.cpu_budget, 6.0), model_kind=args.model)
                 out["cpu_baseline"] = fit if sm is None else dict(sm["cpu_measured"], extrapolated=fit)
         out["elbo_vs_1gpu"] = elbo_vs_1gpu(args, w, elbo, steps_before_elbo)
+        if collective is not None:
+            # E-steps/s(N) = 1 / (N-pass + collective + chain): the N-sized kernels of the main stream from the per-kernel HIP
+            # events (the K(X, Z) fill runs beside the chain on the side stream), the collectives from their own events inside
+            # the timed region, the rest -- the replicated M x M chain and the host's turn-around -- by difference
+            npass = sum(v[0] * v[1] for k, v in prof.items()
+                        if k.split("(")[0] in ("tsvgp_moments", "tsvgp_site_accum", "tsvgp_trmm", "tsvgp_lik_map")) / args.steps
+            coll_ms = sum(c["ms"]["mean"] * c["count_per_step"] for c in coll_times.values())
+            ar = coll_times.get("all_reduce_sum")
+            collective.update({
+                "payload_bytes": None if ar is None else ar["payload_bytes"],
+                "allreduce_ms": None if ar is None else {k: round(v, 4) for k, v in ar["ms"].items()},
+                "per_step": {k: {"count_per_step": c["count_per_step"], "payload_bytes": c["payload_bytes"],
+                                 "ms": {a: round(b, 4) for a, b in c["ms"].items()}, "host_ms_mean": round(c["host_ms_mean"], 4)}
+                             for k, c in coll_times.items()},
+                "npass_ms": round(npass, 4), "collective_ms": round(coll_ms, 4),
+                "chain_ms": round(ms_per_step - npass - coll_ms, 4),
+                "note": "rank 0's events: ms_per_step = npass_ms (moments + site sums + whitening launches) + collective_ms "
+                        "(HIP events around every torch.distributed call of the timed steps) + chain_ms (the replicated M x M "
+                        "chain, packing, host turn-around; by difference).  device_per_rank is all_gather_object of what each "
+                        "rank's process group and device report"})
+            out["collective"] = collective
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

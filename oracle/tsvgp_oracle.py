@@ -944,7 +944,12 @@ def natgrad_step_chunked(model, data, lr=0.1, jitter=1e-9, chunk_rows=20000, pro
     G0, G1, A_abs = _CompensatedSum(), _CompensatedSum(), _CompensatedSum()
     N = X.shape[0]
     means, vars_, g0s, g1s, ve = [], [], [], [], []
-    kl_before = model.prior_kl()  # :65-70 at the state the step starts from (for ``last["elbo_before"]``, below)
+    import time as _time
+
+    extras = 0.0  # seconds spent on what is NOT part of the reference's step (marked below): a timed call subtracts them
+    _t = _time.perf_counter()
+    kl_before = model.prior_kl()  # :65-70 at the state the step starts from (for ``last["elbo_before"]``, below); not part of the step
+    extras += _time.perf_counter() - _t
     for lo in range(0, N, chunk_rows):
         Xb, Yb = X[lo:lo + chunk_rows], Y[lo:lo + chunk_rows]
         mean, var = conditional(Xb, iv, kernel, q_mu, q_sqrt=q_sqrt, white=False, _Lm=Lm)  # :246 -> :103
@@ -960,12 +965,16 @@ def natgrad_step_chunked(model, data, lr=0.1, jitter=1e-9, chunk_rows=20000, pro
         # (not part of the step) sum_n |a_n|: the sensitivity of G0 to its inputs -- an error e in g0 moves G0 by at most
         # e * sum_n |a_n|.  G0 = A^T (y - mean) / s2 is a small difference of N-sized terms once the sites fit the data, so
         # its RELATIVE error is unbounded while lambda_1, which it updates, is not affected; comparisons scale by this
+        _t = _time.perf_counter()
         A_abs.add(np.sum(np.abs(A), axis=0))
+        extras += _time.perf_counter() - _t
         G1.add(_einsum_nml_nol_nl(A, g1))  # :280
+        _t = _time.perf_counter()
         means.append(mean), vars_.append(var), g0s.append(g0), g1s.append(g1)
         # not part of the step: the block's term of ``elbo`` (:88-95) at the state the step STARTS from rides along (O(n P)),
         # so one pass over the rows yields both halves of the metric's parity check
         ve.append(float(np.sum(model.likelihood.variational_expectations(mean, var, Yb))))
+        extras += _time.perf_counter() - _t
         if progress is not None:
             progress(min(lo + chunk_rows, N), N)
     grads = [G0.value(), G1.value()]
@@ -978,6 +987,8 @@ def natgrad_step_chunked(model, data, lr=0.1, jitter=1e-9, chunk_rows=20000, pro
     model.sites.lambda_1 = lambda_1  # :302
     model.sites._lambda_2_sqrt = np.tril(lambda_2_sqrt)  # :303
     model.get_mean_chol_cov_inducing_posterior()  # :304 (result discarded)
+    _t = _time.perf_counter()
     model.last = dict(mean=np.concatenate(means), var=np.concatenate(vars_), meanZ=meanZ, g0=np.concatenate(g0s),
                       g1=np.concatenate(g1s), G0=grads[0], G1=grads[1],
                       elbo_before=math.fsum(ve) * scale - kl_before, A_abs_colsum=A_abs.value())
+    model.last["extras_seconds"] = extras + (_time.perf_counter() - _t)

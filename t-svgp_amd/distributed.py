@@ -20,6 +20,55 @@ import torch.distributed as dist
 FORCE_COLLECTIVES = os.environ.get("TSVGP_FORCE_COLLECTIVES", "0") == "1"
 
 
+# Timing of the collectives (bench.py's multi-rank lines): set TIMING to a list and every collective below appends
+# (kind, bytes, start event, stop event, host seconds) -- HIP events on the stream the collective is ordered against (the
+# current stream: a synchronous torch.distributed call makes it wait for the backend's own stream), from a pool filled by
+# ``reserve_timing`` so that no event is created inside a timed region.  None (default): no events, no overhead.
+TIMING = None
+_EVENT_POOL = []
+
+
+def reserve_timing(n_collectives: int):
+    while len(_EVENT_POOL) < 2 * n_collectives:
+        _EVENT_POOL.append(torch.cuda.Event(enable_timing=True))
+
+
+class _timed:
+    def __init__(self, kind: str, t: torch.Tensor):
+        self.on = TIMING is not None and t.is_cuda
+        self.kind, self.nbytes = kind, t.numel() * t.element_size()
+
+    def __enter__(self):
+        if self.on:
+            import time
+
+            self.e0 = _EVENT_POOL.pop() if _EVENT_POOL else torch.cuda.Event(enable_timing=True)
+            self.e1 = _EVENT_POOL.pop() if _EVENT_POOL else torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+            self.t0 = time.perf_counter()
+
+    def __exit__(self, *exc):
+        if self.on:
+            import time
+
+            host = time.perf_counter() - self.t0
+            self.e1.record()
+            TIMING.append((self.kind, self.nbytes, self.e0, self.e1, host))
+
+
+def timing_summary(entries, steps: int):
+    """{kind: {count_per_step, bytes, ms: {mean, min, max}, host_ms_mean}} of TIMING entries (after a synchronize)."""
+    out = {}
+    for kind, nbytes, e0, e1, host in entries:
+        d = out.setdefault(kind, {"n": 0, "bytes": nbytes, "ms": [], "host": 0.0})
+        d["n"] += 1
+        d["ms"].append(e0.elapsed_time(e1))
+        d["host"] += host * 1e3
+    return {k: {"count_per_step": d["n"] / max(steps, 1), "payload_bytes": d["bytes"],
+                "ms": {"mean": sum(d["ms"]) / len(d["ms"]), "min": min(d["ms"]), "max": max(d["ms"])},
+                "host_ms_mean": d["host"] / d["n"]} for k, d in out.items()}
+
+
 def collectives_on() -> bool:
     """True when all_reduce_sum / broadcast_from_rank0 go to the backend: more than one rank, or a forced single rank."""
     if not (dist.is_available() and dist.is_initialized()):
@@ -120,7 +169,8 @@ def reduce_stats(stats, P: int, M: int, with_sites: bool, reduce: bool, eng=None
 def all_reduce_sum(packed: torch.Tensor) -> torch.Tensor:
     """In-place sum over ranks (no-op for a single process)."""
     if collectives_on():
-        dist.all_reduce(packed, op=dist.ReduceOp.SUM)
+        with _timed("all_reduce_sum", packed):
+            dist.all_reduce(packed, op=dist.ReduceOp.SUM)
     return packed
 
 
@@ -136,7 +186,8 @@ def broadcast_from_rank0(t: torch.Tensor) -> torch.Tensor:
 def all_reduce_max(t: torch.Tensor) -> torch.Tensor:
     """In-place maximum over ranks (status words of a latent-split step: every rank raises or retries together)."""
     if collectives_on():
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        with _timed("all_reduce_max", t):
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return t
 
 
@@ -145,7 +196,8 @@ def all_gather_flat(send: torch.Tensor) -> torch.Tensor:
     if not collectives_on():
         return send
     out = torch.empty(dist.get_world_size() * send.numel(), dtype=send.dtype, device=send.device)
-    dist.all_gather_into_tensor(out, send.contiguous())
+    with _timed("all_gather", out):
+        dist.all_gather_into_tensor(out, send.contiguous())
     return out
 
 
@@ -157,8 +209,10 @@ def reduce_scatter_sum(packed: torch.Tensor, world: int) -> torch.Tensor:
     n = packed.numel() // world
     if dist.get_backend() == "nccl":
         out = torch.empty(n, dtype=packed.dtype, device=packed.device)
-        dist.reduce_scatter_tensor(out, packed.contiguous(), op=dist.ReduceOp.SUM)
+        with _timed("reduce_scatter_sum", packed):
+            dist.reduce_scatter_tensor(out, packed.contiguous(), op=dist.ReduceOp.SUM)
         return out
-    dist.all_reduce(packed, op=dist.ReduceOp.SUM)
+    with _timed("reduce_scatter_sum(all_reduce)", packed):
+        dist.all_reduce(packed, op=dist.ReduceOp.SUM)
     r = dist.get_rank()
     return packed[r * n:(r + 1) * n]

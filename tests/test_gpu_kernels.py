@@ -66,6 +66,14 @@ def test_se_fill_exp_is_the_library_exp_bit_for_bit(engines):
     ref = torch.exp(-0.5 * (X * X)).expand(N, M)
     assert torch.equal(out[:N, :M], ref)
     assert float(out[7, 0]) == 0.0 and int((ref == 0).sum()) > 0 and int((ref > 0.5).sum()) > 0
+    # the product's own form, sum_d ((x - z) / l)^2 with NON-ZERO Z (unit lengthscale: the difference and its square are the
+    # same fp64 operations on either side): bit for bit again, down into the underflow range
+    Zr = (torch.rand(M, 1, generator=g, dtype=torch.float64) * 40.0).to("cuda:0")
+    eng.se_fill(X, Zr, torch.ones(1, dtype=torch.float64, device="cuda:0"), 1.0, out)
+    d = X - Zr.reshape(1, M)
+    ref2 = torch.exp(-0.5 * (d * d))
+    assert torch.equal(out[:N, :M], ref2)
+    assert int((ref2 == 0).sum()) > 0 and int((ref2 > 0.5).sum()) > 0
 
 
 @pytest.mark.parametrize("dtype,tol", DTYPES)

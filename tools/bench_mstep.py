@@ -19,5 +19,5 @@ torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
 prof = eng.profile_summary(); eng.profile = None
 print(f"elbo_and_grads: {dt * 1e3:.2f} ms per evaluation; elbo {float(e):.6f}")
 print({k: float(v) if v.dim() == 0 else [round(float(x), 4) for x in v.reshape(-1)[:4]] for k, v in g.items()})
-for k, (n, ms) in prof.items():
+for k, (n, ms, *_) in prof.items():
     print(f"  {k:22s} x{n / 5:.0f}  {ms:8.3f} ms")
