@@ -445,6 +445,9 @@ def main():
     ap.add_argument("--no-side-lines", action="store_true", help="skip warm / forced-route / mean-only side measurements")
     ap.add_argument("--no-state-match", action="store_true",
                     help="skip the oracle's full-N E-step (state match + measured CPU baseline); elbo_match alone then runs")
+    ap.add_argument("--loop", default=None, choices=["em"],
+                    help="em: add the `em_loop` side line -- ONE iteration of the reference's training loop (8 E-steps + 20 Adam "
+                         "M-steps, experiments/uci_regression.py:132-160) timed with its E / M split; never `value`")
     ap.add_argument("--state-budget", type=float, default=250.0,
                     help="seconds the oracle's full-N E-step may take (projected from its first row block); beyond it the step "
                          "is skipped and elbo_match / the extrapolated cpu_baseline stand alone")
@@ -714,6 +717,65 @@ def main():
                      "note": "skip_unused_variance=True (Gaussian likelihood): cold E-step without the predictive-variance "
                              "product, whose value the Gaussian site update does not use; not the headline"}
 
+    # One iteration of the reference's E/M loop (experiments/uci_regression.py:132-160, defaults :17-21: 8 E-steps at lr 0.8, the
+    # ELBO, 20 Adam steps at 0.1 on kernel variance / lengthscales / noise variance / Z), on a COPY of the state so that the parity
+    # half below still sees the state the timed E-steps left.  A side line, never `value`.
+    em_line = None
+    if args.loop == "em" and args.model == "tsvgp" and not w.get("separate"):
+        tr = pkg.training
+        saved = (model.lambda_1.value.clone(), model.lambda_2_sqrt.value.clone(),
+                 {n: p.value.clone() for n, (p, _) in tr.trainable_parameters(model).items()})
+        opt = tr.Adam(0.1)
+        for _ in range(2):  # library handles, buffers of the gradient pass
+            model.elbo_and_grads((Xd, Yd))
+        barrier()
+        eng.profile = {}
+        t0 = time.perf_counter()
+        for _ in range(8):
+            model.natgrad_step((Xd, Yd), lr=0.8)
+        barrier()
+        t_e = time.perf_counter() - t0
+        e_kernels = eng.profile_summary()
+        eng.profile = {}
+        t0 = time.perf_counter()
+        elbo_em = float(model.elbo((Xd, Yd)))
+        barrier()
+        t_l = time.perf_counter() - t0
+        eng.profile = {}
+        t0 = time.perf_counter()
+        tr.m_step(model, (Xd, Yd), opt, 20)
+        barrier()
+        t_m = time.perf_counter() - t0
+        m_kernels = eng.profile_summary()
+        eng.profile = None
+        tm = torch.tensor([t_e, t_l, t_m], dtype=torch.float64, device=device)
+        if world > 1:
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        t_e, t_l, t_m = (float(v) for v in tm)
+        Mq, Pq = w["M"], w["P"]
+        # algorithmic flops of one gradient evaluation on this rank's rows: the moments' triangular product and the site sums
+        # (N M (M + 1) P each), and Q k_n for every row (2 N M^2 P as one dense product, or N M (M + 1) P when the moments'
+        # product is reused: the figure below prices the CHEAPER form, whatever ran)
+        g_flops = 3.0 * rows * Mq * (Mq + 1) * Pq
+        em_line = {"iteration_s": round(t_e + t_l + t_m, 4), "e_block_ms": round(t_e * 1e3, 2), "elbo_log_ms": round(t_l * 1e3, 2),
+                   "m_block_ms": round(t_m * 1e3, 2), "m_share": round(t_m / (t_e + t_l + t_m), 4),
+                   "e_step_ms": round(t_e / 8 * 1e3, 3), "grad_eval_plus_adam_ms": round(t_m / 20 * 1e3, 3),
+                   "elbo_after_e_block": elbo_em,
+                   "m_step_roofline": {"bound": "mfma", "achieved": round(g_flops / (t_m / 20) / 1e12, 3), "peak": PEAK_TFLOPS[w["dtype"]],
+                                       "unit": "TFLOP/s", "frac": round(g_flops / (t_m / 20) / 1e12 / PEAK_TFLOPS[w["dtype"]], 4),
+                                       "algorithmic_flops_per_evaluation": g_flops,
+                                       "note": "3 N M (M + 1) P: moments product, site sums, Q k_n from the moments' product"},
+                   "m_step_kernel_avg_ms": {k: round(v[1], 4) for k, v in sorted(m_kernels.items())},
+                   "m_step_kernel_ms_per_evaluation": round(sum(v[0] * v[1] for v in m_kernels.values()) / 20, 3),
+                   "e_block_kernel_ms_per_step": round(sum(v[0] * v[1] for v in e_kernels.values()) / 8, 3),
+                   "note": "ONE iteration of the reference's loop (experiments/uci_regression.py:132-160): 8 cold E-steps (lr 0.8), the "
+                           "ELBO, 20 x (elbo_and_grads + Adam 0.1 on variance, lengthscales, noise variance, Z); every M-step changes "
+                           "theta and Z, so each gradient pass rebuilds K_uu, K_uf and the factorisations; a side line, never `value`"}
+        model.lambda_1.assign(saved[0])
+        model.sites.assign_lambda_2_sqrt(saved[1])
+        for n, (p_, _) in tr.trainable_parameters(model).items():
+            p_.assign(saved[2][n])
+
     # the label of config.parallelism is computed on EVERY rank: _routes() may issue a broadcast when its cache misses, and a
     # collective only rank 0 enters (the others already wait in the closing barrier) would hang the job
     split_on = bool(world > 1 and getattr(model, "_latent_split", None) is not None
@@ -782,6 +844,7 @@ def main():
                      "note": "cache_whitened=True: the factor of K_uu+jitter I, its inverse and the N x M operand (K_fu, or "
                              "the whitened B) reused across E-steps with unchanged hyperparameters; not the headline"},
             "hipgraph": graph_line,
+            "em_loop": em_line,
             "skip_unused_variance": skip_line,
             "roofline": roofline,
             "step_roofline": step_roofline,

@@ -46,6 +46,7 @@ class EStepStats:
     var: Optional[torch.Tensor] = None  # [N, P]
     g0: Optional[torch.Tensor] = None  # [N, P]
     g1: Optional[torch.Tensor] = None  # [N, P]
+    tile: Optional[torch.Tensor] = None  # [Np, Mp] the stored triangular product t_n = Tm k_n (run(keep_tile=True))
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -268,7 +269,7 @@ class EStepEngine:
                                                 out.stride(0), M, nb, float(scale), int(flip), self._stream()), "tsvgp_tri_copy")
         return out
 
-    def cholesky_solve_upper(self, A: torch.Tensor, Lrhs, robust: bool = False):
+    def cholesky_solve_upper(self, A: torch.Tensor, Lrhs, robust: bool = False, beside_fill: bool = False):
         """Upper-form factorisation AND the triangular solve behind it in one pass (``tsvgp_potrf_solve_f64``):
             A = U U^T (U upper triangular, as ``cholesky(upper_form=True)``),   D = U^-1 Lrhs^T   (upper triangular)
         for A [.., M, M] and a lower triangular Lrhs [.., M, M] -- reference src/util.py:168-175 with W = I + L^T K L for A and the
@@ -277,7 +278,12 @@ class EStepEngine:
         the factorisation of J A J as extra panel rows and comes out as (J L J) C^-T = (C^-1 J L^T J)^T; one transposing pass turns
         that into D.  Replaces the inverse recursion (three levels of launch pairs), two triangle copies, a 1024^3 GEMM and a triu
         pass on the critical path of the replicated M x M chain.  ``Lrhs`` may be a LIST of [n_i, M, M] tensors, one run of the
-        batch each.  Returns (U, info, D); no host synchronisation."""
+        batch each.  Returns (U, info, D); no host synchronisation.
+        ``beside_fill``: the N-sized K(X, Z) fill is in flight on the side stream and will outlast this call.  Round 5's panel
+        kernel holds a strip and two column blocks of operands in 250 registers per lane and cannot share a CU with the fill's
+        workgroups (224 registers per lane left), round 4's block step (78-87 registers per kernel) can: under the fill of
+        N = 1e6 rows the call takes 1.69 ms with round 4's step and 2.13 ms with round 5's (profiles/r05_potrf_under_fill_ab.txt),
+        alone 0.49 against 0.45."""
         A = A.to(device=self.device, dtype=torch.float64)
         M = A.shape[-1]
         batch_shape = A.shape[:-2]
@@ -303,7 +309,7 @@ class EStepEngine:
             tall[:, :Mp].diagonal(dim1=-2, dim2=-1)[:, M:] = 1.0  # chol([[A, 0], [0, I]]) = [[C, 0], [0, I]]
         info = torch.empty(nb, dtype=torch.int32, device=self.device)
         work = self._get("potrf_work", (nb, 128 * 128), torch.float64)
-        flags = (B.POTRF_SUBST if robust else 0) | B.POTRF_RHS_UPPER | self.potrf_flags
+        flags = (B.POTRF_SUBST if robust else 0) | B.POTRF_RHS_UPPER | self.potrf_flags | (B.POTRF_DIAG_V1 if beside_fill else 0)
         with torch.cuda.device(self.device):
             self._launch("tsvgp_potrf", lambda: self.lib.tsvgp_potrf_solve_f64(
                 tall.data_ptr(), Mp, Mp, nb, 2 * Mp * Mp, info.data_ptr(), work.data_ptr(), Mp, flags, self._stream()))
@@ -805,8 +811,15 @@ class EStepEngine:
     # ------------------------------------------------------------------ one N-pass
     def run(self, X, Y, Z, kernel, *, moment_Tm, moment_mode, gamma, lik_id=B.LIK_NONE, lik_param=0.0,
             whiten_T=None, whiten_mode=B.TRI_UPPER, project_T=None, sites=False, want_moments=False, want_grads=False,
-            b_tag=None, mean_only=False, prefill=None, moments_on_kfu=False, project_mode=B.TRI_LOWER) -> EStepStats:
+            b_tag=None, mean_only=False, prefill=None, moments_on_kfu=False, project_mode=B.TRI_LOWER,
+            keep_tile=False) -> EStepStats:
         """One pass over the shard's rows.
+
+        keep_tile (one latent, no whitening): the triangular product of the moments, t_n = Tm k_n, is STORED (``tsvgp_trmm``
+        into the buffer "Tt", returned as ``stats.tile``) and the moments are assembled from it -- mean by a matrix-vector
+        product, var = kdiag - |t_n|^2 by a row norm, the gradients by ``tsvgp_lik_map`` -- instead of being squared and summed
+        inside the fused kernel.  For the M-step (t_SVGP.elbo_and_grads), which needs Q k_n = Tm^T t_n for every row: a second
+        triangular product of the stored tile instead of a dense N M^2 GEMM with Q = Tm^T Tm.
 
         X [N, D], Y [N, P] (or None when lik_id == NONE), Z [M, D];
         whiten_T [M, M] fp64: the inverted triangular factor of Kuu + jitter I (B[n, i] = sum_j Kfu[n, j] whiten_T[i, j]
@@ -907,12 +920,26 @@ class EStepEngine:
         mean = torch.empty((N, P), dtype=T, device=dev) if want_moments else None
         var = torch.empty((N, P), dtype=T, device=dev) if (want_moments and not mean_only) else None
         lik_flags = (lik_id | B.LIK_MEANONLY) if mean_only else lik_id
-        with torch.cuda.device(dev):
-            self._launch("tsvgp_moments", lambda: self._fn("tsvgp_moments")(
-                A.data_ptr(), Tm.data_ptr(), gam.data_ptr(), _ptr(Y) if need_g else None, variance, lik_flags,
-                float(lik_param), _ptr(mean), _ptr(var), _ptr(g0), _ptr(g1), ve_partial.data_ptr(),
-                nonpos_partial.data_ptr(), N, Np, Mp, P, moment_mode, self._stream()))
+        tile = None
+        if keep_tile:
+            if P != 1 or mean_only or whiten_T is not None or not need_g:
+                raise ValueError("keep_tile: one latent, a likelihood, no whitening")
+            tile = self._get("Tt", (Np, Mp), T)
+            self.trmm(A, Tm[0], tile, moment_mode)
+            mean = torch.mv(A[:N], gam[:, 0]).reshape(N, 1)  # gam: [Mp, 1], rows >= M zero
+            var = (variance - torch.linalg.vector_norm(tile[:N], dim=1).square()).reshape(N, 1)
+            with torch.cuda.device(dev):
+                self._launch("tsvgp_lik_map", lambda: self._fn("tsvgp_lik_map")(
+                    mean.data_ptr(), var.data_ptr(), Y.data_ptr(), lik_id, float(lik_param), g0.data_ptr(), g1.data_ptr(),
+                    ve_partial.data_ptr(), nonpos_partial.data_ptr(), N, Np, 1, self._stream()))
+        else:
+            with torch.cuda.device(dev):
+                self._launch("tsvgp_moments", lambda: self._fn("tsvgp_moments")(
+                    A.data_ptr(), Tm.data_ptr(), gam.data_ptr(), _ptr(Y) if need_g else None, variance, lik_flags,
+                    float(lik_param), _ptr(mean), _ptr(var), _ptr(g0), _ptr(g1), ve_partial.data_ptr(),
+                    nonpos_partial.data_ptr(), N, Np, Mp, P, moment_mode, self._stream()))
         stats = EStepStats(n_rows=N, ve_sum=ve_partial.sum(), nonpos=nonpos_partial.sum().to(torch.float64))
+        stats.tile = tile
         if want_moments:
             stats.mean, stats.var = mean.to(torch.float64), (None if var is None else var.to(torch.float64))
         if want_grads and need_g:

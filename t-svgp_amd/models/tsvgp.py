@@ -320,7 +320,7 @@ class t_SVGP(base_SVGP):
         return [r == "direct" for r in self._routes(jitter)]
 
     def _site_operands(self, whiten_jitter=None, warm_key=None, routes=None, latents=None, fork=True, Kzz=None, K6=None,
-                       after_w=None):
+                       after_w=None, beside_fill=False):
         """Everything the N-pass needs that depends only on (theta, Z, lambda): O(M^3), fp64, replicated.
         No host synchronisation happens here: Cholesky statuses are collected in ops["infos"] and checked once per
         call by ``_check_step`` (TF raises immediately; here the raise comes at the end of the same call).
@@ -395,7 +395,7 @@ class t_SVGP(base_SVGP):
         Dm = None
         if solve:
             rhs = [L] + ([Id.expand(n9, M, M)] if n9 else [])
-            both, info_w, sol = eng.cholesky_solve_upper(batch, rhs, robust=robust)
+            both, info_w, sol = eng.cholesky_solve_upper(batch, rhs, robust=robust, **({"beside_fill": True} if beside_fill else {}))
             infos.append(info_w.reshape(-1).to(torch.int32))
             U_W, Dm, Uinv_W, inv_both = both[:P_], sol[:P_], None, sol
         else:
@@ -648,13 +648,25 @@ class t_SVGP(base_SVGP):
         for ki, kern in enumerate(kernels):
             lat = [ki] if sep else list(range(P))
             sl = slice(lat[0], lat[-1] + 1)
+            # One latent: the moments' own triangular product t_n = D k_n is KEPT (tsvgp_trmm) and Q k_n = D^T t_n is a second
+            # triangular product of it -- 2 N M^2 flops for moments + U instead of the 3 N M^2 of the fused moments kernel plus a
+            # dense GEMM with Q = D^T D (round 5; 16.8 + 28.1 ms -> 15.5 + ~5 + 16 ms at N = 1e6, M = 1024).
+            tile_path = len(lat) == 1 and hasattr(eng, "trmm") and os.environ.get("TSVGP_MSTEP_TILE", "1") != "0"
             st = eng.run(X, Y[:, sl], ops["Z"], kern, moment_Tm=Dm[sl], moment_mode=ops["moment_mode"], gamma=beta[:, sl],
                          lik_id=self.likelihood.lik_id | B.LIK_NOCROP, lik_param=self.likelihood.lik_param, sites=True,
-                         want_moments=gaussian)
+                         want_moments=gaussian, **({"keep_tile": True} if tile_path else {}))
             parts.append(st)
             Kfu, g0, g1 = eng._buf["Kfu"], eng._buf["g0"], eng._buf["g1"]  # [Np, Mp], [Np, len(lat)] (rows >= N are zero)
             Ubuf = eng._get("U", tuple(Kfu.shape), Kfu.dtype)
             for c, p_ in enumerate(lat):
+                if tile_path:
+                    # U[n, m] = sum_{i <= m} t[n, i] D[i, m]: the lower-form product with D^T
+                    eng.trmm(st.tile, eng._pad_square(Dm[p_].transpose(-1, -2).contiguous(), Kfu.shape[1], "pad_Dt"), Ubuf, B.TRI_LOWER)
+                    v, l, z = eng.kernel_grad(X, ops["Z"], kern, Ubuf, g0[:, c], g1[:, c], beta[:, p_])
+                    dvar[ki] += v
+                    dls[ki] += l
+                    dZ += z
+                    continue
                 # U = K_fu Q_p: a plain dense GEMM, so it goes to the BLAS library (rocBLAS DGEMM holds 0.95 of the fp64 MFMA
                 # peak at this shape, tools/dgemm_ref.py: 28.1 ms at N = 1e6, M = 1024 against 33.8 for tsvgp_trmm's dense mode)
                 torch.mm(Kfu, eng._pad_square(0.5 * (Q[p_] + Q[p_].T), Kfu.shape[1], "pad_Q"), out=Ubuf)
@@ -781,7 +793,8 @@ class t_SVGP(base_SVGP):
             else:
                 pre = eng.start_fill(X, self._Z(), self.kernel, b_tag=warm_key, want=want, routes=routes)
         if ops is None:
-            ops = self._site_operands(whiten_jitter=jitter, warm_key=warm_key, routes=routes, fork=fork, Kzz=Kzz, K6=K6)
+            ops = self._site_operands(whiten_jitter=jitter, warm_key=warm_key, routes=routes, fork=fork, Kzz=Kzz, K6=K6,
+                                      beside_fill=pre is not None)  # a long fill is already under way: see cholesky_solve_upper
         st = eng.run(X, Y, ops["Z"], self.kernel, moment_Tm=ops["moment_Tm"], prefill=pre,
                      moment_mode=ops["moment_mode"], gamma=ops["gamma"],
                      lik_id=self.likelihood.lik_id, lik_param=self.likelihood.lik_param,
