@@ -307,6 +307,15 @@ template <typename T>
 __device__ __forceinline__ T exp_nonpos(T a) {
     return exp(a);
 }
+// fp32: the hardware exponential, v_exp_f32(a log2 e) -- two instructions where the library's range-reduced expf takes thirteen
+// (a quarter-rate v_exp_f32 among them either way): with the packed distance loop the exponentials were half of the fp32 fill's
+// issue time.  Relative error ~|a| 2^-24 (the product a log2 e is rounded once), i.e. <= 1e-5 for kernel values down to 1e-30 and
+// far inside the fp32 path's stated tolerance against the fp64 oracle (atol 1e-4 + rtol 1e-3); results below the
+// normal range flush to zero.
+template <>
+__device__ __forceinline__ float exp_nonpos<float>(float a) {
+    return __expf(a);
+}
 template <>
 __device__ __forceinline__ double exp_nonpos<double>(double a) {
     constexpr auto C = [](unsigned long long bits) { return __builtin_bit_cast(double, bits); };
@@ -372,7 +381,25 @@ struct FillBatch {
     T v[TSVGP_MAX_BATCH];
 };
 
-template <typename T, int KIND, int DT>
+// CPT = columns per thread: 2, or 4 in fp32 -- a thread's output of one row is then 16 bytes in either type.  With 8-byte
+// stores the fp32 fill reached 2.3 TB/s where the fp64 fill (16-byte stores) reaches 4.5: 8-byte accesses run at 0.54-0.70 of
+// the 16-byte rate (MI355X guide, stores of each flavour), and the four columns give the distance loop four independent chains.
+template <typename T, int CPT>
+struct FillVec;
+template <>
+struct FillVec<double, 2> {
+    typedef v2d type;
+};
+template <>
+struct FillVec<float, 2> {
+    typedef v2f type;
+};
+template <>
+struct FillVec<float, 4> {
+    typedef v4f type;
+};
+
+template <typename T, int KIND, int DT, int CPT = 2>
 __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, TSVGP_FILL_MAXWAVES))) void se_fill_kernel(
     const T* __restrict__ X, const T* __restrict__ Z, const T* __restrict__ inv_ls, FillBatch<T> var, T* __restrict__ K,
     int64_t strideK, int64_t N, int M, int D, int64_t ldk, int64_t rows_pad, int cols_pad, int stream_out, int rows_blk) {
@@ -383,7 +410,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, TSV
 #ifdef TSVGP_FILL_EXPANDED
     __shared__ T Xn[FILL_ROWS];  // |x~|^2 of the staged rows
 #endif
-    typedef typename Mfma<T>::pair_t pair_t;
+    typedef typename FillVec<T, CPT>::type vec_t;
 
     const T variance = var.v[blockIdx.z];
     inv_ls += (size_t)blockIdx.z * D;
@@ -391,15 +418,15 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, TSV
     const int t = threadIdx.x;
     const int ctile = blockIdx.y;
     const int64_t rb_first = blockIdx.x, rb_step = gridDim.x;
-    const int m = ctile * FILL_COLS + 2 * t;  // this thread's column pair
-    const bool v0 = (m < M), v1 = (m + 1 < M), active = (m < cols_pad);
-    const T var0 = v0 ? variance : T(0), var1 = v1 ? variance : T(0);
-    T z0[DT], z1[DT];
+    const int m = ctile * (CPT * NTHREADS) + CPT * t;  // this thread's columns
+    const bool active = (m < cols_pad);
+    T varc[CPT], z[CPT][DT];
 #pragma unroll
-    for (int d = 0; d < DT; ++d) {
-        const T il = d < D ? inv_ls[d] : T(0);
-        z0[d] = (v0 && d < D) ? Z[(int64_t)m * D + d] * il : T(0);
-        z1[d] = (v1 && d < D) ? Z[(int64_t)(m + 1) * D + d] * il : T(0);
+    for (int c = 0; c < CPT; ++c) {
+        const bool vc = m + c < M;
+        varc[c] = vc ? variance : T(0);
+#pragma unroll
+        for (int d = 0; d < DT; ++d) z[c][d] = (vc && d < D) ? Z[(int64_t)(m + c) * D + d] * inv_ls[d] : T(0);
     }
 #ifdef TSVGP_FILL_EXPANDED
     // Round 4 experiment (-DTSVGP_FILL_EXPANDED, measured and NOT the default: profiles/r04_fill_expanded_ab.txt): the scaled squared
@@ -409,13 +436,15 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, TSV
     // D = 16: 1.76 -> 1.68 ms, the step 18.83 -> 18.62 ms -- the kernel is not purely VALU-issue bound -- and in fp32 the expanded
     // form costs accuracy exactly where the E-step has its inducing points (Z = X[:M]: r2 = 0 becomes +-1e-6).  The difference
     // form stays.
-    T zz0 = T(0), zz1 = T(0);
+    T zz[CPT];
 #pragma unroll
-    for (int d = 0; d < DT; ++d) {
-        zz0 += z0[d] * z0[d];
-        zz1 += z1[d] * z1[d];
-        z0[d] *= T(-2);
-        z1[d] *= T(-2);
+    for (int c = 0; c < CPT; ++c) {
+        zz[c] = T(0);
+#pragma unroll
+        for (int d = 0; d < DT; ++d) {
+            zz[c] += z[c][d] * z[c][d];
+            z[c][d] *= T(-2);
+        }
     }
 #endif
     // Row blocks are dealt round-robin to the workgroups of a column tile.  The default grid has one workgroup per
@@ -440,49 +469,83 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, TSV
 #endif
         if (active) {
             // row counts of this block as wave-uniform ints: valid rows get kernel values, the padding rows up to
-            // rows_pad zeros.  Invalid columns of the last pair come out as exact zeros through their variance factor.
+            // rows_pad zeros.  Invalid columns of the last group come out as exact zeros through their variance factor.
             const int64_t left = N - n0, left_pad = rows_pad - n0;
             const int nvalid = left >= rows_blk ? rows_blk : (left > 0 ? (int)left : 0);
             const int nrows = left_pad >= rows_blk ? rows_blk : (int)left_pad;
             T* const Kp = K + n0 * ldk + m;
             for (int rr = 0; rr < nvalid; ++rr) {
+                T sv[CPT];
 #ifdef TSVGP_FILL_EXPANDED
                 const T xn = Xn[rr];
-                T s0 = xn + zz0, s1 = xn + zz1;
+#pragma unroll
+                for (int c = 0; c < CPT; ++c) sv[c] = xn + zz[c];
 #pragma unroll
                 for (int d = 0; d < DT; ++d) {
                     const T x = Xs[rr][d];
-                    s0 = fma(x, z0[d], s0);
-                    s1 = fma(x, z1[d], s1);
+#pragma unroll
+                    for (int c = 0; c < CPT; ++c) sv[c] = fma(x, z[c][d], sv[c]);
                 }
 #else
-                T s0 = T(0), s1 = T(0);
+                if constexpr (sizeof(T) == 4) {
+                    // fp32: two columns per PACKED instruction (v_pk_add_f32 / v_pk_fma_f32).  A plain fp32 vector instruction
+                    // costs a wave64 four cycles on this chip -- the 157 TFLOP/s vector peak is the packed rate -- and the
+                    // difference form is two dependent operations per (dimension, column): measured ~5 cycles per instruction
+                    // and 2.3-2.55 TB/s at D = 16 before (tools/fill_alone_f32.py)
+                    v2f sp[CPT / 2];
 #pragma unroll
-                for (int d = 0; d < DT; ++d) {
-                    const T x = Xs[rr][d];
-                    const T d0 = x - z0[d], d1 = x - z1[d];
-                    s0 += d0 * d0;
-                    s1 += d1 * d1;
+                    for (int c = 0; c < CPT / 2; ++c) sp[c] = v2f{0.0f, 0.0f};
+#pragma unroll
+                    for (int d = 0; d < DT; ++d) {
+                        const float x = Xs[rr][d];
+                        const v2f xx = {x, x};
+#pragma unroll
+                        for (int c = 0; c < CPT / 2; ++c) {
+                            const v2f dd = xx - v2f{z[2 * c][d], z[2 * c + 1][d]};
+                            sp[c] = __builtin_elementwise_fma(dd, dd, sp[c]);
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < CPT / 2; ++c) {
+                        sv[2 * c] = sp[c][0];
+                        sv[2 * c + 1] = sp[c][1];
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < CPT; ++c) sv[c] = T(0);
+#pragma unroll
+                    for (int d = 0; d < DT; ++d) {
+                        const T x = Xs[rr][d];
+#pragma unroll
+                        for (int c = 0; c < CPT; ++c) {
+                            const T dd = x - z[c][d];
+                            sv[c] += dd * dd;
+                        }
+                    }
                 }
 #endif
-                pair_t out;
+                vec_t out;
+#pragma unroll
+                for (int c = 0; c < CPT; ++c) {
 #ifdef TSVGP_EXP_NOEXP  // ablation switch (tools/exp_fill.py): the store-bound floor of the kernel
-                out[0] = var0 * (T(1) - T(0.5) * s0);
-                out[1] = var1 * (T(1) - T(0.5) * s1);
+                    out[c] = varc[c] * (T(1) - T(0.5) * sv[c]);
 #else
-                out[0] = var0 * kernel_profile<KIND>(s0);
-                out[1] = var1 * kernel_profile<KIND>(s1);
+                    out[c] = varc[c] * kernel_profile<KIND>(sv[c]);
 #endif
+                }
 #ifdef TSVGP_EXP_NOSTORE  // ablation switch: the arithmetic alone (the store never executes, the compiler cannot know)
-                if (out[0] == T(-1)) *reinterpret_cast<pair_t*>(Kp + (int64_t)rr * ldk) = out;
+                if (out[0] == T(-1)) *reinterpret_cast<vec_t*>(Kp + (int64_t)rr * ldk) = out;
 #else
                 if (stream_out)
-                    __builtin_nontemporal_store(out, reinterpret_cast<pair_t*>(Kp + (int64_t)rr * ldk));
+                    __builtin_nontemporal_store(out, reinterpret_cast<vec_t*>(Kp + (int64_t)rr * ldk));
                 else
-                    *reinterpret_cast<pair_t*>(Kp + (int64_t)rr * ldk) = out;
+                    *reinterpret_cast<vec_t*>(Kp + (int64_t)rr * ldk) = out;
 #endif
             }
-            for (int rr = nvalid; rr < nrows; ++rr) *reinterpret_cast<pair_t*>(Kp + (int64_t)rr * ldk) = pair_t{T(0), T(0)};
+            vec_t zero;
+#pragma unroll
+            for (int c = 0; c < CPT; ++c) zero[c] = T(0);
+            for (int rr = nvalid; rr < nrows; ++rr) *reinterpret_cast<vec_t*>(Kp + (int64_t)rr * ldk) = zero;
         }
         if (rb + rb_step < nrb) __syncthreads();  // Xs is rewritten by the next row block
     }
@@ -3808,12 +3871,15 @@ int kernel_fill(int kind, const T* X, const T* Z, const T* inv_ls, const T* vari
     FillBatch<T> var{};
     for (int q = 0; q < P; ++q) var.v[q] = variance[q];
     const int rows_blk = rows_pad <= 4096 ? 8 : FILL_ROWS;  // (rows_pad is a multiple of 128: both divide it)
-    dim3 grid((unsigned)((rows_pad + rows_blk - 1) / rows_blk), (unsigned)((cols_pad + FILL_COLS - 1) / FILL_COLS),
-              (unsigned)P);
+    // fp32: four columns per thread (16-byte stores) where the layout allows it, else two
+    const int DT = D <= 1 ? 1 : D <= 2 ? 2 : D <= 4 ? 4 : D <= 8 ? 8 : D <= 16 ? 16 : 32;
+    const bool cpt4 = sizeof(T) == 4 && DT <= 16 && (ldk % 4) == 0 && (strideK % 4) == 0 &&
+                      (reinterpret_cast<uintptr_t>(K) & 15) == 0 && (cols_pad % 4) == 0;  // (DT = 32: 128 registers of Z alone)
+    const int cols_wg = (cpt4 ? 4 : 2) * NTHREADS;
+    dim3 grid((unsigned)((rows_pad + rows_blk - 1) / rows_blk), (unsigned)((cols_pad + cols_wg - 1) / cols_wg), (unsigned)P);
 #ifdef TSVGP_FILL_GRID_CAP  // experiment build (tools/exp_overlap2.py): fewer, looping workgroups
     if ((unsigned)(TSVGP_FILL_GRID_CAP) < grid.x) grid.x = (unsigned)(TSVGP_FILL_GRID_CAP);
 #endif
-    const int DT = D <= 1 ? 1 : D <= 2 ? 2 : D <= 4 ? 4 : D <= 8 ? 8 : D <= 16 ? 16 : 32;
     // An output far beyond the caches (4 MB of L2 per XCD, 256 MB of Infinity Cache) is written with non-temporal stores:
     // nothing of it would still be cached when its reader arrives, and the M x M factorisations that run beside the fill of
     // an E-step keep their operands in L2 (under the fill a factorisation call: 0.87 -> 0.80 ms; the step at N = 1e6
@@ -3823,9 +3889,18 @@ int kernel_fill(int kind, const T* X, const T* Z, const T* inv_ls, const T* vari
 #else
     const int stream_out = (double)rows_pad * (double)ldk * sizeof(T) * P >= 512.0 * 1024 * 1024;
 #endif
-#define TSVGP_FILL_LAUNCH(KIND_, DT_)                                                                                 \
-    hipLaunchKernelGGL((se_fill_kernel<T, KIND_, DT_>), grid, dim3(NTHREADS), 0, (hipStream_t)stream, X, Z, inv_ls,   \
-                       var, K, strideK, N, M, D, ldk, rows_pad, cols_pad, stream_out, rows_blk)
+#define TSVGP_FILL_LAUNCH(KIND_, DT_)                                                                                        \
+    do {                                                                                                                     \
+        if constexpr (sizeof(T) == 4 && DT_ <= 16) {                                                                          \
+            if (cpt4) {                                                                                                      \
+                hipLaunchKernelGGL((se_fill_kernel<T, KIND_, DT_, 4>), grid, dim3(NTHREADS), 0, (hipStream_t)stream, X, Z,   \
+                                   inv_ls, var, K, strideK, N, M, D, ldk, rows_pad, cols_pad, stream_out, rows_blk);         \
+                break;                                                                                                       \
+            }                                                                                                                \
+        }                                                                                                                    \
+        hipLaunchKernelGGL((se_fill_kernel<T, KIND_, DT_, 2>), grid, dim3(NTHREADS), 0, (hipStream_t)stream, X, Z, inv_ls,   \
+                           var, K, strideK, N, M, D, ldk, rows_pad, cols_pad, stream_out, rows_blk);                         \
+    } while (0)
 #define TSVGP_FILL_DT(KIND_)                          \
     switch (DT) {                                     \
         case 1: TSVGP_FILL_LAUNCH(KIND_, 1); break;   \
