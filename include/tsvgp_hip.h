@@ -241,6 +241,8 @@ int tsvgp_site_accum_batched_f32(const float *B, int64_t strideB, const float *g
                                  panel rows by substitution on MFMA tile registers, tsvgp_chol.hip); for A/B measurements */
 #define TSVGP_POTRF_DIAG_V2 8 /* flags: factor the diagonal blocks with the MFMA tile-dataflow kernel of tsvgp_chol.hip
                                  (experimental: measured slower than the row-per-lane kernel, profiles/r05_potrf_diag_lab.txt) */
+#define TSVGP_POTRF_FUSE 16 /* flags: the diagonal block and the panel rows below it in ONE launch (every panel workgroup factors
+                               the diagonal block for itself); experimental: measured slower than the two launches it replaces */
 int tsvgp_potrf_f64(double *A, int M, int lda, int batch, int64_t stride, int32_t *info, double *work, int flags,
                     void *stream);
 

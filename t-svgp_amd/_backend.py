@@ -33,6 +33,7 @@ POTRF_SUBST = 1  # TSVGP_POTRF_SUBST
 POTRF_RHS_UPPER = 2  # TSVGP_POTRF_RHS_UPPER
 POTRF_DIAG_V1 = 4  # TSVGP_POTRF_DIAG_V1
 POTRF_DIAG_V2 = 8  # TSVGP_POTRF_DIAG_V2
+POTRF_FUSE = 16  # TSVGP_POTRF_FUSE
 ABI_VERSION = 4  # TSVGP_ABI_VERSION of include/tsvgp_hip.h these prototypes were written for
 
 _lib = None

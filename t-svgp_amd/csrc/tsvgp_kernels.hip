@@ -3013,10 +3013,21 @@ __device__ __forceinline__ void chol_inv_offdiag(double* __restrict__ S, const d
 //   (2) all waves apply this phase's update to the next block column only (one tile each).
 // Then L_kk is written out and inv(L_kk) is assembled from the sub-block inverses by three levels of the 2x2
 // recursion (chol_inv_offdiag) and written to `work` for the panel kernel.
+// FUSED (round 5): the panel rows below the block are solved by the SAME launch.  grid = (batch, workgroups of eight 16-row
+// strips): every workgroup factors the diagonal block for itself -- redundantly: the factorisation is one workgroup's serial
+// work either way, and nothing has to cross workgroups -- and then each of its waves takes one strip through the substitution
+// of chol_panel2_kernel (tsvgp_chol.hip) with the factor-side operands read straight from the LDS image of the factor.  The
+// strip is requested at the kernel's start (its eight tiles wait in registers behind the 26 us of pivot chains) and leaves
+// through the LDS image, which is dead by then, as whole row halves.  EXPERIMENT (TSVGP_POTRF_FUSE), measured and not the
+// default: one launch fewer per block step, but the substitution fed from LDS (conditional reads of the parked inverses, no
+// operand prefetch) takes longer than the panel kernel fed from `work`: 436 against 412 us at M = 1024
+// (profiles/r05_chain_ab.txt); ~150 registers per lane.
+template <bool FUSED>
 __global__ __launch_bounds__(CH_THREADS) void potrf_diag_kernel(double* __restrict__ A, int lda, int64_t stride, int k,
                                                                 double* __restrict__ work, int* __restrict__ info,
                                                                 int need_inverse, double* __restrict__ Xout,
-                                                                double* __restrict__ Xtout, int ldx, int64_t xstride) {
+                                                                double* __restrict__ Xtout, int ldx, int64_t xstride,
+                                                                int nstrips) {
     // These few waves are the critical path of the M x M prelude while the K(X, Z) fill of the same step fills every CU
     // from a side stream: ask the SIMD arbiter to issue them first.  The fill (96 VGPRs, three waves per SIMD) leaves 224
     // registers per SIMD lane: with at most 112 VGPRs this workgroup (two waves per SIMD) is placed on a CU the fill
@@ -3031,6 +3042,20 @@ __global__ __launch_bounds__(CH_THREADS) void potrf_diag_kernel(double* __restri
     const int t = threadIdx.x, lane = t & 63, b = blockIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6);
     double* Ab = A + (size_t)b * stride + (size_t)k * CH_NB * lda + (size_t)k * CH_NB;
+    // FUSED: this wave's strip of the panel, in the MFMA accumulator layout (lane (n, G), tile s, register r <-> [n][16 s + 4 r + G])
+    const int strip = FUSED ? (int)blockIdx.y * (CH_THREADS / 64) + w : 0;
+    const bool has_strip = FUSED && strip < nstrips;
+    const bool writes_block = !FUSED || blockIdx.y == 0;
+    double* Arow0 = Ab + (size_t)(CH_NB + 16 * strip) * lda;  // (row (k + 1) * 128 + 16 strip, column k * 128)
+    v4d U[FUSED ? CH_NB / 16 : 1];
+    if constexpr (FUSED) {
+        if (has_strip) {
+#pragma unroll
+            for (int s_ = 0; s_ < CH_NB / 16; ++s_)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) U[s_][r] = Arow0[(size_t)(lane & 15) * lda + 16 * s_ + 4 * r + (lane >> 4)];
+        }
+    }
 #ifdef TSVGP_DIAG_POTRF
     unsigned long long stamp[40];
     int nstamp = 0;
@@ -3105,17 +3130,60 @@ __global__ __launch_bounds__(CH_THREADS) void potrf_diag_kernel(double* __restri
     }
 
     // L_kk out (zeros above the diagonal)
+    if (writes_block) {
 #pragma unroll 4
-    for (int it = 0; it < CH_NB * CH_NB / 2 / CH_THREADS; ++it) {
-        const int idx = t + it * CH_THREADS, r = idx >> 6, c = (idx & 63) * 2;
-        v2d v;
-        v[0] = (c <= r) ? S[r * CH_LD + c] : 0.0;
-        v[1] = (c + 1 <= r) ? S[r * CH_LD + c + 1] : 0.0;
-        *reinterpret_cast<v2d*>(Ab + (size_t)r * lda + c) = v;
+        for (int it = 0; it < CH_NB * CH_NB / 2 / CH_THREADS; ++it) {
+            const int idx = t + it * CH_THREADS, r = idx >> 6, c = (idx & 63) * 2;
+            v2d v;
+            v[0] = (c <= r) ? S[r * CH_LD + c] : 0.0;
+            v[1] = (c + 1 <= r) ? S[r * CH_LD + c + 1] : 0.0;
+            *reinterpret_cast<v2d*>(Ab + (size_t)r * lda + c) = v;
+        }
+        if (t == 0 && fail != 0 && info[b] == 0) info[b] = fail;
     }
-    if (t == 0 && fail != 0 && info[b] == 0) info[b] = fail;
     PSTAMP()
-    if (need_inverse == 2) {
+    if constexpr (FUSED) {
+        // P = A_panel inv(L_kk)^T by substitution over the 16-wide column blocks (chol_panel2_kernel's recurrence):
+        //   P_s = U_s inv(L_ss)^T,  U_s' -= P_s L_s's^T (s' > s); operands: lane (n, G), k-step kk <-> row n, column 4 kk + G of the
+        //   tile -- inv(L_ss) from the strict upper triangle + dinv (chol_xval), L_s's from the lower part of the image
+        static_assert(CH_SB == 16 && CH_NB == 128, "fused panel");
+        const int n = lane & 15, G = lane >> 4;
+        if (has_strip) {
+#pragma unroll
+            for (int s_ = 0; s_ < CH_NB / 16; ++s_) {
+                v4d ps = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+                    ps = Mfma<double>::run(chol_xval(S, dinv, 16 * s_ + n, 16 * s_ + 4 * kk + G), U[s_][kk], ps);
+#pragma unroll
+                for (int s2 = s_ + 1; s2 < CH_NB / 16; ++s2)
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk)
+                        U[s2] = Mfma<double>::run(-S[(16 * s2 + n) * CH_LD + 16 * s_ + 4 * kk + G], ps[kk], U[s2]);
+                U[s_] = ps;
+            }
+        }
+        __syncthreads();  // every wave has read its operands: the image is dead and becomes the strips' way out
+        if (has_strip) {
+            constexpr int OLD = 66;  // [16][66] per wave and 64-column half: 8-byte accesses of a half wave on 32 bank pairs
+            double* img = S + (size_t)w * 16 * OLD;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) img[n * OLD + 16 * s_ + 4 * r + G] = U[4 * h + s_][r];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const double* d = img + (2 * i + (lane >> 5)) * OLD + 2 * (lane & 31);
+                    v2d v;
+                    v[0] = d[0];
+                    v[1] = d[1];
+                    *reinterpret_cast<v2d*>(Arow0 + (size_t)(2 * i + (lane >> 5)) * lda + 64 * h + 2 * (lane & 31)) = v;
+                }
+            }
+        }
+    } else if (need_inverse == 2) {
         // round 5: no assembled inverse.  The panel kernel (tsvgp_chol.hip: chol_panel2_kernel) solves by substitution over the
         // 16-wide column blocks and wants the factor's off-diagonal tiles in MFMA register layout and the inverted diagonal
         // sub-blocks (which the factor passes left in the strict upper triangles + dinv) -- tsvgp_chol.h: the `work` image
@@ -4167,12 +4235,12 @@ int site_accum_slots() {
 int potrf(double* A, int M, int lda, int batch, int64_t stride, int* info, double* work, int flags, void* stream,
           double* X = nullptr, double* Xt = nullptr, double* T = nullptr, int rhs_rows = 0) {
     if (!A || !info || !work || M <= 0 || (M % CH_NB) || lda < M || batch <= 0 ||
-        (flags & ~(TSVGP_POTRF_SUBST | TSVGP_POTRF_RHS_UPPER | TSVGP_POTRF_DIAG_V1 | TSVGP_POTRF_DIAG_V2)) || rhs_rows < 0 || (rhs_rows % CH_NB) ||
+        (flags & ~(TSVGP_POTRF_SUBST | TSVGP_POTRF_RHS_UPPER | TSVGP_POTRF_DIAG_V1 | TSVGP_POTRF_DIAG_V2 | TSVGP_POTRF_FUSE)) || rhs_rows < 0 || (rhs_rows % CH_NB) ||
         (rhs_rows > 0 && stride < (int64_t)(M + rhs_rows) * lda))
         return TSVGP_EINVAL;
     const bool rhs_upper = (flags & TSVGP_POTRF_RHS_UPPER) != 0;
     const bool inv = X != nullptr, subst = (flags & TSVGP_POTRF_SUBST) != 0, diag_v1 = (flags & TSVGP_POTRF_DIAG_V1) != 0,
-               diag_v2 = (flags & TSVGP_POTRF_DIAG_V2) != 0;
+               diag_v2 = (flags & TSVGP_POTRF_DIAG_V2) != 0, fuse = (flags & TSVGP_POTRF_FUSE) != 0;
     if (inv && (!Xt || !T)) return TSVGP_EINVAL;
     const int nt = M / CH_NB;
 #ifdef TSVGP_DIAG_POTRF
@@ -4181,7 +4249,9 @@ int potrf(double* A, int M, int lda, int batch, int64_t stride, int* info, doubl
     const size_t smem = (size_t)CH_NB * CH_LD * sizeof(double);
 #endif
     static DynLdsOptIn optin;
-    if (optin.ensure(reinterpret_cast<const void*>(&potrf_diag_kernel), smem) != TSVGP_OK) return TSVGP_ELAUNCH;
+    if (optin.ensure(reinterpret_cast<const void*>(&potrf_diag_kernel<false>), smem) != TSVGP_OK) return TSVGP_ELAUNCH;
+    static DynLdsOptIn optin_fused;
+    if (optin_fused.ensure(reinterpret_cast<const void*>(&potrf_diag_kernel<true>), smem) != TSVGP_OK) return TSVGP_ELAUNCH;
     hipStream_t st = (hipStream_t)stream;
     const int64_t xstride = (int64_t)M * M;
     if (hipMemsetAsync(info, 0, sizeof(int) * batch, st) != hipSuccess) return TSVGP_ELAUNCH;
@@ -4205,11 +4275,17 @@ int potrf(double* A, int M, int lda, int batch, int64_t stride, int* info, doubl
         // (round 4's step, and tsvgp_potrf_inv_f64), or the `work` image of chol_panel2_kernel (round 5)
         const bool panel2 = !inv && !diag_v1 && !subst;
         const int need_inverse = inv ? 1 : ((below > 0 || ext_rows > 0) && !subst) ? (panel2 ? 2 : 1) : 0;
+        const int nstrips = (below * CH_NB + ext_rows) / 16;
+        const bool fused = panel2 && !diag_v2 && fuse && nstrips > 0;  // (measured slower than two launches: tsvgp_hip.h)
         if (panel2 && diag_v2) {  // the diagonal block as an MFMA tile dataflow (tsvgp_chol.hip; experimental)
             if (tsvgp_chol::launch_diag2(A, lda, stride, k, work, info, need_inverse, batch, st) != hipSuccess) return TSVGP_ELAUNCH;
+        } else if (fused) {  // diagonal block AND the panel rows below it in one launch
+            const int per = CH_THREADS / 64;
+            hipLaunchKernelGGL(potrf_diag_kernel<true>, dim3(batch, (nstrips + per - 1) / per), dim3(CH_THREADS), smem, st, A, lda, stride,
+                               k, work, info, 2, X, Xt, M, xstride, nstrips);
         } else {
-            hipLaunchKernelGGL(potrf_diag_kernel, dim3(batch), dim3(CH_THREADS), smem, st, A, lda, stride, k, work, info,
-                               need_inverse, X, Xt, M, xstride);
+            hipLaunchKernelGGL(potrf_diag_kernel<false>, dim3(batch), dim3(CH_THREADS), smem, st, A, lda, stride, k, work, info,
+                               need_inverse, X, Xt, M, xstride, 0);
         }
         if (below > 0 || ext_rows > 0) {
             // the panel: the matrix rows below the diagonal block and, contiguous with them (row M on), the right-hand-side rows
@@ -4218,7 +4294,9 @@ int potrf(double* A, int M, int lda, int batch, int64_t stride, int* info, doubl
             if (subst)
                 hipLaunchKernelGGL(chol_panel_subst_kernel, dim3((below * CH_NB + ext_rows) / PS_ROWS, batch), dim3(NTHREADS), 0,
                                    st, A, lda, stride, k);
-            else if (panel2) {  // substitution on tile registers against the diagonal kernel's `work` image
+            else if (fused) {
+                // (done by the diagonal block's launch)
+            } else if (panel2) {  // substitution on tile registers against the diagonal kernel's `work` image
                 if (tsvgp_chol::launch_panel2(A, lda, stride, k, work, (below * CH_NB + ext_rows) / 16, batch, st) != hipSuccess)
                     return TSVGP_ELAUNCH;
             } else

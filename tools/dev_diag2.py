@@ -26,7 +26,7 @@ for M in Ms:
         A = A @ A.transpose(-1, -2) / M + torch.eye(M, dtype=torch.float64, device=dev)
         ref = torch.linalg.cholesky(A)
         out = {}
-        for name, fl in (("new", 0), ("old", B.POTRF_DIAG_V1), ("dv2", B.POTRF_DIAG_V2)):
+        for name, fl in (("new", 0), ("fused", B.POTRF_FUSE), ("old", B.POTRF_DIAG_V1), ("dv2", B.POTRF_DIAG_V2)):
             eng.potrf_flags = fl
             L, info = eng.cholesky(A)
             err = ((L - ref).abs().max() / ref.abs().max()).item()
