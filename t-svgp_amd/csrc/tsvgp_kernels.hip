@@ -30,6 +30,7 @@
 #include <atomic>
 #include <type_traits>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "tsvgp_hip.h"
 #include "tsvgp_chol.h"
@@ -294,6 +295,10 @@ __device__ __forceinline__ void lik_eval(int lik_flags, double s2, double m, dou
 // grid = (row blocks of FILL_ROWS, column tiles of FILL_COLS); each thread owns two adjacent columns.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int FILL_ROWS = 64;
+#ifndef TSVGP_FILL_ROWS_DEFAULT
+#define TSVGP_FILL_ROWS_DEFAULT 64
+#endif
+constexpr int FILL_ROWS_DEFAULT = TSVGP_FILL_ROWS_DEFAULT;
 constexpr int FILL_COLS = 512;
 
 // exp(a) for a <= 0 (every kernel profile below).  fp64: the device library's algorithm restated -- k = rint(a log2 e),
@@ -310,7 +315,7 @@ __device__ __forceinline__ T exp_nonpos(T a) {
 // fp32: the hardware exponential, v_exp_f32(a log2 e) -- two instructions where the library's range-reduced expf takes thirteen
 // (a quarter-rate v_exp_f32 among them either way): with the packed distance loop the exponentials were half of the fp32 fill's
 // issue time.  Relative error ~|a| 2^-24 (the product a log2 e is rounded once), i.e. <= 1e-5 for kernel values down to 1e-30 and
-// far inside the fp32 path's stated tolerance against the fp64 oracle (atol 1e-4 + rtol 1e-3); results below the
+// far inside the fp32 path's stated tolerance against the fp64 reference values (atol 1e-4 + rtol 1e-3); results below the
 // normal range flush to zero.
 template <>
 __device__ __forceinline__ float exp_nonpos<float>(float a) {
@@ -3938,7 +3943,13 @@ int kernel_fill(int kind, const T* X, const T* Z, const T* inv_ls, const T* vari
     if (D > 32) return TSVGP_EINVAL;  // input dimensions are padded to a compile-time size (1, 2, 4, 8, 16, 32)
     FillBatch<T> var{};
     for (int q = 0; q < P; ++q) var.v[q] = variance[q];
-    const int rows_blk = rows_pad <= 4096 ? 8 : FILL_ROWS;  // (rows_pad is a multiple of 128: both divide it)
+    // (rows_pad is a multiple of 128: every power of two up to FILL_ROWS divides it)
+    static const int rows_big = [] {
+        const char* e = getenv("TSVGP_FILL_ROWS_BLK");  // experiment knob: rows per workgroup of the N-sized fill (8, 16, 32, 64)
+        const int v = e ? atoi(e) : 0;
+        return (v == 8 || v == 16 || v == 32 || v == 64) ? v : FILL_ROWS_DEFAULT;
+    }();
+    const int rows_blk = rows_pad <= 4096 ? 8 : rows_big;
     // fp32: four columns per thread (16-byte stores) where the layout allows it, else two
     const int DT = D <= 1 ? 1 : D <= 2 ? 2 : D <= 4 ? 4 : D <= 8 ? 8 : D <= 16 ? 16 : 32;
     const bool cpt4 = sizeof(T) == 4 && DT <= 16 && (ldk % 4) == 0 && (strideK % 4) == 0 &&

@@ -590,3 +590,53 @@ def test_fill_large_input_dimension(engines, dtype, tol, kind, name, N, M, D):
     ref = getattr(O, name)(variance=1.3, lengthscales=ls).K(X, Z)
     assert relerr(K[:N, :M], ref) < (tol * 10 if dtype == torch.float64 else 2e-4)
     assert np.all(K[N:, :] == 0) and np.all(K[:, M:] == 0)
+
+
+@pytest.mark.parametrize("variant", ["default", "DIAG_V1", "DIAG_V2", "FUSE"])
+@pytest.mark.parametrize("M,batch", [(128, 1), (256, 2), (384, 3), (1024, 1)])
+def test_potrf_block_step_variants(engines, variant, M, batch):
+    """Round 5: the block step of tsvgp_potrf_f64 / tsvgp_potrf_solve_f64 in its four forms -- the default (inverted 16 x 16
+    diagonal tiles + substitution panels on MFMA tile registers, tsvgp_chol.hip), round 4's (TSVGP_POTRF_DIAG_V1: assembled
+    128 x 128 inverse + product panels; what a call beside a long fill takes), the tile-dataflow diagonal kernel
+    (TSVGP_POTRF_DIAG_V2) and the fused diagonal + panel launch (TSVGP_POTRF_FUSE) -- against NumPy: factor, solve and
+    the LAPACK index of the first non-positive pivot (reference src/util.py:376-389, src/models/tsvgp.py:270, :300)."""
+    eng = engines[torch.float64]
+    B = pkg()._backend
+    saved = eng.potrf_flags
+    eng.potrf_flags = {"default": 0, "DIAG_V1": B.POTRF_DIAG_V1, "DIAG_V2": B.POTRF_DIAG_V2, "FUSE": B.POTRF_FUSE}[variant]
+    try:
+        rng = np.random.RandomState(11 + M)
+        A = rng.randn(batch, M, M)
+        A = A @ np.swapaxes(A, -1, -2) / M + np.eye(M)
+        Ad = torch.as_tensor(A, device="cuda:0")
+        L, info = eng.cholesky(Ad)
+        assert int(info.abs().sum()) == 0
+        assert relerr(L.cpu().numpy(), np.linalg.cholesky(A)) < 1e-13
+        Lr = np.tril(rng.randn(batch, M, M)) / np.sqrt(M)
+        U, info, Dm = eng.cholesky_solve_upper(Ad, torch.as_tensor(Lr, device="cuda:0"))
+        assert int(info.abs().sum()) == 0
+        Un = U.cpu().numpy()
+        assert relerr(Un @ np.swapaxes(Un, -1, -2), A) < 1e-13
+        assert relerr(Dm.cpu().numpy(), np.linalg.solve(Un, np.swapaxes(Lr, -1, -2))) < 1e-11
+        for c in sorted({1, 17, min(70, M), M - 5}):  # first non-positive pivot at column c (1-based, LAPACK's info)
+            bad = np.tile(2.0 * np.eye(M), (batch, 1, 1))
+            bad[0, c - 1, c - 1] = -1.0
+            _, info = eng.cholesky(torch.as_tensor(bad, device="cuda:0"))
+            assert int(info[0]) == c and int(info[1:].abs().sum()) == 0
+    finally:
+        eng.potrf_flags = saved
+
+
+@pytest.mark.parametrize("M,P,shared", [(64, 1, True), (200, 3, True), (1024, 2, False)])
+def test_gemv_rows(engines, M, P, shared):
+    """tsvgp_gemv_f64 (``EStepEngine.gemv``): y[:, p] = A_p v[:, p], one matrix for every latent or one per latent -- the
+    matrix-vector products of the replicated chain ((K_uu + 1e-6 I) lambda_1, K_uu beta: reference src/util.py:176-179,
+    src/models/tsvgp.py:249-254) -- against NumPy, odd M included (the scalar path)."""
+    eng = engines[torch.float64]
+    rng = np.random.RandomState(3 + M)
+    for Mx in (M, M + 1):
+        A = rng.randn(Mx, Mx) if shared else rng.randn(P, Mx, Mx)
+        v = rng.randn(Mx, P)
+        y = eng.gemv(torch.as_tensor(A, device="cuda:0"), torch.as_tensor(v, device="cuda:0")).cpu().numpy()
+        ref = A @ v if shared else np.einsum("pmk,kp->mp", A, v)
+        assert relerr(y, ref) < 1e-13

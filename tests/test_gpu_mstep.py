@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from oracle import tsvgp_oracle as O
-from tests.helpers import pkg, synthetic
+from tests.helpers import pkg, relerr, synthetic
 
 pytestmark = pytest.mark.gpu
 
@@ -260,3 +260,25 @@ def test_elbo_gradients_large_input_dimension(kname, lik):
     if lik == "gaussian":
         ref = (f(noise=noise + h) - f(noise=noise - h)) / (2 * h)
         assert abs(float(grads["likelihood_variance"]) - ref) < 2e-6 * max(abs(ref), scale)
+
+
+def test_gradient_pass_on_the_stored_tile_equals_the_fused_pass(monkeypatch):
+    """Round 5: with one latent ``elbo_and_grads`` keeps the moments' triangular product (``EStepEngine.run(keep_tile=True)``:
+    tsvgp_trmm, mean by a matrix-vector product, var by a row norm, tsvgp_lik_map) and takes Q k_n as a second triangular
+    product of it; TSVGP_MSTEP_TILE=0 is round 3's pass (fused moments kernel + dense GEMM with Q).  Same ELBO and gradients,
+    Gaussian and Bernoulli, fp64 to 1e-10 (reference experiments/uci_regression.py:159-160: what the M-step differentiates)."""
+    p = pkg()
+    for lik in ("gaussian", "bernoulli"):
+        X, Y, Z = synthetic(N=1500, M=96, D=3, lik=lik, seed=4)
+        Xd, Yd = torch.as_tensor(X, device="cuda:0"), torch.as_tensor(Y, device="cuda:0")
+        out = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("TSVGP_MSTEP_TILE", mode)
+            m = p.t_SVGP(p.SquaredExponential(1.3, 0.9), p.Gaussian(0.2) if lik == "gaussian" else p.Bernoulli(), Z, num_data=1500)
+            for _ in range(3):
+                m.natgrad_step((Xd, Yd), lr=0.7)
+            e, g = m.elbo_and_grads((Xd, Yd))
+            out[mode] = (float(e), {k: v.cpu().numpy() for k, v in g.items()})
+        assert abs(out["1"][0] - out["0"][0]) < 1e-10 * abs(out["0"][0])
+        for k in out["0"][1]:
+            assert relerr(out["1"][1][k], out["0"][1][k]) < 1e-9, (lik, k)
