@@ -86,16 +86,55 @@ __device__ __forceinline__ v4d tile_identity(int n, int G) {
     for (int r = 0; r < 4; ++r) t[r] = (n == 4 * r + G) ? 1.0 : 0.0;
     return t;
 }
-// tile (i, j), i >= j, of the symmetric block whose lower triangle is stored at Ab (a diagonal tile is mirrored)
-__device__ __forceinline__ v4d tile_load_global(const double* __restrict__ Ab, int lda, int i, int j, int n, int G) {
-    v4d t;
+// Global traffic of a tile goes as whole rows -- lane l moves the two doubles (row l / 8 + 8 h, columns 2 (l % 8), + 1), 16 bytes,
+// eight 128-byte row segments per wave instruction -- and changes layout in LDS.  In the register layout itself (lane (n, G): 16
+// rows x 32 bytes per 8-byte instruction) a tile's four loads or stores took ~160-240 cycles EACH to issue and queued on the
+// CU's one address path: 10 us of staging and ~1 us per block column in front of the pivot wave (tools/diag2_lab.hip).
+typedef double v2d_ __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int tile_word(int row, int c) { return (c >> 2) * 64 + row + 16 * (c & 3); }  // [n][c] in the image
+// tile (i, j), i >= j, of the block whose lower triangle is stored at Ab -> LDS image tp; a diagonal tile is mirrored
+__device__ __forceinline__ void tile_g2l(double* __restrict__ tp, const double* __restrict__ Ab, int lda, int i, int j, int lane) {
+    v2d_ v[2];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int row = 16 * i + n, col = 16 * j + 4 * r + G;
-        const int hi = row > col ? row : col, lo = row > col ? col : row;
-        t[r] = Ab[(size_t)hi * lda + lo];
+    for (int h = 0; h < 2; ++h)
+        v[h] = *reinterpret_cast<const v2d_*>(Ab + (size_t)(16 * i + (lane >> 3) + 8 * h) * lda + 16 * j + 2 * (lane & 7));
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int row = (lane >> 3) + 8 * h, c = 2 * (lane & 7);
+        if (i != j) {
+            tp[tile_word(row, c)] = v[h][0];
+            tp[tile_word(row, c + 1)] = v[h][1];
+        } else {  // stored: c <= row; the image is the full symmetric tile
+            if (c <= row) {
+                tp[tile_word(row, c)] = v[h][0];
+                tp[tile_word(c, row)] = v[h][0];
+            }
+            if (c + 1 <= row) {
+                tp[tile_word(row, c + 1)] = v[h][1];
+                tp[tile_word(c + 1, row)] = v[h][1];
+            }
+        }
     }
-    return t;
+}
+// LDS image tp -> tile (i, j) of the matrix at Ab; a diagonal tile goes out with zeros above its diagonal
+__device__ __forceinline__ void tile_l2g(const double* __restrict__ tp, double* __restrict__ Ab, int lda, int i, int j, int lane) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int row = (lane >> 3) + 8 * h, c = 2 * (lane & 7);
+        v2d_ v;
+        v[0] = tp[tile_word(row, c)];
+        v[1] = tp[tile_word(row, c + 1)];
+        if (i == j) {
+            v[0] = (c <= row) ? v[0] : 0.0;
+            v[1] = (c + 1 <= row) ? v[1] : 0.0;
+        }
+        *reinterpret_cast<v2d_*>(Ab + (size_t)(16 * i + row) * lda + 16 * j + c) = v;
+    }
+}
+__device__ __forceinline__ void tile_zero_global(double* __restrict__ Ab, int lda, int i, int j, int lane) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+        *reinterpret_cast<v2d_*>(Ab + (size_t)(16 * i + (lane >> 3) + 8 * h) * lda + 16 * j + 2 * (lane & 7)) = v2d_{0.0, 0.0};
 }
 
 #ifdef TSVGP_DIAG_D2  // tools/diag2_lab.hip: s_memtime stamps of the pivot wave, 16 per block column + 8
@@ -115,21 +154,20 @@ __device__ __forceinline__ double row_shr(double v) {
     return __hiloint2double(hi, lo);
 }
 
-// the entry (max(n, G), min(n, G)) of a symmetric 4 x 4 matrix for the lanes n < 4 (sel = 4 max + min), 0 elsewhere (sel < 0)
+// the entry (max(n, G), min(n, G)) of a symmetric 4 x 4 matrix for the lanes n < 4 (sel = 4 max + min), 0 elsewhere (sel < 0).
+// A TREE of selects (depth 4) on the two index bits of each coordinate: as a chain of ten dependent v_cndmask pairs it was
+// ~160 cycles of the pivot wave's critical path, twice per pivot group.
 __device__ __forceinline__ double sel_sym(int sel, double v00, double v10, double v11, double v20, double v21, double v22,
                                           double v30, double v31, double v32, double v33) {
-    double a = 0.0;
-    a = sel == 0 ? v00 : a;
-    a = sel == 4 ? v10 : a;
-    a = sel == 5 ? v11 : a;
-    a = sel == 8 ? v20 : a;
-    a = sel == 9 ? v21 : a;
-    a = sel == 10 ? v22 : a;
-    a = sel == 12 ? v30 : a;
-    a = sel == 13 ? v31 : a;
-    a = sel == 14 ? v32 : a;
-    a = sel == 15 ? v33 : a;
-    return a;
+    const int hi = sel >> 2, lo = sel & 3;  // hi = max, lo = min (sel >= 0)
+    const bool l1 = lo & 1, l2 = lo & 2;
+    // row `hi` of the lower triangle, indexed by lo (entries beyond the diagonal are never selected: lo <= hi)
+    const double r0 = v00;
+    const double r1 = l1 ? v11 : v10;
+    const double r2 = l2 ? v22 : (l1 ? v21 : v20);
+    const double r3 = l2 ? (l1 ? v33 : v32) : (l1 ? v31 : v30);
+    const double a = (hi & 2) ? ((hi & 1) ? r3 : r2) : ((hi & 1) ? r1 : r0);
+    return sel < 0 ? 0.0 : a;
 }
 
 // A tile of the column through pivot group Q: T' = [T with register Q zeroed] + mfma(aop, T[Q]) -- rows of aop above the
@@ -184,6 +222,10 @@ __device__ __forceinline__ double pivot_chain(const v4d& D, int n, int sel_s, bo
     return aop;
 }
 
+// Workgroup barrier for LDS traffic only: __syncthreads() also waits for the wave's outstanding GLOBAL stores (vmcnt(0)), and the
+// finished tiles leave for global memory right in front of the barriers -- every barrier then sat out a store round trip (1-2 us).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 struct Helper {  // what a helper wave keeps in registers: its tile row and the look-ahead sum of the next column's tile
     v4d t, la;
     int row;      // 1 .. 7
@@ -202,6 +244,21 @@ __device__ __forceinline__ bool job_decode(int p, int g, int& d, int& u) {
     return p + d < NTC;
 }
 
+// Trailing job g of column p (p >= 0): the rank-16 update of tile (j, u) -- column j slot u pairs with column p slot u + d, the A
+// operand is column p slot d.
+__device__ __forceinline__ void helper_job(double* __restrict__ S, int p, int g, int lane) {
+    int d, u;
+    if (p >= 0 && job_decode(p, g, d, u)) {
+        double* tp = tile_ptr(S, p + d, u);
+        const v4d a = tile_read(tile_ptr(S, p, d), lane);
+        const v4d bq = tile_read(tile_ptr(S, p, u + d), lane);
+        v4d c = tile_read(tp, lane);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) c = mfma(-a[kk], bq[kk], c);
+        tile_write(tp, lane, c);
+    }
+}
+
 // What the helper waves do behind barrier G(s, Q): the group's step on their own tile (A operand from the pivot wave through
 // LDS), register Q of the tile published at once (it is final), the look-ahead product of the register finished one group
 // ago (A operand: the same register of row s + 1's tile, published by its owner one barrier ago), and ONE job.
@@ -216,37 +273,13 @@ __device__ __forceinline__ void helper_group(Helper& h, double* __restrict__ S, 
         }
         tile_step<Q>(h.t, aop);
         tile_ptr(S, s, h.row - s)[Q * 64 + lane] = h.t[Q];
-        if constexpr (Q == 3) {  // tile (row, s) of L is final: to the matrix, and in register layout to the panel kernel
-            double* wt = Wb + (size_t)tile_index(s, h.row - s) * 256;
+        if constexpr (Q == 3) {  // tile (row, s) of L is final: in register layout to the panel kernel (512 contiguous bytes per
+            double* wt = Wb + (size_t)tile_index(s, h.row - s) * 256;  // register; the matrix gets it behind barrier E)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                Ab[(size_t)(16 * h.row + n) * lda + 16 * s + 4 * r + G] = h.t[r];
-                wt[r * 64 + lane] = h.t[r];
-            }
+            for (int r = 0; r < 4; ++r) wt[r * 64 + lane] = h.t[r];
         }
     }
-    const int p = s - 1, g = (w - 1) + 7 * Q;
-    int d, u;
-    if (job_decode(p, g, d, u)) {
-        const int j = p + d;
-        double* tp = tile_ptr(S, j, u);
-        if (p < 0) {
-            // staging (column 0's phase): tile (j + u, j) from global memory; its mirror above the diagonal is zeroed
-            tile_write(tp, lane, tile_load_global(Ab, lda, j + u, j, n, G));
-            if (u > 0) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) Ab[(size_t)(16 * j + n) * lda + 16 * (j + u) + 4 * r + G] = 0.0;
-            }
-        } else {
-            // rank-16 update of column p: column j slot u pairs with column p slot u + d, the A operand is column p slot d
-            const v4d a = tile_read(tile_ptr(S, p, d), lane);
-            const v4d bq = tile_read(tile_ptr(S, p, u + d), lane);
-            v4d c = tile_read(tp, lane);
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) c = mfma(-a[kk], bq[kk], c);
-            tile_write(tp, lane, c);
-        }
-    }
+    if constexpr (Q < 3) helper_job(S, s - 1, (w - 1) + 7 * Q, lane);  // (the fourth job of a phase runs behind barrier E)
 }
 
 __global__ __launch_bounds__(D2_THREADS) void potrf_diag2_kernel(double* __restrict__ A, int lda, int64_t stride, int k,
@@ -267,30 +300,42 @@ __global__ __launch_bounds__(D2_THREADS) void potrf_diag2_kernel(double* __restr
     int bad = 0;
     if (w == 0) {
         __builtin_amdgcn_s_setprio(3);
-        D = tile_load_global(Ab, lda, 0, 0, n, G);
+        tile_g2l(tile_ptr(S, 0, 0), Ab, lda, 0, 0, lane);  // (this wave's own LDS words: no barrier in between)
+        D = tile_read(tile_ptr(S, 0, 0), lane);
     } else {
         __builtin_amdgcn_s_setprio(2);
         h.row = w;
         h.active = true;
-        h.t = tile_load_global(Ab, lda, w, 0, n, G);
         h.la = v4d{0.0, 0.0, 0.0, 0.0};
+        // staging: the wave's own tile (w, 0), and four of the 28 tiles of the columns >= 1 (job list of p = -1) with zeros to
+        // their mirrors above the diagonal of the block -- everything requested before anything is waited for
+        tile_g2l(tile_ptr(S, 0, w), Ab, lda, w, 0, lane);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Ab[(size_t)n * lda + 16 * w + 4 * r + G] = 0.0;  // tile (0, w), above the diagonal
+        for (int q = 0; q < 4; ++q) {
+            int d, u;
+            if (job_decode(-1, (w - 1) + 7 * q, d, u)) {
+                const int j = d - 1;
+                tile_g2l(tile_ptr(S, j, u), Ab, lda, j + u, j, lane);
+                if (u > 0) tile_zero_global(Ab, lda, j, j + u, lane);
+            }
+        }
+        tile_zero_global(Ab, lda, 0, w, lane);
+        h.t = tile_read(tile_ptr(S, 0, w), lane);
     }
     for (int s = 0; s < NTC; ++s) {
         D2_STAMP(8 + 16 * s + 0)
-        if (w == 0) X = tile_identity(n, G);
+        if (w == NTC - 1) X = tile_identity(n, G);  // (the inverse tile rides in wave 7: one MFMA per group off the pivot wave)
 #define D2_GROUP(Q)                                                               \
         if (w == 0) {                                                             \
             int fb;                                                               \
             const double aop = pivot_chain<Q>(D, n, sel_s, lower, fb);            \
             aopbuf[Q * 64 + lane] = aop;                                          \
             tile_step<Q>(D, aop);                                                 \
-            tile_step<Q>(X, aop);                                                 \
             if (bad == 0 && fb != 0) bad = 16 * s + 4 * Q + fb;                   \
         }                                                                         \
-        __syncthreads(); /* G(s, Q) */                                            \
+        lds_barrier(); /* G(s, Q) */                                                \
         if (w != 0) helper_group<Q>(h, S, aopbuf, Ab, lda, Wb, s, w, lane, n, G); \
+        if (w == NTC - 1) tile_step<Q>(X, aopbuf[Q * 64 + lane]);                 \
         D2_STAMP(8 + 16 * s + 1 + Q)
         D2_GROUP(0)
         D2_GROUP(1)
@@ -298,13 +343,7 @@ __global__ __launch_bounds__(D2_THREADS) void potrf_diag2_kernel(double* __restr
         D2_GROUP(3)
 #undef D2_GROUP
         if (w == 0) {
-            // L_ss (zeros above its diagonal) to the matrix; X[n][c] = inv(L_ss)[c][n] row-major to the panel kernel
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int c = 4 * r + G;
-                Ab[(size_t)(16 * s + n) * lda + 16 * s + c] = (c <= n) ? D[r] : 0.0;
-                if (need_inverse) Wb[(size_t)NTILES * 256 + s * 256 + c * 16 + n] = X[r];
-            }
+            tile_write(tile_ptr(S, s, 0), lane, D);  // L_ss: a helper takes it to the matrix behind the barrier
         } else if (s + 1 < NTC && h.active && h.row == s + 1) {
             // the owner of row s + 1 finishes the diagonal tile of the next column from its own registers and hands it over
             h.la = mfma(-h.t[3], h.t[3], h.la);
@@ -312,9 +351,19 @@ __global__ __launch_bounds__(D2_THREADS) void potrf_diag2_kernel(double* __restr
             tile_write(dp, lane, tile_read(dp, lane) + h.la);
             h.active = false;
         }
+        if (w == NTC - 1 && need_inverse) {  // X[n][c] = inv(L_ss)[c][n] row-major to the panel kernel
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Wb[(size_t)NTILES * 256 + s * 256 + (4 * r + G) * 16 + n] = X[r];
+        }
         D2_STAMP(8 + 16 * s + 5)
-        __syncthreads();  // E(s)
+        lds_barrier();  // E(s)
         D2_STAMP(8 + 16 * s + 6)
+        if (w != 0) {
+            // column s is complete in LDS: its tiles go to the matrix, one per helper (tile (s + u, s) by wave 1 + u % 7), and the
+            // phase's fourth trailing job runs -- both in the shadow of the next column's first pivot chain
+            for (int u = w - 1; u < NTC - s; u += NTC - 1) tile_l2g(tile_ptr(S, s, u), Ab, lda, s + u, s, lane);
+            helper_job(S, s - 1, (w - 1) + 7 * 3, lane);
+        }
         if (s + 1 < NTC) {
             if (w == 0) {
                 D = tile_read(tile_ptr(S, s + 1, 0), lane);

@@ -120,6 +120,20 @@ def trailing_jobs(p):
     return [(j, u) for j in range(p + 2, NT) for u in range(0, NT - j)]
 
 
+def run_job(lds, w, p, jobs, g):
+    """Trailing job g of column p by wave w: tile (j, u) -= sum_kk P_jp[kk] (x) P_(j+u)p[kk] (read-modify-write in LDS)."""
+    if p < 0 or g >= len(jobs):
+        return
+    j, u = jobs[g]
+    av = [lds.read(w, ("col", p, j - p, kk)) for kk in range(4)]
+    bv = [lds.read(w, ("col", p, u + (j - p), kk)) for kk in range(4)]
+    c = np.array([lds.read(w, ("col", j, u, r)) for r in range(4)])
+    for kk in range(4):
+        c = mfma(-av[kk], bv[kk], c)
+    for r in range(4):
+        lds.write(w, ("col", j, u, r), c[r])
+
+
 def factor(Ablk):
     """Tile dataflow of potrf_diag2_kernel.  Returns (L, [X_ss]): the factor and the inverses of its 16 x 16 diagonal tiles."""
     full = np.tril(Ablk) + np.tril(Ablk, -1).T
@@ -134,9 +148,14 @@ def factor(Ablk):
     tiles = {w: [] for w in range(1, NW)}
     for i in range(1, NT):
         tiles[row_owner(i)].append(dict(row=i, t=gA(i, 0), la=np.zeros((4, 64))))
+    # staging, before the first barrier: every tile of the columns >= 1 from global memory, four per helper (the jobs of p = -1)
+    for g, (j, u) in enumerate(trailing_jobs(-1)):
+        c = gA(j + u, j)
+        for r in range(4):
+            lds.write(1 + g % 7, ("col", j, u, r), c[r])
     for s in range(NT):
-        jobs = trailing_jobs(s - 1)
-        X = ident.copy()
+        jobs = trailing_jobs(s - 1) if s >= 1 else []
+        X = ident.copy()  # (rides in wave 7)
         for q in range(4):
             # ---- pivot wave: chain, W, aop, broadcast, own step, the inverse tile's step
             shifted, pinv_op = pivot_chain(D[q], q)
@@ -147,8 +166,8 @@ def factor(Ablk):
                 aop = shifted
             lds.write(0, ("aop", q), aop)
             D = tile_step(D, q, aop)
-            X = tile_step(X, q, aop)
             lds.barrier()  # G(s, q)
+            X = tile_step(X, q, lds.read(NW - 1, ("aop", q)))
             # ---- helpers
             for w in range(1, NW):
                 a = lds.read(w, ("aop", q))
@@ -161,20 +180,8 @@ def factor(Ablk):
                     lds.write(w, ("col", s, u, q), tl["t"][q])
                     if q == 3:
                         Lout[(tl["row"], s)] = tl["t"].copy()
-                g = (w - 1) + 7 * q  # one job per chunk
-                if g < len(jobs):
-                    p = s - 1
-                    j, u = jobs[g]
-                    if p < 0:  # staging: global -> LDS
-                        c = gA(j + u, j)
-                    else:
-                        av = [lds.read(w, ("col", p, j - p, kk)) for kk in range(4)]
-                        bv = [lds.read(w, ("col", p, u + (j - p), kk)) for kk in range(4)]
-                        c = np.array([lds.read(w, ("col", j, u, r)) for r in range(4)])
-                        for kk in range(4):
-                            c = mfma(-av[kk], bv[kk], c)
-                    for r in range(4):
-                        lds.write(w, ("col", j, u, r), c[r])
+                if q < 3:  # one trailing job per barrier interval; the phase's fourth job runs behind barrier E (below)
+                    run_job(lds, w, s - 1, jobs, (w - 1) + 7 * q)
         assert len(jobs) <= 28
         Lout[(s, s)] = D.copy()
         Xout.append(X.copy())
@@ -185,7 +192,11 @@ def factor(Ablk):
             nd = np.array([lds.read(w1, ("col", s + 1, 0, r)) for r in range(4)]) + tl["la"]
             for r in range(4):
                 lds.write(w1, ("col", s + 1, 0, r), nd[r])
+        for r in range(4):
+            lds.write(0, ("col", s, 0, r), D[r])  # L_ss: a helper takes it to the matrix behind the barrier
         lds.barrier()  # E(s)
+        for w in range(1, NW):
+            run_job(lds, w, s - 1, jobs, (w - 1) + 7 * 3)
         if s + 1 < NT:
             D = np.array([lds.read(0, ("col", s + 1, 0, r)) for r in range(4)])
             for w in range(1, NW):
