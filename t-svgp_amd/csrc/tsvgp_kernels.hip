@@ -3309,9 +3309,14 @@ __global__ __launch_bounds__(NTHREADS) void chol_tile_kernel(double* __restrict_
                 for (int n = 0; n < 2; ++n) acc[s][n][r] = Cb[(size_t)(16 * s + g + 4 * r) * lda + 16 * n];
     }
     if (active) {
-        const double* Arow = Ab + (size_t)(base + CH_WT * ti + li) * lda + (size_t)k * CH_NB + 16 * g;
-        const double* Brow = (OP == 0) ? work + (size_t)b * CH_NB * CH_NB + (size_t)(CH_WT * tj + li) * CH_NB + 16 * g
-                                       : Ab + (size_t)(base + CH_WT * tj + li) * lda + (size_t)k * CH_NB + 16 * g;
+        // Round 5: which k a lane group supplies to which MFMA step is free (both operands use the same map), and the map decides
+        // what one load instruction touches.  Lane (i, g) used to stream the contiguous run [64 h + 16 g, + 16) of its row: 64
+        // separate 16-byte pieces per instruction.  Now the four lanes of a row take ADJACENT pairs -- load q covers k in
+        // [64 h + 8 q, + 8) of 16 rows, 64 contiguous bytes each -- a quarter of the segments (scattered accesses queue on the
+        // CU's one address path at ~200 cycles each, profiles/r05_potrf_diag_lab.txt).
+        const double* Arow = Ab + (size_t)(base + CH_WT * ti + li) * lda + (size_t)k * CH_NB + 2 * g;
+        const double* Brow = (OP == 0) ? work + (size_t)b * CH_NB * CH_NB + (size_t)(CH_WT * tj + li) * CH_NB + 2 * g
+                                       : Ab + (size_t)(base + CH_WT * tj + li) * lda + (size_t)k * CH_NB + 2 * g;
         const size_t bstep = (OP == 0) ? (size_t)16 * CH_NB : (size_t)16 * lda;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -3320,8 +3325,8 @@ __global__ __launch_bounds__(NTHREADS) void chol_tile_kernel(double* __restrict_
             for (int s = 0; s < 2; ++s)
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
-                    ra[s][q] = *reinterpret_cast<const v2d*>(Arow + (size_t)16 * s * lda + 64 * h + 2 * q);
-                    rb[s][q] = *reinterpret_cast<const v2d*>(Brow + s * bstep + 64 * h + 2 * q);
+                    ra[s][q] = *reinterpret_cast<const v2d*>(Arow + (size_t)16 * s * lda + 64 * h + 8 * q);
+                    rb[s][q] = *reinterpret_cast<const v2d*>(Brow + s * bstep + 64 * h + 8 * q);
                 }
 #pragma unroll
             for (int kk = 0; kk < 16; ++kk)
