@@ -80,6 +80,32 @@ def rev_cholesky(a: torch.Tensor, infos: list, potrf=None, inverse: bool = False
     return torch.flip(res, (-2, -1))
 
 
+def _cond2_engine(A: torch.Tensor, eng, iters: int, v0: torch.Tensor) -> torch.Tensor:
+    """``cond2_estimate`` of ONE matrix through the engine's own kernels: the upper-form factorisation with the identity
+    riding along (``EStepEngine.cholesky_solve_upper``: A = U U^T and D = U^-1 in one pass, so A^-1 = D^T D) and row GEMVs
+    (``EStepEngine.gemv``, ~5 us each at M = 1024 instead of a rocBLAS call plus a norm and a division per product).  The
+    iterates are normalised every fourth step only: the growth per step is at most lambda_max (resp. 1 / lambda_min
+    <= 1 / jitter), far inside fp64's range over four steps."""
+    M = A.shape[-1]
+    Id = torch.eye(M, dtype=torch.float64, device=A.device)
+    _, info, D = eng.cholesky_solve_upper(A[None], Id[None])
+    D = D[0]
+    Dt = D.transpose(0, 1).contiguous()
+    v, w = v0.clone(), v0.clone()
+    for it in range(iters):
+        v = eng.gemv(A, v)
+        w = eng.gemv(Dt, eng.gemv(D, w))
+        if it % 4 == 3 or it == iters - 1:
+            v = v / torch.linalg.vector_norm(v, dim=0, keepdim=True)
+            w = w / torch.linalg.vector_norm(w, dim=0, keepdim=True)
+    lam_max = torch.sum(v * eng.gemv(A, v), dim=0).amax()
+    Dw = eng.gemv(D, w)
+    inv_min = torch.sum(Dw * Dw, dim=0).amax()
+    cond = (lam_max * inv_min).reshape(1)
+    bad = (info.reshape(-1)[:1] != 0) | ~torch.isfinite(cond)
+    return torch.where(bad, torch.full_like(cond, float("inf")), cond)
+
+
 def cond2_estimate(A: torch.Tensor, potrf=None, iters: int = 32) -> torch.Tensor:
     """Estimate of the 2-norm condition number of the symmetric positive definite A [..., M, M] (one value per matrix,
     device tensor, no host synchronisation): lambda_max by power iteration on A, 1 / lambda_min by power iteration on
@@ -87,13 +113,16 @@ def cond2_estimate(A: torch.Tensor, potrf=None, iters: int = 32) -> torch.Tensor
     Rayleigh quotients approach their eigenvalue from inside the spectrum, so the estimate is a LOWER bound of cond_2,
     within a few percent after 32 steps on kernel matrices (their small eigenvalues decay geometrically or sit on the
     jitter); ``inf`` where the factorisation fails.  Replaces a symmetric eigendecomposition (22 ms at M = 1024 through
-    rocSOLVER) by ~2 ms of GEMVs in the route gate of the models."""
+    rocSOLVER) by ~2 ms of GEMVs in the route gate of the models (``_cond2_engine`` when ``potrf`` is the engine's)."""
     A = A if A.dim() == 3 else A[None]
-    infos = []
-    _, X = cholesky_deferred(A.clone(), infos, potrf, inverse=True, overwrite=True)
     M = A.shape[-1]
     g = torch.Generator(device="cpu").manual_seed(1234)
     v0 = torch.randn(M, 2, generator=g, dtype=torch.float64).to(A.device)
+    eng = getattr(potrf, "__self__", None)  # ``potrf`` is the bound EStepEngine.cholesky: the engine's kernels do the rest
+    if eng is not None and A.is_cuda and A.dtype == torch.float64 and hasattr(eng, "gemv"):
+        return torch.cat([_cond2_engine(A[b].contiguous(), eng, iters, v0) for b in range(A.shape[0])])
+    infos = []
+    _, X = cholesky_deferred(A.clone(), infos, potrf, inverse=True, overwrite=True)
     v = v0.expand(A.shape[0], M, 2).clone()  # two start vectors per matrix: the larger quotient is kept
     w = v.clone()
     for _ in range(iters):

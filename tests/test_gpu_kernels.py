@@ -640,3 +640,32 @@ def test_gemv_rows(engines, M, P, shared):
         y = eng.gemv(torch.as_tensor(A, device="cuda:0"), torch.as_tensor(v, device="cuda:0")).cpu().numpy()
         ref = A @ v if shared else np.einsum("pmk,kp->mp", A, v)
         assert relerr(y, ref) < 1e-13
+
+
+def test_cond2_estimate_through_the_engine(engines):
+    """util.cond2_estimate with the engine's factorisation (the route gate of the models, tsvgp.py ``_routes``): the fast path
+    -- upper-form factorisation with the identity riding along, row GEMVs, a normalisation every fourth step -- against the exact
+    2-norm condition number on kernel matrices from cond 1e1 to 1e9 (a lower bound within ten percent, as on the CPU path),
+    a batch of matrices, M not a multiple of 128, and inf for a matrix that is not positive definite."""
+    from importlib import import_module
+
+    U = import_module("t-svgp_amd.util")
+    eng = engines[torch.float64]
+    rng = np.random.RandomState(0)
+    for M in (200, 1024):
+        X = rng.randn(M, 6)
+        mats = []
+        for ell in (0.6, 1.0, 1.6, 2.5):
+            Z = X / ell
+            d2 = ((Z[:, None, :] - Z[None]) ** 2).sum(-1)
+            mats.append(np.exp(-0.5 * d2) + 1e-9 * np.eye(M))
+        A = torch.as_tensor(np.stack(mats), device="cuda:0")
+        est = U.cond2_estimate(A, eng.cholesky).cpu().numpy()
+        slow = U.cond2_estimate(A).cpu().numpy()  # torch's factorisation and GEMVs: the same iteration
+        for a, e, s in zip(mats, est, slow):
+            ev = np.linalg.eigvalsh(a)
+            c = ev[-1] / ev[0]
+            assert 0.9 * c <= e <= 1.0001 * c, (M, c, e)
+            assert abs(e - s) <= 1e-6 * s, (M, e, s)
+    bad = torch.as_tensor(np.diag([1.0, -1.0, 2.0] + [1.0] * 125), device="cuda:0")
+    assert np.isinf(float(U.cond2_estimate(bad, eng.cholesky)[0]))
