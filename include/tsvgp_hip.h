@@ -312,6 +312,16 @@ int tsvgp_site_beta_f64(const double *D, const double *v, const double *l1, doub
  *     reference src/util.py:176-179 / src/models/tsvgp.py:249-254, K9^-1 acc1 of :279 -- one wave per row. */
 int tsvgp_gemv_f64(const double *A, int64_t strideA, const double *v, double *y, int M, int P, void *stream);
 
+/* (7k) Clock keeper.  Not part of the reference's algorithm: the M x M section of reference src/util.py:168-185 and
+ *     src/models/tsvgp.py:293-300 is latency-bound (a few workgroups at a time for ~1.5 ms at M = 1024), the chip's clock sags
+ *     over it and the N-sized kernels behind it pay for the climb back.  tsvgp_keeper_run launches, on
+ *     `stream` (a side stream), `workgroups` workgroups (0: one per CU) of register-only fp64 FMAs at the lowest wave priority
+ *     that leave as soon as *flag != 0 or after max_us microseconds (0 < max_us <= 1e6), whichever comes first;
+ *     tsvgp_keeper_signal stores `value` to *flag in stream order (0 in front of the launch, 1 on the stream of the chain when
+ *     the chain is through).  flag: one int32 in device memory. */
+int tsvgp_keeper_run(const int32_t *flag, double max_us, int workgroups, void *stream);
+int tsvgp_keeper_signal(int32_t *flag, int value, void *stream);
+
 /* (7c) Status word of one step: flags[0] = sum |info_a| (prelude factorisations), flags[1] = nonpos[0] (count of
  *     non-positive predictive variances, the assert_positive of :113; NULL = 0), flags[2] = sum |info_b| (the final
  *     factorisation, :300).  One device->host read of these three doubles ends a step. */

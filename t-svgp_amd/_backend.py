@@ -142,6 +142,8 @@ _PROTOTYPES = {
                                       c_double, c_double, c_void_p, c_double, c_void_p]),
     "tsvgp_site_beta_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "tsvgp_gemv_f64": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "tsvgp_keeper_run": (c_int, [c_void_p, c_double, c_int, c_void_p]),
+    "tsvgp_keeper_signal": (c_int, [c_void_p, c_int, c_void_p]),
     "tsvgp_step_status_f64": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "tsvgp_sym_pack_f64": (c_int, [c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "tsvgp_sym_unpack_f64": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p]),

@@ -417,6 +417,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, TSV
 #endif
     typedef typename FillVec<T, CPT>::type vec_t;
 
+    __builtin_amdgcn_s_setprio(1);  // in front of the clock keeper's waves (priority 0), behind the factorisation's (3)
     const T variance = var.v[blockIdx.z];
     inv_ls += (size_t)blockIdx.z * D;
     K += (size_t)blockIdx.z * strideK;
@@ -3542,6 +3543,7 @@ inline void zero_fill(void* p, size_t bytes, hipStream_t st) {  // bytes a multi
 __global__ __launch_bounds__(NTHREADS) void tri_copy_kernel(const double* __restrict__ src, int lds_, int64_t sstride,
                                                             double* __restrict__ dst, int ldd, int64_t dstride, int M,
                                                             double scale, int flip) {
+    __builtin_amdgcn_s_setprio(1);
     const int b = blockIdx.z, i = blockIdx.y;
     const int j = blockIdx.x * NTHREADS + threadIdx.x;
     if (j >= M) return;
@@ -3750,6 +3752,52 @@ __global__ __launch_bounds__(NTHREADS) void gemv_rows_kernel(const double* __res
 }
 
 // flags[0] = sum |info_a|, flags[1] = nonpos (as is, NaN included), flags[2] = sum |info_b|   (t_SVGP._status_flags)
+// ---------------------------------------------------------------------------------------------------------------
+// Clock keeper (round 5).  The chip's clock follows its load with a time constant of several milliseconds: behind 1.5 ms of
+// the latency-bound M x M chain (a handful of workgroups at a time) the moments kernel starts near 2.05 GHz and climbs back
+// towards the 2.3-2.4 GHz it holds back-to-back -- 2.22 ms instead of 1.95 for a 125 000-row launch, 16.5 instead of 15.2 at
+// N = 1e6 (profiles/r05_clock_lab.txt, tools/clock_lab.py).  A kernel that keeps the vector ALUs of every CU issuing fp64 FMAs
+// on registers over that stretch -- one wave per SIMD, lowest priority, no memory traffic but the poll of a flag -- holds the
+// clock (1.95 ms again).  It runs on a side stream beside the chain and leaves when the main stream raises the flag in front of
+// the N-pass, or after max_ticks of the 100 MHz real-time counter, whichever comes first: every wave reaches one of the two.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NTHREADS) void clock_keeper_kernel(const int* __restrict__ flag, unsigned max_ticks) {
+    __shared__ int leave;
+    __builtin_amdgcn_s_setprio(0);
+    if (threadIdx.x == 0) leave = 0;
+    __syncthreads();
+    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+    const bool poller = threadIdx.x < 64;  // wave 0 polls the flag (one load per workgroup and round), the others read LDS
+    double x0 = 1.0 + 1e-9 * threadIdx.x, x1 = x0 + 0.25, x2 = x0 + 0.5, x3 = x0 + 0.75;
+    const double a = 1.0 - 0x1p-40, b = 0x1p-40;
+    for (;;) {
+#pragma unroll 1
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {  // 4 x 128 FMAs per lane: ~2 us of the SIMD's fp64 issue slots per round
+                x0 = __builtin_fma(x0, a, b);
+                x1 = __builtin_fma(x1, a, b);
+                x2 = __builtin_fma(x2, a, b);
+                x3 = __builtin_fma(x3, a, b);
+            }
+        }
+        if (poller) {
+            if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
+                __builtin_amdgcn_s_memrealtime() - t0 >= max_ticks) {
+                if (threadIdx.x == 0) __hip_atomic_store(&leave, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                break;
+            }
+        } else if (__hip_atomic_load(&leave, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0 ||
+                   __builtin_amdgcn_s_memrealtime() - t0 >= max_ticks) {
+            break;
+        }
+    }
+    asm volatile("" ::"v"(x0), "v"(x1), "v"(x2), "v"(x3));
+}
+__global__ void keeper_signal_kernel(int* flag, int value) {
+    __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __global__ void step_status_kernel(const int* __restrict__ info_a, int na, const int* __restrict__ info_b, int nb,
                                    const double* __restrict__ nonpos, double* __restrict__ flags) {
     if (threadIdx.x == 0) {
@@ -4588,6 +4636,22 @@ int tsvgp_step_status_f64(const int32_t* info_a, int na, const int32_t* info_b, 
                           void* stream) {
     if (!flags || na < 0 || nb < 0 || (na > 0 && !info_a) || (nb > 0 && !info_b)) return TSVGP_EINVAL;
     hipLaunchKernelGGL(step_status_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, info_a, na, info_b, nb, nonpos, flags);
+    return launch_status();
+}
+int tsvgp_keeper_run(const int32_t* flag, double max_us, int workgroups, void* stream) {
+    if (!flag || !(max_us > 0.0) || max_us > 1.0e6 || workgroups < 0) return TSVGP_EINVAL;
+    if (workgroups == 0) {  // one workgroup of four waves per CU: one wave per SIMD
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+            return TSVGP_ELAUNCH;
+        workgroups = cus;
+    }
+    hipLaunchKernelGGL(clock_keeper_kernel, dim3(workgroups), dim3(NTHREADS), 0, (hipStream_t)stream, flag, (unsigned)(max_us * 100.0));
+    return launch_status();
+}
+int tsvgp_keeper_signal(int32_t* flag, int value, void* stream) {
+    if (!flag) return TSVGP_EINVAL;
+    hipLaunchKernelGGL(keeper_signal_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, flag, value);
     return launch_status();
 }
 int tsvgp_sym_pack_f64(const double* A, int lda, int64_t stride, int M, int P, double* packed, void* stream) {

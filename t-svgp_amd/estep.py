@@ -110,6 +110,13 @@ class EStepEngine:
         self.profile_only = None  # a set of kernel names: bracket only these launches
         # A/B switch (tools/dev_diag2.py): round 4's diagonal-block kernel instead of round 5's (TSVGP_POTRF_DIAG_V1)
         self.potrf_flags = B.POTRF_DIAG_V1 if os.environ.get("TSVGP_POTRF_DIAG_V1") == "1" else 0
+        # Clock keeper (``keeper_begin`` / ``keeper_end``), an experiment that is OFF by default: it holds the clock in isolation
+        # but costs the M x M chain as much as the N-pass gains (profiles/r05_clock_lab.txt).  TSVGP_CLOCK_KEEPER=-1: one
+        # workgroup per CU, =N: N workgroups; TSVGP_KEEPER_MAX_US: the bound after which its waves leave on their own
+        self.clock_keeper = int(os.environ.get("TSVGP_CLOCK_KEEPER", "0"))
+        self.keeper_max_us = float(os.environ.get("TSVGP_KEEPER_MAX_US", "4000"))
+        self._keeper_side = None
+        self._keeper_flag = None
 
     # ------------------------------------------------------------------ helpers
     def _stream(self):
@@ -432,6 +439,39 @@ class EStepEngine:
             B.check(self.lib.tsvgp_gemv_f64(A.data_ptr(), 0 if A.dim() == 2 else M * M, v.data_ptr(), y.data_ptr(), M, P, self._stream()),
                     "tsvgp_gemv")
         return y
+
+    def keeper_begin(self):
+        """Starts the clock keeper (``tsvgp_keeper_run``) on its own side stream beside whatever the current stream runs next and
+        returns a ticket for ``keeper_end``; None when it is switched off.  The M x M sections of a step keep a few workgroups
+        busy at a time; the chip's clock sags over them and the N-sized kernels behind pay for the climb back (moments at
+        125 000 x 1024: 2.22 ms behind 1.5 ms of near-idle, 1.95 ms back-to-back or behind the keeper -- profiles/r05_clock_lab.txt).
+        Inside a stream capture the side stream joins the capture (fork here, join in ``keeper_end``)."""
+        if self.clock_keeper == 0:
+            return None
+        dev = self.device
+        main = torch.cuda.current_stream(dev)
+        if self._keeper_side is None:
+            self._keeper_side = torch.cuda.Stream(dev)
+            self._keeper_flag = torch.zeros(16, dtype=torch.int32, device=dev)
+        side, flag = self._keeper_side, self._keeper_flag
+        with torch.cuda.device(dev):
+            B.check(self.lib.tsvgp_keeper_signal(flag.data_ptr(), 0, main.cuda_stream), "tsvgp_keeper_signal")
+            side.wait_stream(main)
+            B.check(self.lib.tsvgp_keeper_run(flag.data_ptr(), self.keeper_max_us, max(self.clock_keeper, 0), side.cuda_stream),
+                    "tsvgp_keeper_run")
+            done = torch.cuda.Event()
+            done.record(side)
+        return done
+
+    def keeper_end(self, ticket):
+        """Raises the keeper's flag in the order of the current stream and makes that stream wait for the keeper's waves to leave
+        (microseconds): call it in front of the N-sized launch the keeper was bridging to."""
+        if ticket is None:
+            return
+        main = torch.cuda.current_stream(self.device)
+        with torch.cuda.device(self.device):
+            B.check(self.lib.tsvgp_keeper_signal(self._keeper_flag.data_ptr(), 1, main.cuda_stream), "tsvgp_keeper_signal")
+        main.wait_event(ticket)
 
     def step_status(self, infos_a, infos_b, nonpos):
         """[3] fp64 device tensor (sum |info| of the prelude factorisations, nonpos, sum |info| of the final one)."""

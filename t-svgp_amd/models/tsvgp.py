@@ -764,6 +764,10 @@ class t_SVGP(base_SVGP):
         statistics, prelude operands).  No host synchronisation."""
         warm_key = self._warm_key(X, jitter)
         eng = self._get_engine()
+        # the clock keeper bridges the M x M prelude to the N-pass (EStepEngine.keeper_begin); the epilogue has its own
+        self._keep_clock = (self.device.type == "cuda" and getattr(eng, "clock_keeper", 0) != 0
+                            and X.shape[0] * self.num_inducing >= self.KEEPER_MIN_NM)
+        keeper = eng.keeper_begin() if self._keep_clock else None
         # K(X, Z) depends on neither lambda nor the M x M factors: its fill runs on a side stream beside the prelude.
         # (Starting it only behind the two GEMMs that assemble W -- they take 130-190 us each under the fill instead of 40 --
         # measured 0.1-0.2 ms SLOWER per step, and again 36.61 vs 36.46 ms after the fill and the factorisation were reworked:
@@ -795,6 +799,8 @@ class t_SVGP(base_SVGP):
         if ops is None:
             ops = self._site_operands(whiten_jitter=jitter, warm_key=warm_key, routes=routes, fork=fork, Kzz=Kzz, K6=K6,
                                       beside_fill=pre is not None)  # a long fill is already under way: see cholesky_solve_upper
+        if keeper is not None:
+            eng.keeper_end(keeper)
         st = eng.run(X, Y, ops["Z"], self.kernel, moment_Tm=ops["moment_Tm"], prefill=pre,
                      moment_mode=ops["moment_mode"], gamma=ops["gamma"],
                      lik_id=self.likelihood.lik_id, lik_param=self.likelihood.lik_param,
@@ -804,6 +810,7 @@ class t_SVGP(base_SVGP):
                      mean_only=self.skip_unused_variance and self.likelihood.lik_id == B.LIK_GAUSSIAN)
         return st, ops
 
+    KEEPER_MIN_NM = int(os.environ.get("TSVGP_KEEPER_MIN_NM", "50000000"))  # N * M from which the M x M sections get a clock keeper
     LATE_FILL_MAX_NM = int(os.environ.get("TSVGP_LATE_FILL_MAX_NM", "300000000"))  # N * M up to which the fill starts behind W's GEMMs
 
     def _late_fill(self, X) -> bool:
@@ -1104,6 +1111,15 @@ class t_SVGP(base_SVGP):
         """All-reduce of the packed accumulators (RCCL) + the replicated M x M epilogue (tsvgp.py:278-303).
         Returns the status flags (device tensor, see ``_status_flags``).  ``reduced``: the already summed
         (acc2, acc1, nonpos, rows) when the caller did the collective itself (the two-graph replay)."""
+        eng = self._get_engine()
+        keeper = eng.keeper_begin() if getattr(self, "_keep_clock", False) else None  # to the next step's prelude
+        try:
+            return self._site_update_body(st, ops, lr, jitter, inplace, reduced, latents)
+        finally:
+            if keeper is not None:
+                eng.keeper_end(keeper)
+
+    def _site_update_body(self, st, ops, lr, jitter, inplace, reduced, latents):
         P, M = self.num_latent_gps, self.num_inducing
         eng = self._get_engine()
         if reduced is not None:

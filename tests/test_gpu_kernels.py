@@ -669,3 +669,53 @@ def test_cond2_estimate_through_the_engine(engines):
             assert abs(e - s) <= 1e-6 * s, (M, e, s)
     bad = torch.as_tensor(np.diag([1.0, -1.0, 2.0] + [1.0] * 125), device="cuda:0")
     assert np.isinf(float(U.cond2_estimate(bad, eng.cholesky)[0]))
+
+
+def test_clock_keeper_leaves_on_the_flag_and_on_its_bound(engines):
+    """tsvgp_keeper_run / tsvgp_keeper_signal (the opt-in clock keeper beside the M x M sections): its waves
+    leave when the flag is raised -- at once when it already is, within microseconds of a signal from another stream -- and
+    after max_us on their own when nobody raises it (the exit condition every wave reaches)."""
+    eng = engines[torch.float64]
+    dev = eng.device
+    lib = eng.lib
+    flag = torch.zeros(16, dtype=torch.int32, device=dev)
+    main = torch.cuda.current_stream(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def timed(fn):
+        torch.cuda.synchronize()
+        e0.record()
+        fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1)
+
+    assert lib.tsvgp_keeper_signal(flag.data_ptr(), 1, main.cuda_stream) == 0
+    timed(lambda: lib.tsvgp_keeper_run(flag.data_ptr(), 50000.0, 0, main.cuda_stream))  # (first launch: code load)
+    raised = timed(lambda: lib.tsvgp_keeper_run(flag.data_ptr(), 50000.0, 0, main.cuda_stream))
+    assert int(flag[0]) == 1 and raised < 5.0, raised
+    assert lib.tsvgp_keeper_signal(flag.data_ptr(), 0, main.cuda_stream) == 0
+    bound = timed(lambda: lib.tsvgp_keeper_run(flag.data_ptr(), 3000.0, 0, main.cuda_stream))
+    assert 2.9 < bound < 8.0, bound
+    # through the engine: begin on the side stream, a little work on the main stream, end -- far below the bound
+    old = eng.clock_keeper, eng.keeper_max_us
+    eng.clock_keeper, eng.keeper_max_us = -1, 200000.0
+    try:
+        a = torch.randn(512, 512, dtype=torch.float64, device=dev)
+
+        def bridged():
+            t = eng.keeper_begin()
+            assert t is not None
+            for _ in range(4):
+                a @ a
+            eng.keeper_end(t)
+
+        ms = timed(bridged)
+        assert ms < 50.0, ms
+        eng.clock_keeper = 0
+        assert eng.keeper_begin() is None
+    finally:
+        eng.clock_keeper, eng.keeper_max_us = old
+    for bad in (lambda: lib.tsvgp_keeper_run(None, 10.0, 0, None), lambda: lib.tsvgp_keeper_run(flag.data_ptr(), 0.0, 0, None),
+                lambda: lib.tsvgp_keeper_run(flag.data_ptr(), 2.0e6, 0, None), lambda: lib.tsvgp_keeper_signal(None, 1, None)):
+        assert bad() == 1  # TSVGP_EINVAL

@@ -678,3 +678,24 @@ def test_large_input_dimension_matches_oracle():
     mu_h, var_h = hip.predict_f(X[:100] + 0.01)
     mu_o, var_o = ora.predict_f(X[:100] + 0.01)
     assert relerr(mu_h.cpu().numpy(), mu_o) < 1e-8 and relerr(var_h.cpu().numpy(), var_o) < 1e-8
+
+
+def test_clock_keeper_does_not_change_a_step():
+    """The opt-in clock keeper (EStepEngine.keeper_begin / keeper_end around the M x M prelude and epilogue) only runs register
+    arithmetic on a side stream: a trajectory with it is the trajectory without it, bit for bit -- eagerly and replayed from a
+    hipGraph (the side stream joins the capture)."""
+    p = pkg()
+    X, Y, Z = synthetic(N=3000, M=130, D=3, lik="gaussian", seed=11)
+    Xd, Yd = torch.as_tensor(X, device="cuda:0"), torch.as_tensor(Y, device="cuda:0")
+    for use_graph in (False, True):
+        plain = p.t_SVGP(p.SquaredExponential(1.0, 1.0), p.Gaussian(0.1), Z, use_graph=use_graph)
+        kept = p.t_SVGP(p.SquaredExponential(1.0, 1.0), p.Gaussian(0.1), Z, use_graph=use_graph)
+        kept.KEEPER_MIN_NM = 0
+        kept._get_engine().clock_keeper = -1  # (the default, TSVGP_CLOCK_KEEPER unset, is 0: off)
+        assert plain._get_engine().clock_keeper == 0
+        for i in range(4):
+            plain.natgrad_step((Xd, Yd), lr=0.6)
+            kept.natgrad_step((Xd, Yd), lr=0.6)
+            assert kept._keep_clock and not plain._keep_clock
+            assert relerr(kept.lambda_1.numpy(), plain.lambda_1.numpy()) == 0.0
+            assert relerr(kept.lambda_2.cpu().numpy(), plain.lambda_2.cpu().numpy()) == 0.0
