@@ -692,26 +692,52 @@ class t_SVGP(base_SVGP):
         self._check_step(ops, nonpos)
         scale = (float(self.num_data) / rows) if self.num_data is not None else 1.0
 
-        # M x M part by autograd: a1, A2, sum g1 are constants here
+        # M x M part: a1, A2, sum g1 are constants here.  With K = K_uu + 1e-6 I, W = I + L^T K L, Q = L W^-1 L^T = D^T D and
+        # beta = l1 - Q K l1 (util.py:168-179, tsvgp.py:65-70):   dQ = -Q dK Q,   d beta = -Q dK beta,   d log|W| = tr(Q dK),  so
+        #   d KL            = 1/2 [ beta^T dK beta - 2 (Q K beta)^T dK beta + tr(Q K Q dK) ]
+        #   d (beta^T a1 - tr(Q A2)) = -beta^T dK (Q a1) + tr(Q A2 Q dK)
+        # i.e. one symmetric M x M matrix G = d surrogate / d K per latent from six GEMMs on the prelude's own Q, beta -- and autograd
+        # only through the elementwise K(Z, Z; theta) (round 5; the factorisation and the triangular solve used to sit inside the
+        # autograd graph: ~4.5 ms of rocSOLVER / rocBLAS launches per evaluation, forward and backward).  TSVGP_MSTEP_AUTOGRAD=1: that
+        # form, kept as the cross-check of tests/test_gpu_mstep.py.
         var_t = [k.variance.value.detach().to(self.device).clone().requires_grad_(True) for k in kernels]
         ls_t = [k.lengthscales.value.detach().to(self.device).clone().requires_grad_(True) for k in kernels]
         Z_t = self._Z().detach().clone().requires_grad_(True)
         l1, L = self.lambda_1.value.detach(), self.lambda_2_sqrt.value.detach()
         Id = ops["Id"]
-        with torch.enable_grad():
-            K6 = torch.stack([k.K_torch(Z_t, v_, l_) for k, v_, l_ in zip(kernels, var_t, ls_t)]) + default_jitter() * Id
-            K6 = K6.expand(P, M, M)  # one shared kernel: the same matrix for every latent
-            W = Id + L.transpose(-1, -2) @ (K6 @ L)
-            cW = torch.linalg.cholesky(0.5 * (W + W.transpose(-1, -2)))
-            Dt = torch.linalg.solve_triangular(cW, L.transpose(-1, -2), upper=False)
-            Qt = Dt.transpose(-1, -2) @ Dt
-            K6l = torch.einsum("pmk,kp->mp", K6, l1)
-            beta_t = l1 - torch.einsum("pmk,kp->mp", Qt, K6l)
-            kl = 0.5 * (torch.einsum("mp,pmk,kp->", beta_t, K6, beta_t) - torch.sum(Qt * K6)
-                        + 2.0 * torch.sum(torch.log(torch.diagonal(cW, dim1=-2, dim2=-1))))
-            knn = sum(v_ * s_ for v_, s_ in zip(var_t, sum_g1))  # sum_np g1 * k(x, x), k(x, x) = variance
-            surrogate = scale * (torch.sum(beta_t * acc1.transpose(-1, -2)) - torch.sum(Qt * acc2) + knn) - kl
-            g_all = torch.autograd.grad(surrogate, var_t + ls_t + [Z_t])
+        if os.environ.get("TSVGP_MSTEP_AUTOGRAD", "0") == "1":
+            with torch.enable_grad():
+                K6 = torch.stack([k.K_torch(Z_t, v_, l_) for k, v_, l_ in zip(kernels, var_t, ls_t)]) + default_jitter() * Id
+                K6 = K6.expand(P, M, M)  # one shared kernel: the same matrix for every latent
+                W = Id + L.transpose(-1, -2) @ (K6 @ L)
+                cW = torch.linalg.cholesky(0.5 * (W + W.transpose(-1, -2)))
+                Dt = torch.linalg.solve_triangular(cW, L.transpose(-1, -2), upper=False)
+                Qt = Dt.transpose(-1, -2) @ Dt
+                K6l = torch.einsum("pmk,kp->mp", K6, l1)
+                beta_t = l1 - torch.einsum("pmk,kp->mp", Qt, K6l)
+                kl = 0.5 * (torch.einsum("mp,pmk,kp->", beta_t, K6, beta_t) - torch.sum(Qt * K6)
+                            + 2.0 * torch.sum(torch.log(torch.diagonal(cW, dim1=-2, dim2=-1))))
+                knn = sum(v_ * s_ for v_, s_ in zip(var_t, sum_g1))  # sum_np g1 * k(x, x), k(x, x) = variance
+                surrogate = scale * (torch.sum(beta_t * acc1.transpose(-1, -2)) - torch.sum(Qt * acc2) + knn) - kl
+                g_all = torch.autograd.grad(surrogate, var_t + ls_t + [Z_t])
+            kl = kl.detach()
+        else:
+            K6c = ops["K6"].expand(P, M, M)
+            outer = lambda a, b: torch.einsum("mp,kp->pmk", a, b)  # [M, P] x [M, P] -> [P, M, M]
+            QK = Q @ K6c
+            QKb = torch.einsum("pmk,kp->mp", QK, beta)
+            Qa1 = torch.einsum("pmk,pk->mp", Q, acc1)
+            G_kl = 0.5 * (outer(beta, beta) - outer(QKb, beta) - outer(beta, QKb) + QK @ Q)
+            G_t = (Q @ acc2) @ Q - 0.5 * (outer(beta, Qa1) + outer(Qa1, beta))
+            G = scale * G_t - G_kl
+            G = 0.5 * (G + G.transpose(-1, -2))
+            if not sep:
+                G = G.sum(dim=0, keepdim=True)  # one kernel behind every latent
+            kl = kl_from_dense_site(ops["K6"], l1, Dm, ops["U_W"], beta)
+            with torch.enable_grad():
+                Kt = torch.stack([k.K_torch(Z_t, v_, l_) for k, v_, l_ in zip(kernels, var_t, ls_t)])
+                knn = sum(v_ * s_ for v_, s_ in zip(var_t, sum_g1))  # sum_np g1 * k(x, x), k(x, x) = variance
+                g_all = torch.autograd.grad(torch.sum(G.detach() * Kt) + scale * knn, var_t + ls_t + [Z_t])
         g_var, g_ls, g_Z = g_all[:nk], g_all[nk:2 * nk], g_all[-1]
         grads = {"Z": g_Z + scale * dZ}
         for ki, k in enumerate(kernels):
@@ -723,7 +749,7 @@ class t_SVGP(base_SVGP):
         if gaussian:
             s2 = self.likelihood.lik_param
             grads["likelihood_variance"] = scale * (-0.5 * rows * P / s2 + 0.5 * res / (s2 * s2))
-        elbo = ve_sum * scale - kl.detach()
+        elbo = ve_sum * scale - kl
         return elbo, grads
 
     # -- the hot path ------------------------------------------------------------------------------------------

@@ -281,4 +281,36 @@ def test_gradient_pass_on_the_stored_tile_equals_the_fused_pass(monkeypatch):
             out[mode] = (float(e), {k: v.cpu().numpy() for k, v in g.items()})
         assert abs(out["1"][0] - out["0"][0]) < 1e-10 * abs(out["0"][0])
         for k in out["0"][1]:
-            assert relerr(out["1"][1][k], out["0"][1][k]) < 1e-9, (lik, k)
+            # (1e-8: the two passes round g0, g1 differently at the 1e-13 level, and the M x M part -- Q A2 Q against Q K Q -- carries
+            #  that through a cancellation of ~1e4: 3.4e-9 of the largest entry on dZ, Bernoulli, measured)
+            assert relerr(out["1"][1][k], out["0"][1][k]) < 1e-8, (lik, k)
+
+
+@pytest.mark.parametrize("lik,P,sep", [("gaussian", 1, False), ("bernoulli", 2, False), ("gaussian", 2, True)])
+def test_closed_form_kuu_gradient_equals_autograd_through_the_factorisation(monkeypatch, lik, P, sep):
+    """The M x M part of elbo_and_grads: the closed form d surrogate / d K_uu (dQ = -Q dK Q, d beta = -Q dK beta, d log|W| =
+    tr(Q dK); six GEMMs on the prelude's Q and beta, autograd only through K(Z, Z; theta)) against round 3's form, which
+    differentiates through the factorisation of W and the triangular solve (TSVGP_MSTEP_AUTOGRAD=1): the same ELBO and the same
+    gradients, for a shared kernel behind one and two latents and for one kernel per latent."""
+    p = pkg()
+    X, Y, Z = synthetic(N=1500, M=48, D=3, P=P, lik=lik, seed=21)
+    Xd, Yd = torch.as_tensor(X, device="cuda:0"), torch.as_tensor(Y, device="cuda:0")
+    likelihood = p.Gaussian(0.2) if lik == "gaussian" else p.Bernoulli()
+    if sep:
+        kern = p.SeparateIndependent([p.SquaredExponential(1.3, [0.9, 1.1, 1.4]), p.SquaredExponential(0.8, [1.2, 0.7, 1.0])])
+    else:
+        kern = p.SquaredExponential(1.3, [0.9, 1.1, 1.4])
+    m = p.t_SVGP(kern, likelihood, Z, num_latent_gps=P, num_data=4000)
+    for _ in range(3):
+        m.natgrad_step((Xd, Yd), lr=0.5)
+    monkeypatch.setenv("TSVGP_MSTEP_AUTOGRAD", "1")
+    e_a, g_a = m.elbo_and_grads((Xd, Yd))
+    monkeypatch.setenv("TSVGP_MSTEP_AUTOGRAD", "0")
+    e_c, g_c = m.elbo_and_grads((Xd, Yd))
+    assert abs(float(e_a) - float(e_c)) <= 1e-11 * abs(float(e_a))
+    assert sorted(g_a) == sorted(g_c)
+    for k in g_a:
+        # 2e-7 of the largest entry: both forms subtract scale Q A2 Q and Q K Q / 2, terms some 1e6 times the gradient that is left
+        # (1.2e-8 measured on dZ, Gaussian; the stored-tile / fused comparison above sees the same amplification)
+        err = relerr(g_c[k].detach().cpu().numpy(), g_a[k].detach().cpu().numpy())
+        assert err < 2e-7, (k, err)
