@@ -16,8 +16,12 @@ prec = sys.argv[3] if len(sys.argv) > 3 else "f64"
 flags = sys.argv[4:]
 so = "/tmp/libtsvgp_diag_panel1_%d.so" % (abs(hash(" ".join(flags))) % 100000)
 if not os.path.exists(so):
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-DTSVGP_DIAG_PANEL1",
-                           *flags, "-I", root + "/include", root + "/t-svgp_amd/csrc/tsvgp_kernels.hip", "-o", so])
+    # (two objects, as _backend.build_library: the factorisation's second source has its own code-generation flag)
+    cc = ["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-I", root + "/include"]
+    o1, o2 = so + ".kernels.o", so + ".chol.o"
+    subprocess.check_call(cc + ["-DTSVGP_DIAG_PANEL1", *flags, "-c", root + "/t-svgp_amd/csrc/tsvgp_kernels.hip", "-o", o1])
+    subprocess.check_call(cc + ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-c", root + "/t-svgp_amd/csrc/tsvgp_chol.hip", "-o", o2])
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", o1, o2, "-o", so])
 lib = ctypes.CDLL(so)
 vp, i64 = ctypes.c_void_p, ctypes.c_int64
 dev = "cuda:0"
