@@ -810,7 +810,13 @@ class t_SVGP(base_SVGP):
                 Kzz = eng.kuu(self._Z(), self.kernel)
                 K6 = self._k6_of(Kzz)
             want = "Kfu" if all(r == "direct" for r in routes) else "B"
-            if self._late_fill(X):
+            if X.shape[0] * self.num_inducing <= self.FILL_INLINE_MAX_NM:
+                # One rank's share of a large job, smaller still: the fill goes in line, right in front of the moments kernel
+                # (``EStepEngine.run`` fills when it gets no ticket).  Beside the factorisation it gains nothing -- the two contend
+                # one for one -- and as the last thing the chip does before the N-pass it hands the MFMA kernels a higher clock than
+                # the latency-bound chain does (profiles/r05_clock_lab.txt, r05_fill_placement.txt).
+                pass
+            elif self._late_fill(X):
                 # One rank's share of a large job: the fill is shorter than the factorisation chain, and its workgroups take every
                 # CU slot from the two M^3 GEMMs that assemble W (126 + 129 us under the fill against 40 + 40 alone at 125 000 x
                 # 1024, profiles/r05_v1_ns_mxm_timeline_rows125000.txt): it starts behind them and runs beside the factorisation.
@@ -837,6 +843,7 @@ class t_SVGP(base_SVGP):
         return st, ops
 
     KEEPER_MIN_NM = int(os.environ.get("TSVGP_KEEPER_MIN_NM", "50000000"))  # N * M from which the M x M sections get a clock keeper
+    FILL_INLINE_MAX_NM = int(os.environ.get("TSVGP_FILL_INLINE_MAX_NM", "0"))  # N * M up to which the fill runs in line in front of the moments
     LATE_FILL_MAX_NM = int(os.environ.get("TSVGP_LATE_FILL_MAX_NM", "300000000"))  # N * M up to which the fill starts behind W's GEMMs
 
     def _late_fill(self, X) -> bool:
