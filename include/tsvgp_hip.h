@@ -279,6 +279,11 @@ int tsvgp_potrf_inv_f64(double *A, int M, int lda, int batch, int64_t stride, in
  *     src/models/tsvgp.py:300 (scale = -1) in one pass.  src [batch x * x lds], dst [batch x * x ldd] (strides in elements). */
 int tsvgp_tri_copy_f64(const double *src, int lds, int64_t sstride, double *dst, int ldd, int64_t dstride, int M, int batch,
                        double scale, int flip, void *stream);
+/* (7') The same pass with a shift of the diagonal, dst[b][i][i] += diag_add (after the scale), and flip = 3: (si, sj) = (i, j), keep
+ *     everything -- K_uu + jitter I (reference src/models/tsvgp.py:209-211, :270) and I + L^T K L (src/util.py:171-172) written where
+ *     the factorisation reads them, instead of a copy, an addition on the diagonal and a triangle pass each. */
+int tsvgp_tri_copy_shift_f64(const double *src, int lds, int64_t sstride, double *dst, int ldd, int64_t dstride, int M, int batch,
+                             double scale, double diag_add, int flip, void *stream);
 
 /* (7b) The matrix of the final factorisation of one E-step (reference src/models/tsvgp.py:286-300), in one pass:
  *        G1s    = (G1 + G1^T) / 2

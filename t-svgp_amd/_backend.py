@@ -136,6 +136,8 @@ _PROTOTYPES = {
     "tsvgp_potrf_inv_f64": (c_int, [c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_int, c_void_p]),
     "tsvgp_tri_copy_f64": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int, c_int64, c_int, c_int, c_double, c_int, c_void_p]),
+    "tsvgp_tri_copy_shift_f64": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int, c_int64, c_int, c_int, c_double, c_double, c_int,
+                                         c_void_p]),
     "tsvgp_site_target_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_double, c_double, c_double, c_void_p,
                                       c_double, c_void_p]),
     "tsvgp_site_update_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,

@@ -3566,16 +3566,18 @@ inline void zero_fill(void* p, size_t bytes, hipStream_t st) {  // bytes a multi
 //   flip == 2: (si, sj) = (M - 1 - i, M - 1 - j), keep everything   -- J A J, the input of that factorisation
 __global__ __launch_bounds__(NTHREADS) void tri_copy_kernel(const double* __restrict__ src, int lds_, int64_t sstride,
                                                             double* __restrict__ dst, int ldd, int64_t dstride, int M,
-                                                            double scale, int flip) {
+                                                            double scale, int flip, double diag_add) {
     __builtin_amdgcn_s_setprio(1);
     const int b = blockIdx.z, i = blockIdx.y;
     const int j = blockIdx.x * NTHREADS + threadIdx.x;
     if (j >= M) return;
-    const bool keep = flip == 2 ? true : flip ? (i <= j) : (i >= j);
+    const bool keep = flip >= 2 ? true : flip ? (i <= j) : (i >= j);
     double v = 0.0;
     if (keep) {
-        const int si = flip ? M - 1 - i : i, sj = flip ? M - 1 - j : j;
+        const bool rev = flip == 1 || flip == 2;
+        const int si = rev ? M - 1 - i : i, sj = rev ? M - 1 - j : j;
         v = scale * src[(size_t)b * sstride + (size_t)si * lds_ + sj];
+        if (i == j) v += diag_add;
     }
     dst[(size_t)b * dstride + (size_t)i * ldd + j] = v;
 }
@@ -4605,13 +4607,18 @@ int tsvgp_potrf_inv_f64(double* A, int M, int lda, int batch, int64_t stride, in
     return potrf(A, M, lda, batch, stride, info, work, flags, stream, X, Xt, T);
 }
 
-int tsvgp_tri_copy_f64(const double* src, int lds, int64_t sstride, double* dst, int ldd, int64_t dstride, int M, int batch,
-                       double scale, int flip, void* stream) {
-    if (!src || !dst || M <= 0 || lds < M || ldd < M || batch <= 0 || batch > 65535 || M > 65535 || flip < 0 || flip > 2)
+int tsvgp_tri_copy_shift_f64(const double* src, int lds, int64_t sstride, double* dst, int ldd, int64_t dstride, int M, int batch,
+                             double scale, double diag_add, int flip, void* stream) {
+    if (!src || !dst || M <= 0 || lds < M || ldd < M || batch <= 0 || batch > 65535 || M > 65535 || flip < 0 || flip > 3)
         return TSVGP_EINVAL;
     hipLaunchKernelGGL(tri_copy_kernel, dim3((M + NTHREADS - 1) / NTHREADS, M, batch), dim3(NTHREADS), 0, (hipStream_t)stream,
-                       src, lds, sstride, dst, ldd, dstride, M, scale, flip);
+                       src, lds, sstride, dst, ldd, dstride, M, scale, flip, diag_add);
     return launch_status();
+}
+int tsvgp_tri_copy_f64(const double* src, int lds, int64_t sstride, double* dst, int ldd, int64_t dstride, int M, int batch,
+                       double scale, int flip, void* stream) {
+    if (flip > 2) return TSVGP_EINVAL;
+    return tsvgp_tri_copy_shift_f64(src, lds, sstride, dst, ldd, dstride, M, batch, scale, 0.0, flip, stream);
 }
 
 int tsvgp_site_target_f64(const double* G1, const double* LLt, double* target, double* G1s, int M, int P, double c_ll,

@@ -263,17 +263,20 @@ class EStepEngine:
         self.se_fill(Z, Z, inv_ls, kernel.variance.item(), out, kernel.kind)
         return out[:M, :M].contiguous()
 
-    def tri_copy(self, src: torch.Tensor, M: int, scale: float = 1.0, flip: int = 0, out: torch.Tensor = None) -> torch.Tensor:
+    def tri_copy(self, src: torch.Tensor, M: int, scale: float = 1.0, flip: int = 0, out: torch.Tensor = None,
+                 diag_add: float = 0.0) -> torch.Tensor:
         """[nb, M, M] contiguous <- triangle / index reversal of the leading M x M block of src [nb, R, C]
-        (``tsvgp_tri_copy_f64``: flip 0 = lower triangle, 1 = reversed indices, upper triangle, 2 = reversed, everything).
+        (``tsvgp_tri_copy_shift_f64``: flip 0 = lower triangle, 1 = reversed indices, upper triangle, 2 = reversed, everything,
+        3 = as it is, everything); ``diag_add`` is added on the diagonal behind the scale.
         ``out``: a [nb, >= M, >= M] view (unit element stride) whose leading M x M blocks are written instead."""
         nb, R, C = src.shape
         if out is None:
             out = torch.empty((nb, M, M), dtype=torch.float64, device=self.device)
         assert src.stride(2) == 1 and out.stride(2) == 1 and out.shape[0] == nb
         with torch.cuda.device(self.device):
-            B.check(self.lib.tsvgp_tri_copy_f64(src.data_ptr(), src.stride(1), src.stride(0), out.data_ptr(), out.stride(1),
-                                                out.stride(0), M, nb, float(scale), int(flip), self._stream()), "tsvgp_tri_copy")
+            B.check(self.lib.tsvgp_tri_copy_shift_f64(src.data_ptr(), src.stride(1), src.stride(0), out.data_ptr(), out.stride(1),
+                                                      out.stride(0), M, nb, float(scale), float(diag_add), int(flip), self._stream()),
+                    "tsvgp_tri_copy")
         return out
 
     def cholesky_solve_upper(self, A: torch.Tensor, Lrhs, robust: bool = False, beside_fill: bool = False):
@@ -291,18 +294,30 @@ class EStepEngine:
         workgroups (224 registers per lane left), round 4's block step (78-87 registers per kernel) can: under the fill of
         N = 1e6 rows the call takes 1.69 ms with round 4's step and 2.13 ms with round 5's (profiles/r05_potrf_under_fill_ab.txt),
         alone 0.49 against 0.45."""
-        A = A.to(device=self.device, dtype=torch.float64)
-        M = A.shape[-1]
-        batch_shape = A.shape[:-2]
+        # ``A`` may also be a LIST of (matrices [n_i, M, M], shift) runs of the batch: run i is factored as matrices_i + shift_i I.
+        # The shift rides on the pass that writes J A J where the factorisation reads it, so W = I + L^T K L and K_uu + jitter I
+        # need no assembled batch, no copy and no additions on the diagonal in front of this call (round 5).
+        if isinstance(A, (list, tuple)):
+            runs = [(a.to(device=self.device, dtype=torch.float64).reshape(-1, a.shape[-1], a.shape[-1]), float(sh)) for a, sh in A]
+            M = runs[0][0].shape[-1]
+            nb = sum(r.shape[0] for r, _ in runs)
+            batch_shape = (nb,)
+        else:
+            A = A.to(device=self.device, dtype=torch.float64)
+            M = A.shape[-1]
+            batch_shape = A.shape[:-2]
+            nb = 1
+            for d in batch_shape:
+                nb *= int(d)
+            runs = [(A.reshape(nb, M, M), 0.0)]
         Mp = B.round_up(M)
-        nb = 1
-        for d in batch_shape:
-            nb *= int(d)
         tall = (torch.empty if Mp == M else torch.zeros)((nb, 2 * Mp, Mp), dtype=torch.float64, device=self.device)
-        A3 = A.reshape(nb, M, M)
-        if A3.stride(2) != 1:
-            A3 = A3.contiguous()
-        self.tri_copy(A3, M, 1.0, 2, out=tall[:, :Mp])  # J A J
+        a0 = 0
+        for A3, shift in runs:
+            if A3.stride(2) != 1:
+                A3 = A3.contiguous()
+            self.tri_copy(A3, M, 1.0, 2, out=tall[a0:a0 + A3.shape[0], :Mp], diag_add=shift)  # J (A + shift I) J
+            a0 += A3.shape[0]
         # J tril(L) J: upper triangular, the rows the solve carries along
         parts, b0 = (list(Lrhs) if isinstance(Lrhs, (list, tuple)) else [Lrhs]), 0
         for part in parts:

@@ -260,6 +260,14 @@ class t_SVGP(base_SVGP):
         K6.diagonal(dim1=-2, dim2=-1).add_(default_jitter())
         return K6
 
+    def _k6(self, Kzz: torch.Tensor) -> torch.Tensor:
+        """``_k6_of`` in one launch on the GPU (``tsvgp_tri_copy_shift_f64``: a copy with the jitter on the diagonal)."""
+        eng = self._get_engine()
+        if Kzz.is_cuda and Kzz.dtype == torch.float64 and hasattr(eng, "tri_copy"):
+            M = Kzz.shape[-1]
+            return eng.tri_copy(Kzz.reshape(-1, M, M), M, 1.0, 3, diag_add=default_jitter()).reshape(Kzz.shape)
+        return self._k6_of(Kzz)
+
     def _warm_key(self, X, jitter):
         """Cache key of everything B = K(X, Z) U9^-T depends on; None when caching is off or X is not a device tensor."""
         if not self.cache_whitened or not isinstance(X, torch.Tensor) or X.device != self.device:
@@ -351,7 +359,7 @@ class t_SVGP(base_SVGP):
         if warm and "K6" in warm[1]:
             K6 = warm[1]["K6"]  # read only from here on (40 us of copy + strided add per step otherwise)
         elif K6 is None or latents is not None:
-            K6 = self._k6_of(Kzz)
+            K6 = self._k6(Kzz)
         P_ = L.shape[0]
         potrf = getattr(eng, "cholesky", None)  # HIP blocked Cholesky (tsvgp_potrf_f64)
         robust = potrf is not None and routes is not None and any(r == "projected" for r in routes)
@@ -374,28 +382,38 @@ class t_SVGP(base_SVGP):
         with_k9 = whiten_jitter is not None and not warm and not lower9
         n9 = (Kzz.shape[0] if Kzz.dim() == 3 else 1) if with_k9 else 0
         K6l = self._kmv(K6, l1)  # [M, P]: needed behind the factorisation (beta) -- issued in front of it, off the path to the moments
-        batch = torch.empty((P_ + n9, M, M), dtype=torch.float64, device=Kzz.device)
-        # (bmm + a strided add of the identity: baddbmm first copies its [P, M, M] addend into the output, 8 MB per latent)
         # (the transposed-operand rocBLAS kernels take 60 us at M = 1024 where the plain one takes 40: L^T is copied out first,
         # for this product and for L L^T below)
         Lt = L.transpose(-1, -2).contiguous()
-        torch.bmm(Lt, K6 @ L, out=batch[:P_])
-        batch[:P_].diagonal(dim1=-2, dim2=-1).add_(1.0)
-        if after_w is not None:
-            after_w()  # a small shard's K(X, Z) fill starts here, behind the two GEMMs it would otherwise starve (_step_front)
-        if with_k9:
-            batch[P_:].copy_(Kzz if Kzz.dim() == 3 else Kzz[None])
-            batch[P_:].diagonal(dim1=-2, dim2=-1).add_(whiten_jitter)  # K9 = K_uu + jitter I, tsvgp.py:270
+        solve = potrf is not None and hasattr(eng, "cholesky_solve_upper") and os.environ.get("TSVGP_POTRF_SOLVE", "1") != "0"
+        if solve:
+            # the identity of W and the jitter of K9 = K_uu + jitter I (tsvgp.py:270) ride on the pass that hands the matrices to
+            # the factorisation (EStepEngine.cholesky_solve_upper with a list of runs): no assembled batch, no 8 MB copy of K_uu,
+            # no strided additions -- three launches fewer on the chain
+            runs = [(torch.bmm(Lt, K6 @ L), 1.0)]
+            if after_w is not None:
+                after_w()  # a small shard's K(X, Z) fill starts here, behind the two GEMMs it would otherwise starve (_step_front)
+            if with_k9:
+                runs.append((Kzz if Kzz.dim() == 3 else Kzz[None], whiten_jitter))
+        else:
+            batch = torch.empty((P_ + n9, M, M), dtype=torch.float64, device=Kzz.device)
+            # (bmm + a strided add of the identity: baddbmm first copies its [P, M, M] addend into the output, 8 MB per latent)
+            torch.bmm(Lt, K6 @ L, out=batch[:P_])
+            batch[:P_].diagonal(dim1=-2, dim2=-1).add_(1.0)
+            if after_w is not None:
+                after_w()
+            if with_k9:
+                batch[P_:].copy_(Kzz if Kzz.dim() == 3 else Kzz[None])
+                batch[P_:].diagonal(dim1=-2, dim2=-1).add_(whiten_jitter)  # K9 = K_uu + jitter I, tsvgp.py:270
         # Factor AND solve in one pass (EStepEngine.cholesky_solve_upper): D = U_W^-1 L^T comes out of the factorisation itself,
         # J L J riding along as panel rows -- and with the identity riding along K_uu + jitter I, its inverse factor -- instead of
         # from the inverse recursion (three levels of launch pairs), two triangle copies, a 1024^3 GEMM and a triu pass.
         # (Measured and NOT kept, profiles/r04_chain_ab.txt: K_uu + jitter I factored on the side stream, off the chain -- its 24
         # dependent launches then queue behind the moments kernel's workgroups: 4 ms per call at N = 1e6, the step 0.2 ms slower.)
-        solve = potrf is not None and hasattr(eng, "cholesky_solve_upper") and os.environ.get("TSVGP_POTRF_SOLVE", "1") != "0"
         Dm = None
         if solve:
             rhs = [L] + ([Id.expand(n9, M, M)] if n9 else [])
-            both, info_w, sol = eng.cholesky_solve_upper(batch, rhs, robust=robust, **({"beside_fill": True} if beside_fill else {}))
+            both, info_w, sol = eng.cholesky_solve_upper(runs, rhs, robust=robust, **({"beside_fill": True} if beside_fill else {}))
             infos.append(info_w.reshape(-1).to(torch.int32))
             U_W, Dm, Uinv_W, inv_both = both[:P_], sol[:P_], None, sol
         else:
@@ -808,7 +826,7 @@ class t_SVGP(base_SVGP):
             # workgroups otherwise take every CU first (the small fill then waited for slots: 54 us instead of ~8 at M = 1024)
             if not (warm_key is not None and self._warm is not None and self._warm[0] == warm_key):
                 Kzz = eng.kuu(self._Z(), self.kernel)
-                K6 = self._k6_of(Kzz)
+                K6 = self._k6(Kzz)
             want = "Kfu" if all(r == "direct" for r in routes) else "B"
             if X.shape[0] * self.num_inducing <= self.FILL_INLINE_MAX_NM:
                 # One rank's share of a large job, smaller still: the fill goes in line, right in front of the moments kernel
