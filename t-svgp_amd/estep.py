@@ -298,50 +298,74 @@ class EStepEngine:
         # The shift rides on the pass that writes J A J where the factorisation reads it, so W = I + L^T K L and K_uu + jitter I
         # need no assembled batch, no copy and no additions on the diagonal in front of this call (round 5).
         if isinstance(A, (list, tuple)):
-            runs = [(a.to(device=self.device, dtype=torch.float64).reshape(-1, a.shape[-1], a.shape[-1]), float(sh)) for a, sh in A]
+            runs = [(a.reshape(-1, a.shape[-1], a.shape[-1]), float(sh)) for a, sh in A]
             M = runs[0][0].shape[-1]
             nb = sum(r.shape[0] for r, _ in runs)
             batch_shape = (nb,)
         else:
-            A = A.to(device=self.device, dtype=torch.float64)
             M = A.shape[-1]
             batch_shape = A.shape[:-2]
             nb = 1
             for d in batch_shape:
                 nb *= int(d)
             runs = [(A.reshape(nb, M, M), 0.0)]
-        Mp = B.round_up(M)
-        tall = (torch.empty if Mp == M else torch.zeros)((nb, 2 * Mp, Mp), dtype=torch.float64, device=self.device)
+        job = self.solve_upper_begin(nb, M)
         a0 = 0
         for A3, shift in runs:
-            if A3.stride(2) != 1:
-                A3 = A3.contiguous()
-            self.tri_copy(A3, M, 1.0, 2, out=tall[a0:a0 + A3.shape[0], :Mp], diag_add=shift)  # J (A + shift I) J
+            self.solve_upper_put(job, a0, A3, shift)
             a0 += A3.shape[0]
-        # J tril(L) J: upper triangular, the rows the solve carries along
         parts, b0 = (list(Lrhs) if isinstance(Lrhs, (list, tuple)) else [Lrhs]), 0
         for part in parts:
-            L3 = part.to(device=self.device, dtype=torch.float64).reshape(-1, M, M)
-            if L3.stride(2) != 1:
-                L3 = L3.contiguous()
-            self.tri_copy(L3, M, 1.0, 1, out=tall[b0:b0 + L3.shape[0], Mp:])
-            b0 += L3.shape[0]
+            b0 += self.solve_upper_put_rhs(job, b0, part)
         assert b0 == nb, "one right-hand side per matrix of the batch"
+        U, info, Dm = self.solve_upper_run(job, robust=robust, beside_fill=beside_fill)
+        out_shape = tuple(batch_shape) + (M, M)
+        return U.reshape(out_shape), info, Dm.reshape(out_shape)
+
+    # The same call in pieces, for a caller whose operands become available at different times (t_SVGP._site_operands: K_uu +
+    # jitter I and both right-hand sides exist before the two GEMMs that make W, and a shard's K(X, Z) fill starts right behind W:
+    # handed over early, their passes run on an idle chip -- 7 us each -- instead of beside the fill -- 20-30 us each).
+    def solve_upper_begin(self, nb: int, M: int) -> dict:
+        """The tall operand [nb, 2 Mp, Mp] of ``tsvgp_potrf_solve_f64``: J A J on top, the right-hand-side rows below."""
+        Mp = B.round_up(M)
+        tall = (torch.empty if Mp == M else torch.zeros)((nb, 2 * Mp, Mp), dtype=torch.float64, device=self.device)
         if Mp != M:
             tall[:, :Mp].diagonal(dim1=-2, dim2=-1)[:, M:] = 1.0  # chol([[A, 0], [0, I]]) = [[C, 0], [0, I]]
+        return dict(tall=tall, nb=nb, M=M, Mp=Mp)
+
+    def solve_upper_put(self, job: dict, b0: int, A3: torch.Tensor, shift: float = 0.0) -> int:
+        """Matrices b0 .. of the batch <- A3 [n, M, M] + shift I (index-reversed where the factorisation reads them)."""
+        M, Mp = job["M"], job["Mp"]
+        A3 = A3.to(device=self.device, dtype=torch.float64).reshape(-1, M, M)
+        if A3.stride(2) != 1:
+            A3 = A3.contiguous()
+        self.tri_copy(A3, M, 1.0, 2, out=job["tall"][b0:b0 + A3.shape[0], :Mp], diag_add=shift)  # J (A + shift I) J
+        return A3.shape[0]
+
+    def solve_upper_put_rhs(self, job: dict, b0: int, L3: torch.Tensor) -> int:
+        """Right-hand sides b0 .. <- the lower triangular L3 [n, M, M] (J tril(L) J: upper triangular, the rows the solve carries along)."""
+        M, Mp = job["M"], job["Mp"]
+        L3 = L3.to(device=self.device, dtype=torch.float64).reshape(-1, M, M)
+        if L3.stride(2) != 1:
+            L3 = L3.contiguous()
+        self.tri_copy(L3, M, 1.0, 1, out=job["tall"][b0:b0 + L3.shape[0], Mp:])
+        return L3.shape[0]
+
+    def solve_upper_run(self, job: dict, robust: bool = False, beside_fill: bool = False):
+        """Factor and solve what ``solve_upper_put`` / ``solve_upper_put_rhs`` handed over: (U [nb, M, M], info, D [nb, M, M])."""
+        tall, nb, M, Mp = job["tall"], job["nb"], job["M"], job["Mp"]
         info = torch.empty(nb, dtype=torch.int32, device=self.device)
         work = self._get("potrf_work", (nb, 128 * 128), torch.float64)
         flags = (B.POTRF_SUBST if robust else 0) | B.POTRF_RHS_UPPER | self.potrf_flags | (B.POTRF_DIAG_V1 if beside_fill else 0)
         with torch.cuda.device(self.device):
             self._launch("tsvgp_potrf", lambda: self.lib.tsvgp_potrf_solve_f64(
                 tall.data_ptr(), Mp, Mp, nb, 2 * Mp * Mp, info.data_ptr(), work.data_ptr(), Mp, flags, self._stream()))
-        out_shape = tuple(batch_shape) + (M, M)
-        U = self.tri_copy(tall[:, :Mp], M, 1.0, 1).reshape(out_shape)
+        U = self.tri_copy(tall[:, :Mp], M, 1.0, 1)
         Dm = torch.empty((nb, M, M), dtype=torch.float64, device=self.device)
         with torch.cuda.device(self.device):
             B.check(self.lib.tsvgp_flip_transpose_f64(tall[:, Mp:].data_ptr(), Mp, 2 * Mp * Mp, Dm.data_ptr(), M, M * M, M, nb,
                                                       self._stream()), "tsvgp_flip_transpose")
-        return U, info, Dm.reshape(out_shape)
+        return U, info, Dm
 
     def cholesky(self, A: torch.Tensor, inverse: bool = False, overwrite: bool = False, robust: bool = False,
                  scale: float = 1.0, upper_form: bool = False):

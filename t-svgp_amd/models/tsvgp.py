@@ -388,13 +388,19 @@ class t_SVGP(base_SVGP):
         solve = potrf is not None and hasattr(eng, "cholesky_solve_upper") and os.environ.get("TSVGP_POTRF_SOLVE", "1") != "0"
         if solve:
             # the identity of W and the jitter of K9 = K_uu + jitter I (tsvgp.py:270) ride on the pass that hands the matrices to
-            # the factorisation (EStepEngine.cholesky_solve_upper with a list of runs): no assembled batch, no 8 MB copy of K_uu,
-            # no strided additions -- three launches fewer on the chain
-            runs = [(torch.bmm(Lt, K6 @ L), 1.0)]
+            # the factorisation (EStepEngine.solve_upper_put): no assembled batch, no 8 MB copy of K_uu, no strided additions --
+            # three launches fewer on the chain.  What exists before W does -- K9 and both right-hand sides -- is handed over
+            # first, on a chip the shard's fill has not reached yet (three passes of 7 us instead of 20-30 each beside it; the
+            # step does not notice: handed over behind the fill's start it measures the same to 0.03 ms, the fill then runs that
+            # much longer -- one more section in which the fill and the chain trade one for one).
+            job = eng.solve_upper_begin(P_ + n9, M)
+            eng.solve_upper_put_rhs(job, 0, L)
+            if with_k9:
+                eng.solve_upper_put(job, P_, Kzz if Kzz.dim() == 3 else Kzz[None], whiten_jitter)
+                eng.solve_upper_put_rhs(job, P_, Id.expand(n9, M, M))
+            eng.solve_upper_put(job, 0, torch.bmm(Lt, K6 @ L), 1.0)
             if after_w is not None:
                 after_w()  # a small shard's K(X, Z) fill starts here, behind the two GEMMs it would otherwise starve (_step_front)
-            if with_k9:
-                runs.append((Kzz if Kzz.dim() == 3 else Kzz[None], whiten_jitter))
         else:
             batch = torch.empty((P_ + n9, M, M), dtype=torch.float64, device=Kzz.device)
             # (bmm + a strided add of the identity: baddbmm first copies its [P, M, M] addend into the output, 8 MB per latent)
@@ -412,8 +418,7 @@ class t_SVGP(base_SVGP):
         # dependent launches then queue behind the moments kernel's workgroups: 4 ms per call at N = 1e6, the step 0.2 ms slower.)
         Dm = None
         if solve:
-            rhs = [L] + ([Id.expand(n9, M, M)] if n9 else [])
-            both, info_w, sol = eng.cholesky_solve_upper(runs, rhs, robust=robust, **({"beside_fill": True} if beside_fill else {}))
+            both, info_w, sol = eng.solve_upper_run(job, robust=robust, beside_fill=bool(beside_fill))
             infos.append(info_w.reshape(-1).to(torch.int32))
             U_W, Dm, Uinv_W, inv_both = both[:P_], sol[:P_], None, sol
         else:
