@@ -702,6 +702,9 @@ def test_clock_keeper_leaves_on_the_flag_and_on_its_bound(engines):
     eng.clock_keeper, eng.keeper_max_us = -1, 200000.0
     try:
         a = torch.randn(512, 512, dtype=torch.float64, device=dev)
+        a @ a  # (the library's first call loads code objects, which waits for every running kernel: behind a running keeper that
+        #         is a wait for its bound -- the reason the engine's default bound is 4 ms, not this test's 200)
+        torch.cuda.synchronize()
 
         def bridged():
             t = eng.keeper_begin()
@@ -719,3 +722,39 @@ def test_clock_keeper_leaves_on_the_flag_and_on_its_bound(engines):
     for bad in (lambda: lib.tsvgp_keeper_run(None, 10.0, 0, None), lambda: lib.tsvgp_keeper_run(flag.data_ptr(), 0.0, 0, None),
                 lambda: lib.tsvgp_keeper_run(flag.data_ptr(), 2.0e6, 0, None), lambda: lib.tsvgp_keeper_signal(None, 1, None)):
         assert bad() == 1  # TSVGP_EINVAL
+
+
+def test_tri_copy_shift_and_the_runs_form_of_factor_and_solve(engines):
+    """tsvgp_tri_copy_shift_f64 (the copy / triangle / index reversal of tsvgp_tri_copy_f64 with a shift of the diagonal, flip = 3: a
+    plain copy) against NumPy, and ``EStepEngine.cholesky_solve_upper`` fed with runs (matrices, shift) -- K_uu + jitter I of reference
+    src/models/tsvgp.py:270 and I + L^T K L of src/util.py:171-172 without an assembled batch -- against the same call on the
+    batch assembled by hand: bit for bit (the shift is the same addition, made in another kernel)."""
+    eng = engines[torch.float64]
+    rng = np.random.RandomState(5)
+    for M in (96, 128, 200):
+        A = rng.randn(2, M, M)
+        At = torch.as_tensor(A, device="cuda:0")
+        J = np.eye(M)[::-1]
+        for flip, ref in ((0, np.tril(A) * 0.5), (1, np.triu(J @ A @ J) * 0.5), (2, (J @ A @ J) * 0.5), (3, A * 0.5)):
+            got = eng.tri_copy(At, M, 0.5, flip, diag_add=0.25).cpu().numpy()
+            want = ref + 0.25 * np.eye(M)
+            assert np.array_equal(got, want), (M, flip)
+        # factor and solve: runs against the assembled batch
+        X = rng.randn(3, M, M + 5)
+        S = X @ X.transpose(0, 2, 1) / M
+        L = np.tril(rng.randn(3, M, M))
+        St, Lt_ = torch.as_tensor(S, device="cuda:0"), torch.as_tensor(L, device="cuda:0")
+        batch = St.clone()
+        batch[:2].diagonal(dim1=-2, dim2=-1).add_(1.0)
+        batch[2:].diagonal(dim1=-2, dim2=-1).add_(1e-3)
+        U0, i0, D0 = eng.cholesky_solve_upper(batch, Lt_)
+        U1, i1, D1 = eng.cholesky_solve_upper([(St[:2], 1.0), (St[2:], 1e-3)], [Lt_[:1], Lt_[1:]])
+        assert int(i0.abs().sum()) == 0 and int(i1.abs().sum()) == 0
+        assert torch.equal(U0, U1) and torch.equal(D0, D1)
+        Ur = U1.cpu().numpy()
+        Sref = S + np.stack([np.eye(M), np.eye(M), 1e-3 * np.eye(M)])
+        assert relerr(Ur @ Ur.transpose(0, 2, 1), Sref) < 1e-13
+        assert relerr(Ur @ D1.cpu().numpy(), L.transpose(0, 2, 1)) < 1e-10
+    lib = eng.lib
+    assert lib.tsvgp_tri_copy_shift_f64(At.data_ptr(), M, M * M, At.data_ptr(), M, M * M, M, 2, 1.0, 0.0, 4, None) == 1  # TSVGP_EINVAL
+    assert lib.tsvgp_tri_copy_f64(At.data_ptr(), M, M * M, At.data_ptr(), M, M * M, M, 2, 1.0, 3, None) == 1
