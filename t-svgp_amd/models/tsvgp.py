@@ -847,7 +847,8 @@ class t_SVGP(base_SVGP):
                 box = {}
                 ops = self._site_operands(whiten_jitter=jitter, warm_key=warm_key, routes=routes, fork=fork, Kzz=Kzz, K6=K6,
                                           after_w=lambda: box.update(pre=eng.start_fill(X, self._Z(), self.kernel, b_tag=warm_key,
-                                                                                        want=want, routes=routes)))
+                                                                                        want=want, routes=routes)),
+                                          beside_fill=self._fill_outlasts_factorisation(X))
                 pre = box.get("pre")
             else:
                 pre = eng.start_fill(X, self._Z(), self.kernel, b_tag=warm_key, want=want, routes=routes)
@@ -868,6 +869,14 @@ class t_SVGP(base_SVGP):
     KEEPER_MIN_NM = int(os.environ.get("TSVGP_KEEPER_MIN_NM", "50000000"))  # N * M from which the M x M sections get a clock keeper
     FILL_INLINE_MAX_NM = int(os.environ.get("TSVGP_FILL_INLINE_MAX_NM", "0"))  # N * M up to which the fill runs in line in front of the moments
     LATE_FILL_MAX_NM = int(os.environ.get("TSVGP_LATE_FILL_MAX_NM", "300000000"))  # N * M up to which the fill starts behind W's GEMMs
+
+    def _fill_outlasts_factorisation(self, X) -> bool:
+        """A late fill of at least ~1.6 GB (0.4 ms and more) covers the whole factor-and-solve call of the prelude: round 4's block
+        step, whose kernels share a CU with the fill's workgroups, is then the faster one (EStepEngine.cholesky_solve_upper,
+        ``beside_fill``); measured, replayed steps on one box: 250 000 x 1024 fp64 9.90-9.98 -> 9.75-9.84 ms, 125 000 x 1024
+        fp64 5.65 -> 5.63 (kept on the default step), 125 000 x 1024 fp32 3.59 -> 3.62 (worse)."""
+        esize = 8 if self.compute_dtype == torch.float64 else 4
+        return X.shape[0] * self.num_inducing * esize >= 1_600_000_000
 
     def _late_fill(self, X) -> bool:
         return X.shape[0] * self.num_inducing <= self.LATE_FILL_MAX_NM
