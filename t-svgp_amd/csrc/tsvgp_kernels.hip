@@ -404,6 +404,19 @@ struct FillVec<float, 4> {
     typedef v4f type;
 };
 
+// A streaming store that also writes THROUGH the L2 (sc0 sc1 nt): it leaves no dirty line behind.  Experiment of round 5
+// (TSVGP_FILL_STORE=wt): every kernel boundary of the M x M chain that runs beside the fill writes the L2s back -- the XCDs' L2s are
+// not coherent with each other -- and with plain or nt stores that write-back finds the fill's dirty lines.
+template <typename V>
+__device__ __forceinline__ void store_write_through(V* p, V v) {
+    if constexpr (sizeof(V) == 16) {
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(p), "v"(v) : "memory");
+    } else {
+        static_assert(sizeof(V) == 8, "8- or 16-byte vectors");
+        asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1 nt" ::"v"(p), "v"(v) : "memory");
+    }
+}
+
 template <typename T, int KIND, int DT, int CPT = 2>
 __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, TSVGP_FILL_MAXWAVES))) void se_fill_kernel(
     const T* __restrict__ X, const T* __restrict__ Z, const T* __restrict__ inv_ls, FillBatch<T> var, T* __restrict__ K,
@@ -542,7 +555,9 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(1, TSV
 #ifdef TSVGP_EXP_NOSTORE  // ablation switch: the arithmetic alone (the store never executes, the compiler cannot know)
                 if (out[0] == T(-1)) *reinterpret_cast<vec_t*>(Kp + (int64_t)rr * ldk) = out;
 #else
-                if (stream_out)
+                if (stream_out == 2)
+                    store_write_through(reinterpret_cast<vec_t*>(Kp + (int64_t)rr * ldk), out);
+                else if (stream_out)
                     __builtin_nontemporal_store(out, reinterpret_cast<vec_t*>(Kp + (int64_t)rr * ldk));
                 else
                     *reinterpret_cast<vec_t*>(Kp + (int64_t)rr * ldk) = out;
@@ -4045,7 +4060,8 @@ int kernel_fill(int kind, const T* X, const T* Z, const T* inv_ls, const T* vari
 #ifdef TSVGP_FILL_STREAM  // experiment builds (tools/exp_fill_nt.py, tools/ab_builds.sh): 0 / 1 for every launch
     const int stream_out = TSVGP_FILL_STREAM;
 #else
-    const int stream_out = (double)rows_pad * (double)ldk * sizeof(T) * P >= 512.0 * 1024 * 1024;
+    static const int store_wt = [] { const char* e = getenv("TSVGP_FILL_STORE"); return e && e[0] == 'w' ? 1 : 0; }();
+    const int stream_out = (double)rows_pad * (double)ldk * sizeof(T) * P >= 512.0 * 1024 * 1024 ? 1 + store_wt : 0;
 #endif
 #define TSVGP_FILL_LAUNCH(KIND_, DT_)                                                                                        \
     do {                                                                                                                     \
