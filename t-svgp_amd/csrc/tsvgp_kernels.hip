@@ -227,7 +227,7 @@ __device__ __forceinline__ void mma_chunk_krow(typename Mfma<T>::acc_t (&acc)[2]
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Likelihood maps (fp64 regardless of T).  Restates gpflow.likelihoods.{Gaussian,Bernoulli}.variational_expectations
+// Likelihood maps (fp64; round 5: the Bernoulli quadrature of fp32 N-arrays in fp32, bern_sums_f below).  Restates gpflow.likelihoods.{Gaussian,Bernoulli}.variational_expectations
 // and its tf.GradientTape derivative (reference src/models/tsvgp.py:256-263).
 // ---------------------------------------------------------------------------------------------------------------
 __device__ const double GH_X[10] = {  // positive nodes of 20-pt Gauss-Hermite, times sqrt(2)
@@ -268,6 +268,54 @@ __device__ __forceinline__ void bern_sums(double m, double sd, bool y1, int i0, 
         av += w * lp;
         a0 += w * dl;
         a1 -= w * dl * z;
+    }
+}
+
+// The same sums in fp32, for the fp32 N-arrays (round 5): mean and variance arrive with 1e-6 of relative error from the fp32 MFMA
+// sums, and the fp64 quadrature -- 20 x (erf, exp, log, a division) per row on four waves per CU -- was 0.30 ms of the 8.0 ms fp32
+// moments kernel at N = 1e6 (profiles/r05_lik_split_lab.txt).  The class probability is formed from erfc of the signed argument,
+// never as 1 - p: p saturates at 1 - 1e-3, where 1 - p in fp32 would keep four digits.
+__device__ const float GH_XF[10] = {3.46964157e-01f, 1.04294535e+00f, 1.74524732e+00f, 2.45866361e+00f, 3.18901482e+00f,
+                                    3.94396735e+00f, 4.73458133e+00f, 5.57873881e+00f, 6.51059016e+00f, 7.61904854e+00f};
+__device__ const float GH_WF[10] = {2.60793063e-01f, 1.61739334e-01f, 6.15063721e-02f, 1.39978374e-02f, 1.83010313e-03f,
+                                    1.28826280e-04f, 4.40212109e-06f, 6.12749026e-08f, 2.48206236e-10f, 1.25780067e-13f};
+__device__ __forceinline__ void bern_point_f(float f, bool y1, float& lp, float& dl) {
+    const float jit = 1e-3f;
+    const float pp = 0.5f * erfcf((y1 ? -f : f) * 0.70710678f) * (1.0f - 2.0f * jit) + jit;  // p(y | f), >= 1e-3
+    const float dp = (1.0f - 2.0f * jit) * 0.39894228f * expf(-0.5f * f * f);
+    lp = logf(pp);
+    dl = (y1 ? dp : -dp) / pp;
+}
+__device__ __forceinline__ void bern_sums_f(float m, float sd, bool y1, int i0, int i1, float& a0, float& a1, float& av) {
+    a0 = a1 = av = 0.0f;
+#pragma unroll 1
+    for (int i = i0; i < i1; ++i) {
+        const float z = GH_XF[i], w = GH_WF[i];
+        float lp, dl;
+        bern_point_f(m + sd * z, y1, lp, dl);
+        av += w * lp;
+        a0 += w * dl;
+        a1 += w * dl * z;
+        bern_point_f(m - sd * z, y1, lp, dl);
+        av += w * lp;
+        a0 += w * dl;
+        a1 -= w * dl * z;
+    }
+}
+// The quadrature in the arithmetic of the N-arrays' type T (TSVGP_BERN_F64=1 at build time: fp64 for both, as up to round 5)
+#ifndef TSVGP_BERN_F64
+#define TSVGP_BERN_F64 0
+#endif
+template <typename T>
+__device__ __forceinline__ void bern_sums_t(double m, double sd, bool y1, int i0, int i1, double& a0, double& a1, double& av) {
+    if constexpr (sizeof(T) == 4 && !TSVGP_BERN_F64) {
+        float b0, b1, bv;
+        bern_sums_f((float)m, (float)sd, y1, i0, i1, b0, b1, bv);
+        a0 = (double)b0;
+        a1 = (double)b1;
+        av = (double)bv;
+    } else {
+        bern_sums(m, sd, y1, i0, i1, a0, a1, av);
     }
 }
 
@@ -1029,7 +1077,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void panel_kernel(PanelArgs<T> a) {
                     // threads that staged a row take five node pairs each and add up
                     double a0, a1, av;
                     const double sd = sqrt(live ? v : 1.0);
-                    bern_sums(live ? mu : 0.0, sd, live && (double)a.Y[n * a.P + p] == 1.0, skh * 5, skh * 5 + 5, a0, a1, av);
+                    bern_sums_t<T>(live ? mu : 0.0, sd, live && (double)a.Y[n * a.P + p] == 1.0, skh * 5, skh * 5 + 5, a0, a1, av);
                     a0 += __shfl_xor(a0, 1);
                     a1 += __shfl_xor(a1, 1);
                     av += __shfl_xor(av, 1);
@@ -1717,7 +1765,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void panel1_kernel(PanelArgs<T> a) {
             if ((a.lik & 0xFF) == TSVGP_LIK_BERNOULLI) {
                 double a0, a1, av;
                 const double sd = sqrt(live ? v : 1.0);
-                bern_sums(live ? mu : 0.0, sd, live && (double)a.Y[n * a.P + p] == 1.0, skh * 5, skh * 5 + 5, a0, a1, av);
+                bern_sums_t<T>(live ? mu : 0.0, sd, live && (double)a.Y[n * a.P + p] == 1.0, skh * 5, skh * 5 + 5, a0, a1, av);
                 a0 += __shfl_xor(a0, 1);
                 a1 += __shfl_xor(a1, 1);
                 av += __shfl_xor(av, 1);
@@ -1810,7 +1858,7 @@ __global__ __launch_bounds__(NTHREADS) void lik_map_kernel(const T* __restrict__
         if ((lik & 0xFF) == TSVGP_LIK_BERNOULLI) {
             double a0, a1, av;
             const double sd = sqrt(v);
-            bern_sums(mu, sd, live && (double)Y[n * P + p] == 1.0, skh * 5, skh * 5 + 5, a0, a1, av);
+            bern_sums_t<T>(mu, sd, live && (double)Y[n * P + p] == 1.0, skh * 5, skh * 5 + 5, a0, a1, av);
             a0 += __shfl_xor(a0, 1);
             a1 += __shfl_xor(a1, 1);
             av += __shfl_xor(av, 1);
