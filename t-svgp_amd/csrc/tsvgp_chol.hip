@@ -377,7 +377,7 @@ __global__ __launch_bounds__(D2_THREADS) void potrf_diag2_kernel(double* __restr
         }
         D2_STAMP(8 + 16 * s + 7)
     }
-    if (t == 0 && bad != 0 && info[b] == 0) info[b] = k * NB + bad;
+    if (t == 0 && (k == 0 || (bad != 0 && info[b] == 0))) info[b] = bad != 0 ? k * NB + bad : 0;  // (block 0 initialises the status word)
     D2_STAMP(1)
 }
 

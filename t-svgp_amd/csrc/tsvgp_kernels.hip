@@ -3232,7 +3232,8 @@ __global__ __launch_bounds__(CH_THREADS) void potrf_diag_kernel(double* __restri
             v[1] = (c + 1 <= r) ? S[r * CH_LD + c + 1] : 0.0;
             *reinterpret_cast<v2d*>(Ab + (size_t)r * lda + c) = v;
         }
-        if (t == 0 && fail != 0 && info[b] == 0) info[b] = fail;
+        // (block 0 initialises the status word -- no memset launch in front of the factorisation -- later blocks keep the first failure)
+        if (t == 0 && (k == 0 || (fail != 0 && info[b] == 0))) info[b] = fail;
     }
     PSTAMP()
     if constexpr (FUSED) {
@@ -4408,7 +4409,6 @@ int potrf(double* A, int M, int lda, int batch, int64_t stride, int* info, doubl
     if (optin_fused.ensure(reinterpret_cast<const void*>(&potrf_diag_kernel<true>), smem) != TSVGP_OK) return TSVGP_ELAUNCH;
     hipStream_t st = (hipStream_t)stream;
     const int64_t xstride = (int64_t)M * M;
-    if (hipMemsetAsync(info, 0, sizeof(int) * batch, st) != hipSuccess) return TSVGP_ELAUNCH;
     if (inv) {  // the blocks the recursion does not write stay zero
         if ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Xt)) & 15) return TSVGP_EINVAL;
         zero_fill(X, sizeof(double) * xstride * batch, st);
