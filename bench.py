@@ -545,8 +545,12 @@ def main():
         the 20-30 steps of a timed region, showed as +1.2 ms per step (measured: one 39 ms `_site_operands` call in 30,
         38.5 instead of 37.0 ms per step at N = 1e6, 12.6 instead of 11.3 ms at M = 512, kernel times unchanged)."""
 
+        def __init__(self, collected=False):
+            self.collected = collected  # the caller ran gc.collect() in front of its warm-up steps (see the headline region)
+
         def __enter__(self):
-            gc.collect()
+            if not self.collected:
+                gc.collect()
             gc.disable()
 
         def __exit__(self, *exc):
@@ -576,10 +580,17 @@ def main():
         route_gate_ms = (time.perf_counter() - t0) * 1e3
         conds = [float(c) for c in model._cond_cache[1]] if model._cond_cache is not None else None
     n_warm = max(args.warmup, 3 if replayed else 0)  # a graph is captured on the second occurrence of a step
-    for _ in range(n_warm):
-        model.natgrad_step((Xd, Yd), lr=0.8)
+    # Housekeeping that takes the host tens of milliseconds -- the full garbage collection of `timed_region`, the pool of timing
+    # events -- happens IN FRONT of the warm-up steps, not between them and the timed steps: the chip's clock follows its recent load
+    # (profiles/r05_clock_lab.txt), and a 40 ms pause there made the first timed step 2.3 ms slower than the others.  The timed
+    # region itself is unchanged: W untimed steps, barrier + synchronize, K steps, barrier + synchronize.
+    gc.collect()
     if not replayed and hasattr(eng, "reserve_events"):
         eng.reserve_events(2 * 8 * args.steps * max(1, w["P"] if w.get("separate") else 1) + 64)
+    if world > 1:
+        pkg.distributed.reserve_timing(8 * args.steps + 16)
+    for _ in range(n_warm):
+        model.natgrad_step((Xd, Yd), lr=0.8)
     barrier()
     # Every C-ABI launch inside the timed region is bracketed with HIP events on its launch stream (pooled: no event is
     # created inside the region); they cost 0.05-0.1 ms per step (A/B with the collector paused: 11.38 vs 11.44 ms at
@@ -587,10 +598,9 @@ def main():
     eng.profile = None if replayed else {}
     D_ = pkg.distributed
     if world > 1:
-        D_.reserve_timing(8 * args.steps + 16)
         D_.TIMING = []  # HIP events around every collective of the timed steps (pooled; replayed steps take them too: the
         #                 all-reduce sits BETWEEN the two graphs of a step)
-    with timed_region():
+    with timed_region(collected=True):
         t0 = time.perf_counter()
         for _ in range(args.steps):
             model.natgrad_step((Xd, Yd), lr=0.8)
@@ -626,10 +636,11 @@ def main():
 
     def timed_steps(n_warm=2):
         """(seconds for args.steps steps, max over ranks) in the model's current mode, after n_warm untimed steps."""
+        gc.collect()
         for _ in range(n_warm):
             model.natgrad_step((Xd, Yd), lr=0.8)
         barrier()
-        with timed_region():
+        with timed_region(collected=True):
             t0 = time.perf_counter()
             for _ in range(args.steps):
                 model.natgrad_step((Xd, Yd), lr=0.8)
