@@ -999,7 +999,7 @@ class t_SVGP(base_SVGP):
         return D_.all_reduce_max(flags.abs())
 
     # -- hipGraph replay of the step (launch-bound problem sizes) -------------------------------------------------
-    GRAPH_AUTO_MAX_NM = 200_000_000  # "auto": replay when N * M is at most this (tools/bench_graph_sizes.py, below)
+    GRAPH_AUTO_MAX_NM = int(os.environ.get("TSVGP_GRAPH_AUTO_MAX_NM", "200000000"))  # "auto": replay when N * M is at most this (tools/bench_graph_sizes.py, below)
     # A captured step forks the K(X, Z) fill and the epilogue operands onto the side stream from this N * M on; below it they
     # are captured in line: the cross-stream edges cost a replay 0.12-0.15 ms, more than the overlap gains at launch-bound
     # sizes -- replayed step, forked / in line (gpurun_out/r3m/c1_routes.txt, graph_fork.txt, graph_fork_sizes.txt):
